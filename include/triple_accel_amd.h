@@ -1,0 +1,194 @@
+/*
+ * triple_accel_amd.h -- C ABI of the MI355X-native edit-distance engine.
+ *
+ * Drop-in boundary for triple_accel's hot path.  The reference
+ * (Rust, /root/reference) has no FFI of its own; each entry point below names the
+ * reference function (file:line) it replaces, and INTEGRATION.md shows the Rust
+ * `extern "C"` shim that maps the reference's public signatures onto it.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; every function returns a ta_status.
+ *   - Rust panics become status codes (the shim re-raises them): TA_ERR_LEN_MISMATCH,
+ *     TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS.  Option::None becomes the sentinel TA_NONE
+ *     (a real distance never reaches it: the reference clamps k to a true upper bound,
+ *     src/levenshtein.rs:734-757).
+ *   - `*_dev` / `*_batch` functions take DEVICE (HBM) pointers and a hipStream_t passed as
+ *     void*; they enqueue work and return without synchronising unless stated.  The plain
+ *     functions take HOST pointers, run on the current HIP device and synchronise.
+ *   - Device string blobs must be readable for TA_BLOB_SLACK bytes past their last byte
+ *     (kernels fetch 16-byte pieces).
+ *   - There is NO CPU fallback: with no HIP device every compute entry point returns
+ *     TA_ERR_HIP.
+ */
+#ifndef TRIPLE_ACCEL_AMD_H
+#define TRIPLE_ACCEL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_NONE 0xFFFFFFFFu
+#define TA_BLOB_SLACK 16
+
+typedef enum {
+    TA_OK = 0,
+    TA_ERR_LEN_MISMATCH = 1, /* assert!(a.len() == b.len())     src/hamming.rs:38,318 */
+    TA_ERR_NULL_BYTE = 2,    /* check_no_null_bytes panic        src/lib.rs:237-243    */
+    TA_ERR_BAD_COSTS = 3,    /* EditCosts::new / check_search    src/levenshtein.rs:44-52,67-71 */
+    TA_ERR_HIP = 4,          /* HIP runtime failure / no device (no CPU fallback) */
+    TA_ERR_ARG = 5,          /* null pointer, size over the documented limit */
+    TA_ERR_UNSUPPORTED = 6,  /* trace_on=true (not on the GPU path yet) */
+    TA_ERR_CAPACITY = 7      /* caller-provided match buffer too small; *n_out holds the need */
+} ta_status;
+
+/* EditCosts, src/levenshtein.rs:20-26 (fields are private there; built via new / the consts) */
+typedef struct {
+    uint8_t mismatch_cost;
+    uint8_t gap_cost;
+    uint8_t start_gap_cost;
+    uint8_t has_transpose;  /* Option<u8>::is_some() */
+    uint8_t transpose_cost;
+} ta_edit_costs;
+
+/* Match, src/lib.rs:135-142 (start inclusive, end exclusive) */
+typedef struct {
+    uint64_t start;
+    uint64_t end;
+    uint32_t k;
+    uint32_t pad_;
+} ta_match;
+
+/* SearchType, src/lib.rs:171-174 */
+typedef enum { TA_SEARCH_ALL = 0, TA_SEARCH_BEST = 1 } ta_search_type;
+
+/* LEVENSHTEIN_COSTS / RDAMERAU_COSTS, src/levenshtein.rs:76-89 */
+ta_edit_costs ta_levenshtein_costs(void);
+ta_edit_costs ta_rdamerau_costs(void);
+/* EditCosts::new validation, src/levenshtein.rs:38-60: TA_OK or TA_ERR_BAD_COSTS */
+int ta_edit_costs_new(uint8_t mismatch, uint8_t gap, uint8_t start_gap, int has_transpose, uint8_t transpose,
+                      ta_edit_costs *out);
+/* check_search, src/levenshtein.rs:67-71 */
+int ta_edit_costs_check_search(const ta_edit_costs *c);
+
+/* ---- runtime ------------------------------------------------------------------------- */
+const char *ta_version(void);
+const char *ta_status_str(int status);
+/* number of visible HIP devices (0 => every compute call returns TA_ERR_HIP) */
+int ta_device_count(void);
+/* text of the last HIP error seen on this thread ("" if none) */
+const char *ta_last_error(void);
+
+/* The dispatcher arithmetic of levenshtein_simd_k_with_opts, src/levenshtein.rs:731-791:
+ * clamped max_k, unit_k, and the cell width (8/16/32 bits) the reference would pick.
+ * The GPU kernels keep u8/u16/u32 *semantics* by this rule (DESIGN.md "cell width"). */
+typedef struct {
+    uint32_t max_k;
+    uint32_t unit_k;
+    uint32_t cell_bits;       /* 8, 16 or 32 */
+    uint32_t ref_lanes;       /* 32/64/128/256 for the u8 Jewel types, 0 for the Vec-backed ones */
+} ta_lev_select;
+int ta_levenshtein_select(size_t a_len, size_t b_len, uint32_t k, const ta_edit_costs *costs, ta_lev_select *out);
+
+/* What the last distance batch launched on this thread used (for tests / debug logging;
+ * the analogue of the reference's `debug` feature println, src/levenshtein.rs:840-847). */
+typedef struct {
+    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup */
+    uint32_t diags_per_lane;  /* D */
+    uint32_t lanes_per_pair;  /* L */
+    uint32_t pairs_per_wave;
+    uint32_t band_offset;     /* o: diagonal index of d = 0 */
+    uint32_t cell_bits;       /* width class chosen by the reference's rule for the batch's max lengths */
+    uint32_t affine;
+    uint32_t transpose;
+    uint32_t grid;
+    uint32_t lds_bytes;
+} ta_launch_info;
+int ta_last_launch_info(ta_launch_info *out);
+
+/* ---- single-call host API (the reference's function set) ------------------------------- */
+
+/* hamming(a, b), src/hamming.rs:390 -> :317 -> :36-47 */
+int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
+
+/* levenshtein_simd_k_with_opts(a, b, k, trace_on, costs), src/levenshtein.rs:714-720.
+ * *out = distance, or TA_NONE when the distance exceeds k.  trace_on != 0 -> TA_ERR_UNSUPPORTED. */
+int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                                    uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out);
+/* levenshtein_simd_k, src/levenshtein.rs:677-684 */
+int ta_levenshtein_simd_k(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k, uint32_t *out);
+/* levenshtein, src/levenshtein.rs:1397 ; rdamerau :1419 */
+int ta_levenshtein(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
+int ta_rdamerau(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
+/* levenshtein_exp :1445, levenshtein_exp_with_opts :1480 (trace_on unsupported), rdamerau_exp :1516 */
+int ta_levenshtein_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
+int ta_levenshtein_exp_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                                 int trace_on, const ta_edit_costs *costs, uint32_t *out);
+int ta_rdamerau_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
+
+/* levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored),
+ * src/levenshtein.rs:1911-1918.  The lazy iterator is materialised: *out is library-owned
+ * (release with ta_free), *n_out its length. */
+int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
+                                         const uint8_t *haystack, size_t haystack_len,
+                                         uint32_t k, int search_type, const ta_edit_costs *costs, int anchored,
+                                         ta_match **out, size_t *n_out);
+/* levenshtein_search, src/levenshtein.rs:2508 (k = ceil(n/2), Best, LEVENSHTEIN_COSTS, unanchored) */
+int ta_levenshtein_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                          ta_match **out, size_t *n_out);
+/* hamming_search_simd_with_opts, src/hamming.rs:454 ; hamming_search :588 */
+int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
+                                     const uint8_t *haystack, size_t haystack_len,
+                                     uint32_t k, int search_type, ta_match **out, size_t *n_out);
+int ta_hamming_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                      ta_match **out, size_t *n_out);
+void ta_free(void *p);
+
+/* ---- batch API on device-resident data (new surface; N = 1 equals the single-call form) -- */
+
+/* String i of a batch is blob[off[i] .. off[i+1]) (CSR, n+1 offsets, device memory), or, when
+ * off == NULL, blob[i*stride .. i*stride+len) (fixed length `len`, byte stride `stride`). */
+typedef struct {
+    const uint8_t *blob;     /* device */
+    const uint64_t *off;     /* device, n+1 entries, or NULL for the strided form */
+    uint64_t stride;         /* strided form only */
+    uint64_t len;            /* strided form only */
+    uint64_t max_len;        /* upper bound on any string length (CSR form; 0 = let the library measure it) */
+} ta_strings;
+
+/* N x levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) -> out[i] (u32 or TA_NONE). */
+int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k,
+                           const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
+/* N x levenshtein_exp_with_opts(a_i, b_i, false, costs): doubling k from 30 over the still-unresolved
+ * subset (src/levenshtein.rs:1480-1494).  Synchronises the stream between rounds. */
+int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
+                             const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
+/* N x hamming(a_i, b_i); out[i] = TA_NONE where the lengths differ (Rust: panic). */
+int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out_dev, void *stream);
+
+/* All-mode hits of one haystack shard resident in HBM (levenshtein_search_simd_with_opts with
+ * SearchType::All; the order-dependent Best fold is a sequential host pass, ta_search_fold_best).
+ * `base` is added to start/end (global offset of this shard inside a larger haystack);
+ * `emit_from` suppresses hits whose end <= emit_from (left-halo positions).
+ * hits_dev holds up to `cap` records sorted by end; *count_dev receives the total found
+ * (may exceed cap => TA_ERR_CAPACITY after sync).  Synchronises the stream. */
+int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
+                              const uint8_t *haystack_dev, size_t haystack_len,
+                              uint32_t k, const ta_edit_costs *costs, int anchored,
+                              uint64_t base, uint64_t emit_from,
+                              ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
+int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
+                          const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                          uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
+
+/* Sequential Best post-pass over All-mode hits in increasing `end` order (host memory):
+ * running curr_k, overlap fold, final filter (src/levenshtein.rs:1792-1796, 1812-1835;
+ * hamming: src/hamming.rs:122-143 with fold = 0).  In place; returns the new count. */
+size_t ta_search_fold_best(ta_match *hits, size_t n, uint32_t k, int overlap_fold);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -503,3 +503,52 @@ int tao_levenshtein_search_naive_with_opts(const uint8_t *needle, size_t needle_
     *out = mv.p; *n_out = mv.n;
     return 0;
 }
+
+/* ---------------------------------------------------------------- batch drivers (bench/test convenience)
+ * Plain loops over the single-pair restatements above; `threads` > 1 splits the batch with OpenMP. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+void tao_levenshtein_k_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                             size_t n, uint32_t k, const tao_costs *costs, uint32_t *out, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (long long i = 0; i < (long long)n; i++) {
+        out[i] = tao_levenshtein_simd_k_with_opts(a_blob + a_off[i], (size_t)(a_off[i + 1] - a_off[i]),
+                                                  b_blob + b_off[i], (size_t)(b_off[i + 1] - b_off[i]),
+                                                  k, 0, costs, NULL, NULL);
+    }
+}
+
+void tao_levenshtein_exp_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                               size_t n, const tao_costs *costs, uint32_t *out, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (long long i = 0; i < (long long)n; i++) {
+        out[i] = tao_levenshtein_exp_with_opts(a_blob + a_off[i], (size_t)(a_off[i + 1] - a_off[i]),
+                                               b_blob + b_off[i], (size_t)(b_off[i + 1] - b_off[i]),
+                                               0, costs, NULL, NULL);
+    }
+}
+
+void tao_hamming_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                       size_t n, uint32_t *out, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (long long i = 0; i < (long long)n; i++) {
+        out[i] = tao_hamming_naive(a_blob + a_off[i], (size_t)(a_off[i + 1] - a_off[i]),
+                                   b_blob + b_off[i], (size_t)(b_off[i + 1] - b_off[i]));
+    }
+}
+
+int tao_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -119,6 +119,16 @@ uint32_t tao_default_search_k(size_t needle_len);
  * the credited unit of work for GCUPS. */
 uint64_t tao_band_cells(size_t a_len, size_t b_len, uint32_t k, const tao_costs *costs);
 
+/* Batch drivers over CSR data (host memory): plain loops over the functions above, optionally
+ * split over `threads` OpenMP threads (bench.py's cpu_baseline leg and the large parity tests). */
+void tao_levenshtein_k_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                             size_t n, uint32_t k, const tao_costs *costs, uint32_t *out, int threads);
+void tao_levenshtein_exp_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                               size_t n, const tao_costs *costs, uint32_t *out, int threads);
+void tao_hamming_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                       size_t n, uint32_t *out, int threads);
+int tao_max_threads(void);
+
 void tao_free(void *p);
 
 #ifdef __cplusplus

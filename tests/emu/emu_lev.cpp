@@ -1,0 +1,46 @@
+// emu_lev.cpp -- runs the band-wavefront kernel body on the host, 64 lanes in lock-step.
+// TESTS ONLY (see emu_wave.h).  Built by tests/emu/Makefile into tests/emu/libta_emu.so.
+#include <stdlib.h>
+#include <string.h>
+
+#include "emu_wave.h"
+#include "lev_band_body.h"
+#include "lev_plan.h"
+
+using namespace ta;
+
+template <int D> static void run_d(const LevParams &P, bool affine, bool trans, uint32_t waves) {
+    uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
+    for (uint32_t w = 0; w < waves; w++) {
+        if (affine && trans) LevBand<EmuWave, D, true, true>::run(P, w, lds);
+        else if (affine) LevBand<EmuWave, D, true, false>::run(P, w, lds);
+        else if (trans) LevBand<EmuWave, D, false, true>::run(P, w, lds);
+        else LevBand<EmuWave, D, false, false>::run(P, w, lds);
+    }
+    free(lds);
+}
+
+extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                            uint32_t n, uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, int has_t, uint32_t tc,
+                            uint64_t max_len, int force_D, int force_L, int force_affine, uint32_t *out,
+                            uint32_t *plan_out /* D, L, PW, u, o */) {
+    LevPlan pl = lev_make_plan(k, gc, sg, max_len, force_D, force_L);
+    if (!pl.ok) return 1;
+    LevParams P;
+    P.a = StrView{a_blob, a_off, 0, 0};
+    P.b = StrView{b_blob, b_off, 0, 0};
+    P.subset = nullptr; P.out = out; P.n = n; P.k = k;
+    P.mc = mc; P.gc = gc; P.sg = sg; P.tc = tc;
+    P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave;
+    if (plan_out) { plan_out[0] = pl.D; plan_out[1] = pl.L; plan_out[2] = pl.PW; plan_out[3] = pl.u; plan_out[4] = pl.o; }
+    uint32_t waves = (n + pl.PW - 1) / pl.PW;
+    bool affine = sg > 0 || force_affine, trans = has_t != 0;
+    switch (pl.D) {
+#define CASE(d) case d: run_d<d>(P, affine, trans, waves); break;
+        CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(28)
+        CASE(32) CASE(34) CASE(40) CASE(48) CASE(56) CASE(66)
+#undef CASE
+        default: return 2;
+    }
+    return 0;
+}

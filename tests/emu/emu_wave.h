@@ -1,0 +1,109 @@
+// emu_wave.h -- 64-lane lock-step host emulation of the wave policy (triple_accel_amd/csrc/wave.h).
+//
+// TESTS ONLY.  Lets the kernel bodies (lev_band_body.h, ...) run in a GPU-less container so
+// their index math can be checked against the oracle.  Never linked into the product library,
+// never a fallback: the product's compute entry points fail with TA_ERR_HIP without a GPU.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "wave.h"
+
+namespace ta {
+
+struct VB {
+    bool v[64];
+};
+struct V32 {
+    uint32_t v[64];
+    V32() {}
+    V32(uint32_t x) { for (int i = 0; i < 64; i++) v[i] = x; }
+};
+struct VP {
+    const uint8_t *v[64];
+};
+
+#define TA_EMU_BIN(op)                                                                    \
+    static inline V32 operator op(const V32 &a, const V32 &b) {                           \
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+TA_EMU_BIN(+) TA_EMU_BIN(-) TA_EMU_BIN(*) TA_EMU_BIN(^) TA_EMU_BIN(|) TA_EMU_BIN(&)
+#undef TA_EMU_BIN
+static inline V32 operator>>(const V32 &a, int s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >> s; return r; }
+static inline V32 operator<<(const V32 &a, int s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] << s; return r; }
+#define TA_EMU_CMP(op)                                                                    \
+    static inline VB operator op(const V32 &a, const V32 &b) {                            \
+        VB r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+TA_EMU_CMP(==) TA_EMU_CMP(!=) TA_EMU_CMP(<) TA_EMU_CMP(<=) TA_EMU_CMP(>) TA_EMU_CMP(>=)
+#undef TA_EMU_CMP
+static inline VB operator&(const VB &a, const VB &b) { VB r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+static inline VB operator|(const VB &a, const VB &b) { VB r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+static inline VB operator!(const VB &a) { VB r; for (int i = 0; i < 64; i++) r.v[i] = !a.v[i]; return r; }
+
+struct EmuWave {
+    using U32 = V32;
+    using Bool = VB;
+    using Ptr = VP;
+
+    static U32 lane() { V32 r; for (int i = 0; i < 64; i++) r.v[i] = i; return r; }
+    static U32 splat(uint32_t x) { return V32(x); }
+    static U32 sel(const Bool &c, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+    static U32 umin(const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+    static U32 umin3(const U32 &a, const U32 &b, const U32 &c) { return umin(umin(a, b), c); }
+    static U32 udiv(const U32 &a, uint32_t d) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] / d; return r; }
+    template <int N> static U32 alignbyte(const U32 &hi, const U32 &lo) {
+        V32 r;
+        for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> (8 * N));
+        return r;
+    }
+    static U32 mul24(const U32 &a, uint32_t b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & 0xffffffu) * (b & 0xffffffu); return r; }
+    static U32 byte_of(const U32 &x, int n) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] >> (8 * n)) & 0xffu; return r; }
+    static U32 bfi(uint32_t mask, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask); return r; }
+    static U32 from_lower(const U32 &x, const U32 &fill) { V32 r; r.v[0] = fill.v[0]; for (int i = 1; i < 64; i++) r.v[i] = x.v[i - 1]; return r; }
+    static U32 from_upper(const U32 &x, const U32 &fill) { V32 r; r.v[63] = fill.v[63]; for (int i = 0; i < 63; i++) r.v[i] = x.v[i + 1]; return r; }
+    static U32 shfl(const U32 &x, const U32 &src) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[src.v[i] & 63]; return r; }
+    static Ptr shfl_ptr(const Ptr &p, const U32 &src) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[src.v[i] & 63]; return r; }
+    static bool any(const Bool &c) { for (int i = 0; i < 64; i++) if (c.v[i]) return true; return false; }
+    static uint32_t wave_max(const U32 &x) { uint32_t m = 0; for (int i = 0; i < 64; i++) if (x.v[i] > m) m = x.v[i]; return m; }
+
+    static void load_str(const StrView &s, const U32 &idx, const Bool &valid, Ptr &p, U32 &len) {
+        for (int i = 0; i < 64; i++) {
+            if (valid.v[i]) {
+                if (s.off) {
+                    p.v[i] = s.blob + s.off[idx.v[i]];
+                    len.v[i] = (uint32_t)(s.off[idx.v[i] + 1] - s.off[idx.v[i]]);
+                } else {
+                    p.v[i] = s.blob + (uint64_t)idx.v[i] * s.stride;
+                    len.v[i] = (uint32_t)s.len;
+                }
+            } else {
+                p.v[i] = s.blob;
+                len.v[i] = 0;
+            }
+        }
+    }
+    static U32 load_u32(const uint32_t *p, const U32 &idx, const Bool &valid, uint32_t dflt) {
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = valid.v[i] ? p[idx.v[i]] : dflt; return r;
+    }
+    static void store_u32(uint32_t *p, const U32 &idx, const U32 &v, const Bool &pred) {
+        for (int i = 0; i < 64; i++) if (pred.v[i]) p[idx.v[i]] = v.v[i];
+    }
+    static Ptr ptr_add(const Ptr &p, const U32 &off) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] + off.v[i]; return r; }
+    static Ptr sel_ptr(const Bool &c, const Ptr &a, const Ptr &b) { VP r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+
+    struct Q128V { Q128 v[64]; };
+    static Q128V gload16(const Ptr &p, const Bool &pred) {
+        Q128V q;
+        for (int i = 0; i < 64; i++) {
+            q.v[i] = Q128{0, 0, 0, 0};
+            if (pred.v[i]) memcpy(&q.v[i], p.v[i], 16);
+        }
+        return q;
+    }
+    static void lds_store16(uint8_t *lds, const U32 &off, const Q128V &q, const Bool &pred) {
+        for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &q.v[i], 16);
+    }
+    static U32 lds_u8(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = lds[off.v[i]]; return r; }
+    static void lds_wave_sync() {}
+};
+
+}  // namespace ta

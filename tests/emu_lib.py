@@ -1,0 +1,51 @@
+"""ctypes binding of the host emulation of the kernel bodies (tests/emu/libta_emu.so). TESTS ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "emu", "libta_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s"])
+        L = C.CDLL(_SO)
+        L.emu_lev_band.restype = C.c_int
+        L.emu_lev_band.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def pack(strings):
+    """list of bytes -> (blob uint8 array with 16 B slack, uint64 offsets)."""
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    blob = np.zeros(int(off[-1]) + 16, dtype=np.uint8)
+    if off[-1]:
+        blob[:int(off[-1])] = np.frombuffer(b"".join(strings), dtype=np.uint8)
+    return blob, off
+
+
+def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False):
+    """-> (list of dist|None, plan dict)"""
+    n = len(a_list)
+    ab, ao = pack(a_list)
+    bb, bo = pack(b_list)
+    out = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    plan = np.zeros(5, dtype=np.uint32)
+    max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
+    mc, gc, sg, tc = costs
+    rc = lib().emu_lev_band(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, mc, gc, sg,
+                            0 if tc is None else 1, 0 if tc is None else tc, max_len, force_D, force_L,
+                            int(force_affine), out.ctypes.data, plan.ctypes.data)
+    if rc:
+        raise RuntimeError("emu_lev_band rc=%d" % rc)
+    res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
+    return res, dict(D=int(plan[0]), L=int(plan[1]), PW=int(plan[2]), u=int(plan[3]), o=int(plan[4]))

@@ -72,6 +72,14 @@ def lib():
         L.tao_levenshtein_search_naive_with_opts.restype = C.c_int
         L.tao_default_search_k.argtypes = [sz]; L.tao_default_search_k.restype = u32
         L.tao_band_cells.argtypes = [sz, sz, u32, cp]; L.tao_band_cells.restype = C.c_uint64
+        for name in ("tao_levenshtein_k_batch",):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, u32, cp, C.c_void_p, C.c_int]
+            getattr(L, name).restype = None
+        L.tao_levenshtein_exp_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, cp, C.c_void_p, C.c_int]
+        L.tao_levenshtein_exp_batch.restype = None
+        L.tao_hamming_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_int]
+        L.tao_hamming_batch.restype = None
+        L.tao_max_threads.argtypes = []; L.tao_max_threads.restype = C.c_int
         L.tao_free.argtypes = [C.c_void_p]; L.tao_free.restype = None
         _lib = L
     return _lib
@@ -207,3 +215,65 @@ def levenshtein_search_naive_with_opts(needle, haystack, k, search_type, costs=L
     if rc:
         raise ValueError("invalid costs for search")
     return _take_matches(mp, n.value)
+
+
+# ---------------------------------------------------------------- batch drivers (numpy CSR in, numpy out)
+def _np():
+    import numpy as np
+    return np
+
+
+def csr_from_list(strings):
+    np = _np()
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    blob = np.zeros(int(off[-1]) + 16, dtype=np.uint8)
+    if off[-1]:
+        blob[:int(off[-1])] = np.frombuffer(b"".join(strings), dtype=np.uint8)
+    return blob, off
+
+
+def csr_from_fixed(arr2d):
+    np = _np()
+    n, length = arr2d.shape
+    blob = np.zeros(n * length + 16, dtype=np.uint8)
+    blob[: n * length] = np.ascontiguousarray(arr2d).reshape(-1)
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length))
+    return blob, off
+
+
+def max_threads():
+    return int(lib().tao_max_threads())
+
+
+def levenshtein_k_batch(a_csr, b_csr, k, costs=LEVENSHTEIN_COSTS, threads=0):
+    """-> uint32 array, 0xFFFFFFFF == None"""
+    np = _np()
+    (ab, ao), (bb, bo) = a_csr, b_csr
+    n = len(ao) - 1
+    out = np.empty(n, dtype=np.uint32)
+    cs = mk_costs(costs)
+    lib().tao_levenshtein_k_batch(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, C.byref(cs),
+                                  out.ctypes.data, threads or max_threads())
+    return out
+
+
+def levenshtein_exp_batch(a_csr, b_csr, costs=LEVENSHTEIN_COSTS, threads=0):
+    np = _np()
+    (ab, ao), (bb, bo) = a_csr, b_csr
+    n = len(ao) - 1
+    out = np.empty(n, dtype=np.uint32)
+    cs = mk_costs(costs)
+    lib().tao_levenshtein_exp_batch(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, C.byref(cs),
+                                    out.ctypes.data, threads or max_threads())
+    return out
+
+
+def hamming_batch(a_csr, b_csr, threads=0):
+    np = _np()
+    (ab, ao), (bb, bo) = a_csr, b_csr
+    n = len(ao) - 1
+    out = np.empty(n, dtype=np.uint32)
+    lib().tao_hamming_batch(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, out.ctypes.data,
+                            threads or max_threads())
+    return out

@@ -1,0 +1,113 @@
+"""Kernel-logic check without a GPU: the band-wavefront kernel body (lev_band_body.h) run as a 64-lane
+host emulation must equal the oracle's scalar banded path bit for bit, for every lane layout (D, L),
+cost family, ragged lengths and multi-chunk strings.  The same body is what hipcc compiles for gfx950."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 3, 0, None), (3, 1, 0, None), (1, 1, 2, None), (2, 1, 2, None),
+         (2, 2, 1, 3), (5, 3, 4, 4)]
+
+
+def oracle(a, b, k, costs):
+    return [O.levenshtein_simd_k_with_opts(x, y, k, False, costs)[0] for x, y in zip(a, b)]
+
+
+def make_pairs(seed, n, maxlen, kmut, swaps):
+    g = Dg.rng(seed)
+    a, b = [], []
+    for i in range(n):
+        la = int(g.integers(0, maxlen + 1))
+        x = Dg.rand_str(g, la)
+        t = i % 4
+        if t == 0:
+            y = Dg.rand_str(g, int(g.integers(0, maxlen + 1)))
+        elif t == 1:
+            y = x
+        else:
+            y = Dg.mutate(g, x, kmut, swaps)
+        a.append(x); b.append(y)
+    return a, b
+
+
+@pytest.mark.parametrize("costs", COSTS)
+def test_emu_small_all_costs(costs):
+    a, b = make_pairs(3, 150, 40, 6, costs[3] is not None)
+    for k in (0, 1, 3, 7, 12, 30):
+        got, plan = E.lev_band(a, b, k, costs)
+        assert got == oracle(a, b, k, costs), (k, costs, plan)
+
+
+@pytest.mark.parametrize("force_D,force_L", [(2, 0), (4, 0), (6, 0), (8, 3), (10, 2), (12, 0), (16, 4), (18, 1),
+                                             (22, 3), (24, 0), (34, 2), (66, 1), (8, 9), (2, 40)])
+def test_emu_lane_layouts(force_D, force_L):
+    """cfg2-like band (k chosen so the needed diagonals fit the forced layout) on every (D, L) shape."""
+    cap = force_D * (force_L if force_L else 64)
+    k = min(32, max(0, (cap - 2) // 2))
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+        a, b = make_pairs(7 + force_D, 70, 90, max(1, k), costs[3] is not None)
+        got, plan = E.lev_band(a, b, k, costs, force_D=force_D, force_L=force_L)
+        assert plan["D"] == force_D
+        assert got == oracle(a, b, k, costs), (k, costs, plan)
+
+
+def test_emu_cfg2_shape():
+    """BASELINE cfg2 geometry: 256 B pairs, k = 32, LEVENSHTEIN_COSTS; random (all None) + mutated."""
+    ar, br = Dg.pairs_random(0x7A02, 30, 256)
+    am, bm = Dg.pairs_mutated_fixed(0x7A12, 50, 256, 32)
+    a = [x.tobytes() for x in ar] + [x.tobytes() for x in am]
+    b = [x.tobytes() for x in br] + [x.tobytes() for x in bm]
+    got, plan = E.lev_band(a, b, 32)
+    want = oracle(a, b, 32, (1, 1, 0, None))
+    assert got == want
+    assert any(v is not None for v in want) and any(v is None for v in want)
+
+
+def test_emu_cfg4_shape():
+    """BASELINE cfg4 geometry: 128 B pairs, k = 8, RDAMERAU_COSTS with planted adjacent swaps."""
+    am, bm = Dg.pairs_mutated_fixed(0x7A04, 80, 128, 8, swaps=True)
+    a = [x.tobytes() for x in am]; b = [x.tobytes() for x in bm]
+    got, plan = E.lev_band(a, b, 8, O.RDAMERAU_COSTS)
+    assert got == oracle(a, b, 8, O.RDAMERAU_COSTS)
+    lev = oracle(a, b, 8, O.LEVENSHTEIN_COSTS)
+    assert got != lev  # the transposition path must matter on this data
+
+
+def test_emu_long_multichunk():
+    """Strings spanning several 64-byte stream chunks, ragged, incl. length difference > band (early None)."""
+    g = Dg.rng(99)
+    a, b = [], []
+    for n in (63, 64, 65, 127, 128, 129, 300, 500, 1000):
+        x = Dg.rand_str(g, n)
+        a += [x, x, x]
+        b += [Dg.mutate(g, x, 20), x[: n // 2], Dg.rand_str(g, n + 5)]
+    for k, costs in [(20, (1, 1, 0, None)), (25, (1, 1, 0, 1)), (40, (2, 1, 3, None)), (0xFFFFFFFF, (1, 1, 0, None))]:
+        if k == 0xFFFFFFFF:
+            aa, bb = a[:12], b[:12]   # full-matrix band: keep it small
+        else:
+            aa, bb = a, b
+        got, plan = E.lev_band(aa, bb, k, costs)
+        assert got == oracle(aa, bb, k, costs), (k, costs, plan)
+
+
+def test_emu_null_bytes_and_edges():
+    """Zero is the window filler value, so NUL bytes are the edge case the reference tests for its SIMD path
+    (tests/basic_tests.rs:503-537)."""
+    a = [b"\0", b"ab\0de", b"\0b", b"\0", b"\0", b"\0\0b\0", b"x", b"", b"a" * 70, b"\0" * 40]
+    b = [b"", b"a\0bde", b"b\0", b"\0\0", b"\0", b"\0b\0\0", b"x\0", b"\0\0\0", b"", b"\0" * 37 + b"a"]
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+        for k in (0, 1, 2, 5, 100):
+            got, plan = E.lev_band(a, b, k, costs)
+            assert got == oracle(a, b, k, costs), (k, costs, plan)
+
+
+def test_emu_affine_kernel_on_linear_costs():
+    """The AFFINE instantiation must agree with the linear one when start_gap = 0."""
+    a, b = make_pairs(5, 100, 60, 8, True)
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (3, 2, 0, None)]:
+        g1, _ = E.lev_band(a, b, 9, costs)
+        g2, _ = E.lev_band(a, b, 9, costs, force_affine=True)
+        assert g1 == g2 == oracle(a, b, 9, costs)

@@ -1,0 +1,172 @@
+"""-m gpu: the batch distance kernels (through the C ABI) against the CPU oracle, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import datagen as Dg
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 3, 0, None), (3, 1, 0, None), (1, 1, 2, None), (2, 1, 2, None),
+         (2, 2, 1, 3), (5, 3, 4, 4)]
+
+
+def gpu_k(a_list, b_list, k, costs):
+    from triple_accel_amd import batch as B
+    sa, sb = B.Strings.from_list(a_list), B.Strings.from_list(b_list)
+    out = B.levenshtein_k_batch(sa, sb, k, costs)
+    return out.cpu().numpy().view(np.uint32)
+
+
+def oracle_k(a_list, b_list, k, costs):
+    return O.levenshtein_k_batch(O.csr_from_list(a_list), O.csr_from_list(b_list), k, costs)
+
+
+def ragged_pairs(seed, n, maxlen, kmut, swaps):
+    g = Dg.rng(seed)
+    a, b = [], []
+    for i in range(n):
+        x = Dg.rand_str(g, int(g.integers(0, maxlen + 1)))
+        t = i % 4
+        y = Dg.rand_str(g, int(g.integers(0, maxlen + 1))) if t == 0 else (x if t == 1 else Dg.mutate(g, x, kmut, swaps))
+        a.append(x); b.append(y)
+    return a, b
+
+
+def test_dpp_and_layouts(monkeypatch):
+    """Every lane layout (D, L) -- this is what pins the DPP wave_shr/wave_shl semantics on hardware."""
+    a, b = ragged_pairs(11, 3000, 90, 12, True)
+    for force_D, force_L in [(2, 0), (4, 0), (6, 0), (8, 3), (10, 2), (12, 0), (16, 4), (18, 1), (22, 3), (24, 0),
+                             (34, 2), (66, 1), (8, 9), (2, 40), (56, 0)]:
+        monkeypatch.setenv("TA_FORCE_D", str(force_D))
+        monkeypatch.setenv("TA_FORCE_L", str(force_L))
+        cap = force_D * (force_L if force_L else 64)
+        k = min(32, max(0, (cap - 2) // 2))
+        for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+            got = gpu_k(a, b, k, costs)
+            want = oracle_k(a, b, k, costs)
+            assert np.array_equal(got, want), (force_D, force_L, k, costs, np.flatnonzero(got != want)[:10])
+
+
+@pytest.mark.parametrize("costs", COSTS)
+def test_all_costs_ragged(costs):
+    a, b = ragged_pairs(3, 5000, 70, 8, costs[3] is not None)
+    for k in (0, 1, 3, 7, 12, 30, 64):
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_cfg2_shape_100k():
+    """BASELINE cfg2 geometry at a size the oracle finishes in seconds: 256 B, k = 32, strided batch."""
+    from triple_accel_amd import batch as B
+    import triple_accel_amd as T
+    n = 100_000
+    ar, br = Dg.pairs_random(0x7A02, n // 2, 256)
+    am, bm = Dg.pairs_mutated_fixed(0x7A12, n // 2, 256, 32)
+    a = np.concatenate([ar, am]); b = np.concatenate([br, bm])
+    out = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 32).cpu().numpy().view(np.uint32)
+    info = T.last_launch_info()
+    assert info["kernel"] == 1 and info["cell_bits"] == 8
+    want = O.levenshtein_k_batch(O.csr_from_fixed(a), O.csr_from_fixed(b), 32)
+    assert np.array_equal(out, want)
+    assert (want[: n // 2] == 0xFFFFFFFF).all() and (want[n // 2:] != 0xFFFFFFFF).mean() > 0.9
+
+
+def test_cfg4_shape_100k():
+    """BASELINE cfg4 geometry: 128 B, k = 8, RDAMERAU_COSTS (transposition path)."""
+    from triple_accel_amd import batch as B
+    n = 100_000
+    am, bm = Dg.pairs_mutated_fixed(0x7A04, n, 128, 8, swaps=True)
+    out = B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), 8, O.RDAMERAU_COSTS)
+    out = out.cpu().numpy().view(np.uint32)
+    want = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 8, O.RDAMERAU_COSTS)
+    assert np.array_equal(out, want)
+    lev = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 8, O.LEVENSHTEIN_COSTS)
+    assert not np.array_equal(want, lev)
+
+
+def test_long_multichunk_and_edges():
+    g = Dg.rng(99)
+    a, b = [b"", b"", b"a", b"\0", b"\0" * 40], [b"", b"abc", b"", b"\0\0", b"\0" * 37 + b"a"]
+    for n in (63, 64, 65, 127, 128, 129, 300, 500, 1000, 2000):
+        x = Dg.rand_str(g, n)
+        a += [x, x, x]
+        b += [Dg.mutate(g, x, 20), x[: n // 2], Dg.rand_str(g, n + 5)]
+    for k, costs in [(20, (1, 1, 0, None)), (25, (1, 1, 0, 1)), (40, (2, 1, 3, None)), (300, (1, 1, 0, None)),
+                     (0xFFFFFFFF, (1, 1, 0, None)), (0xFFFFFFFF, (1, 1, 1, 1))]:
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE cfg2 at full size (1M x 256 B): size-independent properties + a sampled oracle check.
+    Mutated pairs (<= 32 unit edits) must all be Some(d <= 32), d symmetric under swapping a and b,
+    and identical pairs give 0."""
+    from triple_accel_amd import batch as B
+    n = 1_000_000
+    g = Dg.rng(0x7A22)
+    a = g.integers(33, 127, size=(n, 256), dtype=np.uint8)
+    b = a.copy()
+    # cheap vectorised mutation: up to 16 substitutions + one block shift (<= 8 inserts/deletes) per row
+    pos = g.integers(0, 256, size=(n, 16))
+    b[np.arange(n)[:, None], pos] = 32
+    shift = g.integers(0, 9, size=n)
+    for s in range(1, 9):
+        rows = np.flatnonzero(shift == s)
+        b[rows, s:] = b[rows, :-s].copy()
+    b[:1000] = a[:1000]
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    d_ab = B.levenshtein_k_batch(sa, sb, 32).cpu().numpy().view(np.uint32)
+    d_ba = B.levenshtein_k_batch(sb, sa, 32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(d_ab, d_ba)
+    assert (d_ab[:1000] == 0).all()
+    assert (d_ab <= 32).all()
+    idx = g.choice(n, size=20000, replace=False)
+    want = O.levenshtein_k_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx]), 32)
+    assert np.array_equal(d_ab[idx], want)
+
+
+def test_n1_equals_single_call():
+    import triple_accel_amd as T
+    g = Dg.rng(5)
+    for _ in range(20):
+        x = Dg.rand_str(g, int(g.integers(0, 50)))
+        y = Dg.mutate(g, x, 5)
+        assert T.levenshtein(x, y) == O.levenshtein(x, y)
+        assert T.levenshtein_simd_k(x, y, 3) == O.levenshtein_simd_k_with_opts(x, y, 3)[0]
+        assert T.rdamerau(x, y) == O.rdamerau(x, y)
+        assert T.levenshtein_exp(x, y) == O.levenshtein_exp(x, y)
+
+
+def test_exp_batch():
+    from triple_accel_amd import batch as B
+    g = Dg.rng(17)
+    a, b = [], []
+    for n in (10, 100, 300, 700):
+        for _ in range(50):
+            x = Dg.rand_str(g, n)
+            a.append(x); b.append(Dg.mutate(g, x, n // 3) if _ % 2 else Dg.rand_str(g, n))
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1)]:
+        out = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), costs).cpu().numpy().view(np.uint32)
+        want = O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), costs)
+        assert np.array_equal(out, want)
+
+
+def test_hamming_batch():
+    from triple_accel_amd import batch as B
+    import triple_accel_amd as T
+    a, b = Dg.pairs_random(0x7A01, 10000, 1024)      # BASELINE cfg1 shape
+    b[:, ::7] = a[:, ::7]
+    out = B.hamming_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b)).cpu().numpy().view(np.uint32)
+    assert np.array_equal(out, (a != b).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(out, O.hamming_batch(O.csr_from_fixed(a), O.csr_from_fixed(b)))
+    la = [b"", b"abc", b"x" * 33, b"y" * 1000 + b"z"]
+    lb = [b"", b"abd", b"x" * 32 + b"q", b"y" * 1001]
+    out = B.hamming_batch(B.Strings.from_list(la), B.Strings.from_list(lb)).cpu().numpy().view(np.uint32)
+    assert list(out) == [0, 1, 1, 1]
+    out = B.hamming_batch(B.Strings.from_list([b"ab"]), B.Strings.from_list([b"abc"])).cpu().numpy().view(np.uint32)
+    assert out[0] == 0xFFFFFFFF
+    with pytest.raises(T.PanicError):
+        T.hamming(b"ab", b"abc")

@@ -1,0 +1,197 @@
+"""triple_accel_amd -- MI355X-native edit-distance engine behind triple_accel's public API.
+
+Host-side mirror of the reference's public function set (triple_accel v0.4.0, src/lib.rs:126-127
+and the `levenshtein` / `hamming` modules): same names, argument order and meaning, with
+`Option::None` -> `None`, `panic!` -> `PanicError`, `Box<dyn Iterator<Item=Match>>` -> a Python
+iterator of `Match`.  All arithmetic runs in HIP kernels on gfx950 through the C ABI of
+include/triple_accel_amd.h (libtriple_accel_amd.so); there is no CPU fallback.
+
+The Rust shim a maintainer would drop into the reference crate is shown in INTEGRATION.md.
+"""
+import ctypes as _C
+from collections import namedtuple as _nt
+
+from . import _native as _n
+from ._native import TripleAccelError  # noqa: F401
+
+
+class PanicError(AssertionError):
+    """Where the reference panics (assert!/panic!), this is raised."""
+
+
+# src/lib.rs:135-142
+Match = _nt("Match", ["start", "end", "k"])
+# src/lib.rs:148-165
+Edit = _nt("Edit", ["edit", "count"])
+
+
+class EditType:
+    Match, Mismatch, AGap, BGap, Transpose = "Match", "Mismatch", "AGap", "BGap", "Transpose"
+
+
+class SearchType:  # src/lib.rs:171-174
+    All, Best = 0, 1
+
+
+class EditCosts:
+    """src/levenshtein.rs:20-71.  `EditCosts(mismatch, gap, start_gap, transpose_or_None)` == `EditCosts::new`."""
+    __slots__ = ("mismatch_cost", "gap_cost", "start_gap_cost", "transpose_cost")
+
+    def __init__(self, mismatch_cost, gap_cost, start_gap_cost, transpose_cost=None):
+        c = _n.EditCostsC()
+        rc = _n.lib().ta_edit_costs_new(mismatch_cost, gap_cost, start_gap_cost, transpose_cost is not None,
+                                        transpose_cost or 0, _C.byref(c))
+        if rc == _n.TA_ERR_BAD_COSTS:
+            raise PanicError("invalid EditCosts (src/levenshtein.rs:44-52)")
+        _n.check(rc)
+        self.mismatch_cost, self.gap_cost, self.start_gap_cost = mismatch_cost, gap_cost, start_gap_cost
+        self.transpose_cost = transpose_cost
+
+    new = classmethod(lambda cls, *a: cls(*a))
+
+    def _c(self):
+        t = self.transpose_cost
+        return _n.EditCostsC(self.mismatch_cost, self.gap_cost, self.start_gap_cost, 0 if t is None else 1, t or 0)
+
+    def __repr__(self):
+        return "EditCosts(%d, %d, %d, %r)" % (self.mismatch_cost, self.gap_cost, self.start_gap_cost, self.transpose_cost)
+
+
+LEVENSHTEIN_COSTS = EditCosts(1, 1, 0, None)   # src/levenshtein.rs:76-81
+RDAMERAU_COSTS = EditCosts(1, 1, 0, 1)         # src/levenshtein.rs:84-89
+
+
+def _costs(c):
+    if isinstance(c, EditCosts):
+        return c
+    return EditCosts(*c)
+
+
+def _raise(rc):
+    if rc == _n.TA_ERR_LEN_MISMATCH:
+        raise PanicError("assertion failed: a.len() == b.len()")
+    if rc == _n.TA_ERR_NULL_BYTE:
+        raise PanicError("No zero/null bytes allowed in the string!")
+    if rc == _n.TA_ERR_BAD_COSTS:
+        raise PanicError("invalid EditCosts")
+    if rc == _n.TA_ERR_UNSUPPORTED:
+        raise NotImplementedError("triple_accel_amd: not on the GPU path yet (trace_on=true, SURVEY.md 8f)")
+    _n.check(rc)
+
+
+def _u32(fn, *args):
+    out = _C.c_uint32()
+    _raise(fn(*args, _C.byref(out)))
+    return None if out.value == _n.NONE else int(out.value)
+
+
+def _b(x):
+    return bytes(x)
+
+
+# ---------------------------------------------------------------- hamming (src/hamming.rs)
+def hamming(a, b):
+    """src/hamming.rs:390"""
+    a, b = _b(a), _b(b)
+    return _u32(_n.lib().ta_hamming, a, len(a), b, len(b))
+
+
+def _matches(fn, *args):
+    mp = _C.POINTER(_n.MatchC)()
+    cnt = _C.c_size_t()
+    _raise(fn(*args, _C.byref(mp), _C.byref(cnt)))
+    try:
+        out = [Match(int(mp[i].start), int(mp[i].end), int(mp[i].k)) for i in range(cnt.value)]
+    finally:
+        if mp:
+            _n.lib().ta_free(mp)
+    return iter(out)
+
+
+def hamming_search_simd_with_opts(needle, haystack, k, search_type):
+    """src/hamming.rs:454"""
+    needle, haystack = _b(needle), _b(haystack)
+    return _matches(_n.lib().ta_hamming_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
+                    search_type)
+
+
+def hamming_search_simd(needle, haystack):
+    """src/hamming.rs:422"""
+    needle, haystack = _b(needle), _b(haystack)
+    return _matches(_n.lib().ta_hamming_search, needle, len(needle), haystack, len(haystack))
+
+
+hamming_search = hamming_search_simd   # src/hamming.rs:588
+
+
+# ---------------------------------------------------------------- levenshtein (src/levenshtein.rs)
+def levenshtein_simd_k_with_opts(a, b, k, trace_on, costs):
+    """src/levenshtein.rs:714 -> None | (distance, None).  trace_on=True is not on the GPU path yet."""
+    a, b = _b(a), _b(b)
+    d = _u32(_n.lib().ta_levenshtein_simd_k_with_opts, a, len(a), b, len(b), k, int(bool(trace_on)),
+             _C.byref(_costs(costs)._c()))
+    return None if d is None else (d, None)
+
+
+def levenshtein_simd_k(a, b, k):
+    """src/levenshtein.rs:677"""
+    a, b = _b(a), _b(b)
+    return _u32(_n.lib().ta_levenshtein_simd_k, a, len(a), b, len(b), k)
+
+
+def _dist(name):
+    def f(a, b):
+        a, b = _b(a), _b(b)
+        return _u32(getattr(_n.lib(), name), a, len(a), b, len(b))
+    return f
+
+
+levenshtein = _dist("ta_levenshtein")            # src/levenshtein.rs:1397
+rdamerau = _dist("ta_rdamerau")                  # :1419
+levenshtein_exp = _dist("ta_levenshtein_exp")    # :1445
+rdamerau_exp = _dist("ta_rdamerau_exp")          # :1516
+
+
+def levenshtein_exp_with_opts(a, b, trace_on, costs):
+    """src/levenshtein.rs:1480 -> (distance, None)"""
+    a, b = _b(a), _b(b)
+    d = _u32(_n.lib().ta_levenshtein_exp_with_opts, a, len(a), b, len(b), int(bool(trace_on)),
+             _C.byref(_costs(costs)._c()))
+    return (d, None)
+
+
+def levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored):
+    """src/levenshtein.rs:1911"""
+    needle, haystack = _b(needle), _b(haystack)
+    return _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
+                    search_type, _C.byref(_costs(costs)._c()), int(bool(anchored)))
+
+
+def levenshtein_search_simd(needle, haystack):
+    """src/levenshtein.rs:1866"""
+    needle, haystack = _b(needle), _b(haystack)
+    return _matches(_n.lib().ta_levenshtein_search, needle, len(needle), haystack, len(haystack))
+
+
+levenshtein_search = levenshtein_search_simd   # src/levenshtein.rs:2508
+
+
+def levenshtein_select(a_len, b_len, k, costs=LEVENSHTEIN_COSTS):
+    """The dispatcher arithmetic (src/levenshtein.rs:731-791): (max_k, unit_k, cell_bits, ref_lanes)."""
+    s = _n.LevSelectC()
+    _raise(_n.lib().ta_levenshtein_select(a_len, b_len, k, _C.byref(_costs(costs)._c()), _C.byref(s)))
+    return (s.max_k, s.unit_k, s.cell_bits, s.ref_lanes)
+
+
+def last_launch_info():
+    li = _n.LaunchInfoC()
+    _n.check(_n.lib().ta_last_launch_info(_C.byref(li)))
+    return {n: int(getattr(li, n)) for n, _ in _n.LaunchInfoC._fields_}
+
+
+def device_count():
+    return int(_n.lib().ta_device_count())
+
+
+def version():
+    return _n.lib().ta_version().decode()

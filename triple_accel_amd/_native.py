@@ -1,0 +1,116 @@
+"""Loads libtriple_accel_amd.so (the C ABI of include/triple_accel_amd.h) through ctypes.
+
+There is no pure-Python or CPU fallback: if the library is missing this raises, and if no
+HIP device is present every compute call raises TripleAccelError(TA_ERR_HIP).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtriple_accel_amd.so")
+
+NONE = 0xFFFFFFFF
+TA_OK, TA_ERR_LEN_MISMATCH, TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS, TA_ERR_HIP, TA_ERR_ARG, TA_ERR_UNSUPPORTED, \
+    TA_ERR_CAPACITY = range(8)
+
+# every symbol include/triple_accel_amd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ta_levenshtein_costs", "ta_rdamerau_costs", "ta_edit_costs_new", "ta_edit_costs_check_search",
+    "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_levenshtein_select",
+    "ta_last_launch_info", "ta_hamming", "ta_levenshtein_simd_k_with_opts", "ta_levenshtein_simd_k",
+    "ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_levenshtein_exp_with_opts", "ta_rdamerau_exp",
+    "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
+    "ta_hamming_search", "ta_free", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
+    "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best",
+]
+
+
+class EditCostsC(C.Structure):
+    _fields_ = [("mismatch_cost", C.c_uint8), ("gap_cost", C.c_uint8), ("start_gap_cost", C.c_uint8),
+                ("has_transpose", C.c_uint8), ("transpose_cost", C.c_uint8)]
+
+
+class MatchC(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("k", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+class LevSelectC(C.Structure):
+    _fields_ = [("max_k", C.c_uint32), ("unit_k", C.c_uint32), ("cell_bits", C.c_uint32), ("ref_lanes", C.c_uint32)]
+
+
+class LaunchInfoC(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kernel", "diags_per_lane", "lanes_per_pair", "pairs_per_wave",
+                                          "band_offset", "cell_bits", "affine", "transpose", "grid", "lds_bytes")]
+
+
+class StringsC(C.Structure):
+    _fields_ = [("blob", C.c_void_p), ("off", C.c_void_p), ("stride", C.c_uint64), ("len", C.c_uint64),
+                ("max_len", C.c_uint64)]
+
+
+class TripleAccelError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().ta_status_str(status).decode()
+        if detail:
+            msg += ": " + detail
+        super().__init__("triple_accel_amd: " + msg)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("triple_accel_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C triple_accel_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    u8p, sz, u32, i32 = C.c_char_p, C.c_size_t, C.c_uint32, C.c_int
+    cp, u32p = C.POINTER(EditCostsC), C.POINTER(C.c_uint32)
+    mpp, szp = C.POINTER(C.POINTER(MatchC)), C.POINTER(C.c_size_t)
+    sp = C.POINTER(StringsC)
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+    sig("ta_version", C.c_char_p, [])
+    sig("ta_status_str", C.c_char_p, [i32])
+    sig("ta_device_count", i32, [])
+    sig("ta_last_error", C.c_char_p, [])
+    sig("ta_levenshtein_costs", EditCostsC, [])
+    sig("ta_rdamerau_costs", EditCostsC, [])
+    sig("ta_edit_costs_new", i32, [C.c_uint8, C.c_uint8, C.c_uint8, i32, C.c_uint8, cp])
+    sig("ta_edit_costs_check_search", i32, [cp])
+    sig("ta_levenshtein_select", i32, [sz, sz, u32, cp, C.POINTER(LevSelectC)])
+    sig("ta_last_launch_info", i32, [C.POINTER(LaunchInfoC)])
+    sig("ta_hamming", i32, [u8p, sz, u8p, sz, u32p])
+    sig("ta_levenshtein_simd_k_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, cp, u32p])
+    sig("ta_levenshtein_simd_k", i32, [u8p, sz, u8p, sz, u32, u32p])
+    for n in ("ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_rdamerau_exp"):
+        sig(n, i32, [u8p, sz, u8p, sz, u32p])
+    sig("ta_levenshtein_exp_with_opts", i32, [u8p, sz, u8p, sz, i32, cp, u32p])
+    sig("ta_levenshtein_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, cp, i32, mpp, szp])
+    sig("ta_levenshtein_search", i32, [u8p, sz, u8p, sz, mpp, szp])
+    sig("ta_hamming_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])
+    sig("ta_hamming_search", i32, [u8p, sz, u8p, sz, mpp, szp])
+    sig("ta_free", None, [C.c_void_p])
+    sig("ta_levenshtein_k_batch", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p])
+    sig("ta_levenshtein_exp_batch", i32, [sp, sp, sz, cp, C.c_void_p, C.c_void_p])
+    sig("ta_hamming_batch", i32, [sp, sp, sz, C.c_void_p, C.c_void_p])
+    sig("ta_levenshtein_search_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, i32, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, sz, C.POINTER(C.c_uint64), C.c_void_p])
+    sig("ta_hamming_search_dev", i32, [u8p, sz, C.c_void_p, sz, u32, C.c_uint64, C.c_void_p, sz,
+                                       C.POINTER(C.c_uint64), C.c_void_p])
+    sig("ta_search_fold_best", sz, [C.POINTER(MatchC), sz, u32, i32])
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != TA_OK:
+        raise TripleAccelError(status, lib().ta_last_error().decode() if status in (TA_ERR_HIP, TA_ERR_ARG) else "")

@@ -1,0 +1,82 @@
+"""Batch entry points on device-resident data (torch tensors carry the HBM buffers; the
+arithmetic is the HIP kernels behind the C ABI).  New surface with no reference analogue:
+N = 1 equals the single-call functions."""
+import ctypes as _C
+
+import torch
+
+from . import _native as _n
+from . import EditCosts, LEVENSHTEIN_COSTS, _costs, _raise
+
+SLACK = 16
+
+
+class Strings:
+    """A batch side: CSR (blob + n+1 int64 offsets) or strided (fixed length) uint8 data in HBM."""
+
+    def __init__(self, blob, off=None, stride=0, length=0, max_len=0, n=None):
+        assert blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous()
+        self.blob, self.off, self.stride, self.length, self.max_len = blob, off, stride, length, max_len
+        if off is not None:
+            assert off.dtype == torch.int64 and off.is_cuda and off.is_contiguous()
+            self.n = off.numel() - 1
+        else:
+            self.n = n if n is not None else (blob.numel() - SLACK) // max(stride, 1)
+
+    @classmethod
+    def from_list(cls, strings, device="cuda"):
+        import numpy as np
+        lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=len(strings))
+        off = np.zeros(len(strings) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        blob = np.zeros(int(off[-1]) + SLACK, dtype=np.uint8)
+        if off[-1]:
+            blob[:int(off[-1])] = np.frombuffer(b"".join(bytes(s) for s in strings), dtype=np.uint8)
+        return cls(torch.from_numpy(blob).to(device), torch.from_numpy(off).to(device),
+                   max_len=int(lens.max()) if len(strings) else 0)
+
+    @classmethod
+    def from_fixed(cls, array_2d, device="cuda"):
+        """(n, len) uint8 array/tensor -> strided batch (stride == len) with read slack."""
+        t = torch.as_tensor(array_2d, dtype=torch.uint8)
+        n, length = t.shape
+        blob = torch.zeros(n * length + SLACK, dtype=torch.uint8, device=device)
+        blob[: n * length] = t.reshape(-1).to(device)
+        return cls(blob, None, stride=length, length=length, n=n)
+
+    def _c(self):
+        return _n.StringsC(self.blob.data_ptr(), 0 if self.off is None else self.off.data_ptr(),
+                           self.stride, self.length, self.max_len)
+
+
+def _stream():
+    return _C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _out(n, device):
+    return torch.empty(n, dtype=torch.int32, device=device)
+
+
+def levenshtein_k_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, out=None):
+    """out[i] = levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) as int32 (-1 == None)."""
+    assert a.n == b.n
+    out = _out(a.n, a.blob.device) if out is None else out
+    ca, cb, cc = a._c(), b._c(), _costs(costs)._c()
+    _raise(_n.lib().ta_levenshtein_k_batch(_C.byref(ca), _C.byref(cb), a.n, k, _C.byref(cc), out.data_ptr(), _stream()))
+    return out
+
+
+def levenshtein_exp_batch(a: Strings, b: Strings, costs=LEVENSHTEIN_COSTS, out=None):
+    assert a.n == b.n
+    out = _out(a.n, a.blob.device) if out is None else out
+    ca, cb, cc = a._c(), b._c(), _costs(costs)._c()
+    _raise(_n.lib().ta_levenshtein_exp_batch(_C.byref(ca), _C.byref(cb), a.n, _C.byref(cc), out.data_ptr(), _stream()))
+    return out
+
+
+def hamming_batch(a: Strings, b: Strings, out=None):
+    assert a.n == b.n
+    out = _out(a.n, a.blob.device) if out is None else out
+    ca, cb = a._c(), b._c()
+    _raise(_n.lib().ta_hamming_batch(_C.byref(ca), _C.byref(cb), a.n, out.data_ptr(), _stream()))
+    return out

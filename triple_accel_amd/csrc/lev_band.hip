@@ -1,0 +1,46 @@
+// lev_band.hip -- gfx950 instantiations of the band-wavefront kernel (lev_band_body.h).
+#include <hip/hip_runtime.h>
+
+#include "lev_band_body.h"
+#include "lev_plan.h"
+
+namespace ta {
+
+constexpr int LEV_WAVES_PER_BLOCK = 4;
+
+template <int D, bool AFFINE, bool TRANS>
+__global__ __launch_bounds__(64 * LEV_WAVES_PER_BLOCK) void lev_band_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6;
+    LevBand<DevWave, D, AFFINE, TRANS>::run(P, blockIdx.x * LEV_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+}
+
+template <int D>
+static hipError_t launch_d(const LevParams &P, bool affine, bool trans, uint32_t grid, size_t lds, hipStream_t s) {
+    dim3 g(grid), b(64 * LEV_WAVES_PER_BLOCK);
+    if (affine && trans) hipLaunchKernelGGL((lev_band_kernel<D, true, true>), g, b, lds, s, P);
+    else if (affine) hipLaunchKernelGGL((lev_band_kernel<D, true, false>), g, b, lds, s, P);
+    else if (trans) hipLaunchKernelGGL((lev_band_kernel<D, false, true>), g, b, lds, s, P);
+    else hipLaunchKernelGGL((lev_band_kernel<D, false, false>), g, b, lds, s, P);
+    return hipGetLastError();
+}
+
+// Launches the kernel for plan `pl`; returns the grid size through *grid_out.
+hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s,
+                           uint32_t *grid_out, uint32_t *lds_out) {
+    const uint32_t waves = (P.n + pl.PW - 1) / pl.PW;
+    const uint32_t grid = (waves + LEV_WAVES_PER_BLOCK - 1) / LEV_WAVES_PER_BLOCK;
+    const size_t lds = (size_t)pl.lds_per_wave * LEV_WAVES_PER_BLOCK;
+    if (grid_out) *grid_out = grid;
+    if (lds_out) *lds_out = (uint32_t)lds;
+    if (grid == 0) return hipSuccess;
+    switch (pl.D) {
+#define TA_CASE(d) case d: return launch_d<d>(P, affine, trans, grid, lds, s);
+        TA_CASE(2) TA_CASE(4) TA_CASE(6) TA_CASE(8) TA_CASE(10) TA_CASE(12) TA_CASE(16) TA_CASE(18) TA_CASE(20)
+        TA_CASE(22) TA_CASE(24) TA_CASE(28) TA_CASE(32) TA_CASE(34) TA_CASE(40) TA_CASE(48) TA_CASE(56) TA_CASE(66)
+#undef TA_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ta

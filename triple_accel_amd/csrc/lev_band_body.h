@@ -1,0 +1,271 @@
+// lev_band_body.h -- the banded anti-diagonal Levenshtein / restricted-Damerau kernel body.
+//
+// Replaces the reference's SIMD core levenshtein_simd_core_* (src/levenshtein.rs:829-1195)
+// and the jewel layer under it (src/jewel.rs) for BATCHES of pairs; result contract is the
+// scalar path's (src/levenshtein.rs:376-607): out = d if d <= k else None.
+//
+// Mapping.  A pair's band is the diagonals d = j - i in [-u, u]; diagonal
+// index p = d + o with o = u|1 (odd), so dp(0,0) sits on an odd p.  L consecutive lanes of a
+// wavefront own one pair; lane g owns the D diagonals p in [g*D, g*D+D), one DP cell per
+// diagonal kept IN PLACE in a VGPR: cell (i,j) of diagonal p is overwritten by (i+1,j+1) two
+// anti-diagonal steps later.  Step s = i + j updates the cells with p + s + o even ("even
+// phase": q = p - g*D even, "odd phase": q odd); both neighbours of a cell on the previous
+// anti-diagonal are the adjacent diagonals p-1 (cell (i,j-1)) and p+1 (cell (i-1,j)), i.e. the
+// registers next door, or -- at a lane's edge -- the neighbouring lane's edge register, fetched
+// with one DPP wave_shr:1 / wave_shl:1 per step.  64/L pairs advance in lock-step per wave.
+//
+// The two strings are consumed strictly sequentially (one new byte of `a` and of `b` per pair
+// per iteration = 2 steps), so they are streamed HBM -> LDS in 64-byte ring chunks by coalesced
+// 16-byte pieces, and enter the per-lane byte windows (packed 4 chars per VGPR, shifted with
+// v_alignbyte) at the group's edge lanes; between lanes the windows shift through DPP too.
+//
+// Written against a wave policy W (wave.h) so the same text runs as HIP device code and as a
+// 64-lane host emulation for tests.
+#pragma once
+#include "wave.h"
+
+namespace ta {
+
+constexpr uint32_t LEV_INF = 0x3FFFFFFFu;   // "unreachable"; real costs stay far below (n+m < 2^22)
+constexpr int LEV_CH = 64;                  // iterations (= bytes per string) per streamed chunk
+constexpr int LEV_RING = 2 * LEV_CH;        // ring bytes per (pair, string) slot in LDS
+
+struct LevParams {
+    StrView a, b;
+    const uint32_t *subset;   // optional: indices of the pairs to process (exp search), else nullptr
+    uint32_t *out;
+    uint32_t n;               // pairs (or subset length)
+    uint32_t k;               // threshold: out = d <= k ? d : NONE
+    uint32_t mc, gc, sg, tc;  // EditCosts as u32 (src/levenshtein.rs:392-398)
+    uint32_t u;               // band half-width in diagonals (>= every pair's unit_k, :760-763)
+    uint32_t o;               // diagonal index of d = 0 (u | 1)
+    uint32_t L;               // lanes per pair
+    uint32_t PW;              // pairs per wave = 64 / L
+    uint32_t lds_per_wave;    // bytes
+};
+
+template <class W, int D, bool AFFINE, bool TRANS>
+struct LevBand {
+    static_assert(D % 2 == 0 && D >= 2, "D must be even");
+    static constexpr int Dh = D / 2;                 // cells per lane per phase
+    static constexpr int NW = (Dh + 2 + 3) / 4;      // packed window registers (Dh+2 bytes used)
+    using U32 = typename W::U32;
+    using Bool = typename W::Bool;
+    using Ptr = typename W::Ptr;
+
+    struct State {
+        U32 reg[D];   // dp value of the newest cell on each diagonal
+        U32 HA[D];    // cheapest way to LEAVE that cell by a gap along j (a_gap of the next cell): see phase()
+        U32 HB[D];    // ... by a gap along i (b_gap); aliases HA when !AFFINE (unused)
+        U32 PV[D];    // dp value one cell earlier on the diagonal = dp(i-2,j-2) for the next update (TRANS)
+        U32 AW[NW];   // byte c+1 = a[i-1] for this lane's cell c (reversed window), byte 0 = intake
+        U32 BW[NW];   // byte c+1 = b[j-1] for cell c, byte 0 = b[j-2] of cell 0, byte Dh+1 = intake
+    };
+
+    // One anti-diagonal step for the cells q = 2c + PAR of every lane.
+    template <int PAR>
+    static TA_HD inline __attribute__((always_inline)) void phase(State &st, const LevParams &P, Bool is_g0, Bool is_gl) {
+        const U32 INF = W::splat(LEV_INF);
+        U32 X[NW], Z[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) X[w] = st.AW[w] ^ st.BW[w];
+        if (TRANS) {
+            // a[i-1]==b[j-2] && a[i-2]==b[j-1]  (src/levenshtein.rs:517-521) as one zero byte per cell
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                U32 b_up = W::template alignbyte<3>(st.BW[w], w ? st.BW[w - 1] : W::splat(0));          // byte c+1 <- b byte c
+                U32 a_dn = W::template alignbyte<1>(w + 1 < NW ? st.AW[w + 1] : W::splat(0), st.AW[w]); // byte c+1 <- a byte c+2
+                Z[w] = (st.AW[w] ^ b_up) | (a_dn ^ st.BW[w]);
+            }
+        }
+        U32 xl = INF, xr = INF;
+        if (PAR == 0) {
+            xl = W::from_lower(st.HA[D - 1], INF);
+            xl = W::sel(is_g0, INF, xl);            // band edge: nothing left of the pair's first diagonal
+        } else {
+            xr = W::from_upper(AFFINE ? st.HB[0] : st.HA[0], INF);
+            xr = W::sel(is_gl, INF, xr);
+        }
+        // per byte: (a != b) ? mismatch_cost : 0, four cells per VGPR (SWAR), so that each cell's
+        // substitution cost is ONE byte-select add (v_add_u32_sdwa)
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            U32 t = (X[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;      // bit 7 of each byte <- low 7 bits nonzero
+            t = ((t | X[w]) >> 7) & 0x01010101u;              // 1 per nonzero byte
+            X[w] = W::mul24(t, P.mc);                         // mc <= 255: no carry between bytes
+        }
+#pragma unroll
+        for (int c = 0; c < Dh; c++) {
+            const int q = 2 * c + PAR;
+            const int byte = c + 1, w = byte >> 2;
+            U32 sub = st.reg[q] + W::byte_of(X[w], byte & 3);        // :471-475
+            U32 lft = (PAR == 0 && c == 0) ? xl : st.HA[q > 0 ? q - 1 : 0];                   // a_gap  :476-483
+            U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[q + 1 < D ? q + 1 : D - 1] : st.HA[q + 1 < D ? q + 1 : D - 1]);   // b_gap :484-491
+            U32 nv = W::umin3(sub, lft, rgt);                                     // :493-515
+            if (TRANS) {
+                U32 t = st.PV[q] + P.tc;                                          // :523-525 (<= : min)
+                st.PV[q] = st.reg[q];
+                Bool tz = W::byte_of(Z[w], byte & 3) == 0u;
+                nv = W::sel(tz, W::umin(nv, t), nv);
+            }
+            st.reg[q] = nv;
+            if (AFFINE) {
+                U32 go = nv + (P.sg + P.gc);                                      // open a gap from this cell
+                st.HA[q] = W::umin(go, lft + P.gc);                               // or extend the one that reached it
+                st.HB[q] = W::umin(go, rgt + P.gc);
+            } else {
+                st.HA[q] = nv + P.gc;
+            }
+        }
+    }
+
+    // a-window: every char moves one cell up (new row enters at cell 0) -- src/levenshtein.rs:1027-1031
+    static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in, Bool is_g0) {
+        constexpr int sb = Dh;   // byte Dh = cell Dh-1 = the char the next lane needs
+        U32 t = st.AW[sb >> 2] >> (8 * (sb & 3));
+        t = W::from_lower(t, W::splat(0));
+        t = W::sel(is_g0, a_in, t);
+        st.AW[0] = W::bfi(0xffu, t, st.AW[0]);
+#pragma unroll
+        for (int w = NW - 1; w >= 1; w--) st.AW[w] = W::template alignbyte<3>(st.AW[w], st.AW[w - 1]);
+        st.AW[0] = st.AW[0] << 8;
+    }
+    // b-window: every char moves one cell down (new column enters at cell Dh-1) -- :1033-1037
+    static TA_HD inline __attribute__((always_inline)) void advance_b(State &st, U32 b_in, Bool is_gl) {
+        U32 t = st.BW[0] >> 8;   // byte 1 = cell 0
+        t = W::from_upper(t, W::splat(0));
+        t = W::sel(is_gl, b_in, t);
+        constexpr int ib = Dh + 1, iw = ib >> 2, ish = 8 * (ib & 3);
+        st.BW[iw] = W::bfi(0xffu << ish, t << ish, st.BW[iw]);
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) st.BW[w] = W::template alignbyte<1>(st.BW[w + 1], st.BW[w]);
+        st.BW[NW - 1] = st.BW[NW - 1] >> 8;
+    }
+
+    // Stream chunk kc (iterations [kc*CH, kc*CH+CH)) of every pair's two strings into the LDS ring.
+    static TA_HD inline void load_chunk(uint8_t *lds, const LevParams &P, uint32_t kc, U32 lane,
+                                  Ptr aptr, U32 alen, Ptr bptr, U32 blen, uint32_t ea, uint32_t eb) {
+        const uint32_t npieces = 2u * P.PW * (LEV_CH / 16);
+        for (uint32_t base = 0; base < npieces; base += 64) {
+            U32 l = lane + base;
+            Bool pred = l < npieces;
+            U32 slot = l >> 2;                 // LEV_CH/16 == 4 pieces per slot
+            U32 piece = l & 3u;
+            U32 src = (slot >> 1) * P.L;       // first lane of the owning pair
+            Bool isb = (slot & 1u) != 0u;
+            Ptr pa = W::shfl_ptr(aptr, src), pb = W::shfl_ptr(bptr, src);
+            U32 la = W::shfl(alen, src), lb = W::shfl(blen, src);
+            U32 len = W::sel(isb, lb, la);
+            U32 e = W::sel(isb, W::splat(eb), W::splat(ea));
+            U32 y0 = piece * 16u + kc * LEV_CH;          // ring position (absolute)
+            Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
+            U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
+            auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, pb, pa), idx0), ok);
+            W::lds_store16(lds, slot * LEV_RING + (y0 & (LEV_RING - 1)), q, pred);
+        }
+    }
+
+    static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
+        const U32 INF = W::splat(LEV_INF);
+        const U32 lane = W::lane();
+        const uint32_t L = P.L;
+        const U32 grp = W::udiv(lane, L);
+        const U32 g = lane - grp * L;
+        const Bool active = grp < P.PW;
+        const U32 slot_idx = grp + wave_index * P.PW;
+        const Bool valid = active & (slot_idx < P.n);
+        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, valid, 0u) : slot_idx;
+        const Bool is_g0 = (g == 0u), is_gl = (g == L - 1);
+
+        Ptr aptr, bptr;
+        U32 alen, blen;
+        W::load_str(P.a, pair, valid, aptr, alen);
+        W::load_str(P.b, pair, valid, bptr, blen);
+
+        // answer cell (alen, blen): step s_ans, diagonal p_ans = o + blen - alen
+        const U32 s_ans = alen + blen;
+        const U32 diff = W::sel(blen >= alen, blen - alen, alen - blen);
+        const Bool inband = diff <= P.u;                       // else None (:426-428, :860-862)
+        const U32 p_ans = W::sel(inband, (blen + P.o) - alen, W::splat(0));
+        const U32 g_ans = W::udiv(p_ans, (uint32_t)D);
+        const U32 q_ans = p_ans - g_ans * (uint32_t)D;
+
+        const uint32_t Tw = L * Dh;                            // warm-up iterations: windows fill up
+        const uint32_t h = (P.o + 1) >> 1;
+        // iteration t' = tau + Tw feeds a[t' - ca] into lane 0 and b[t' - cb] into lane L-1
+        const uint32_t ca = Tw - h, cb = h;
+        const uint32_t da = (16u - (ca & 15u)) & 15u, db = (16u - (cb & 15u)) & 15u;
+        const uint32_t ea = ca + da, eb = cb + db;             // multiples of 16: pieces never straddle index 0
+        const uint32_t iters = Tw + W::wave_max((s_ans + 1u) >> 1);
+        const U32 t_cap = W::sel(s_ans == 0u, W::splat(0xFFFFFFFFu), ((s_ans - 1u) >> 1) + Tw);
+
+        State st;
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            st.reg[q] = INF; st.HA[q] = INF;
+            if (AFFINE) st.HB[q] = INF;
+            if (TRANS) st.PV[q] = INF;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(0); st.BW[w] = W::splat(0); }
+        {   // seed dp(0,0) = 0 on diagonal p = o  (:450-452 row 0 then grows through the a_gap chain)
+            const uint32_t gs = P.o / D, qs = P.o % D;
+            const Bool seed_lane = (g == gs);
+#pragma unroll
+            for (int q = 1; q < D; q += 2) {
+                Bool hit = seed_lane & (W::splat(qs) == (uint32_t)q);
+                st.reg[q] = W::sel(hit, W::splat(0), st.reg[q]);
+                st.HA[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HA[q]);
+                if (AFFINE) st.HB[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HB[q]);
+            }
+        }
+        U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
+
+        const U32 a_slot = (grp * 2u) * LEV_RING, b_slot = (grp * 2u + 1u) * LEV_RING;
+
+        load_chunk(lds, P, 0, lane, aptr, alen, bptr, blen, ea, eb);
+        load_chunk(lds, P, 1, lane, aptr, alen, bptr, blen, ea, eb);
+        W::lds_wave_sync();
+
+        for (uint32_t kc = 0; kc * LEV_CH < iters; kc++) {
+            if (kc >= 1) {
+                load_chunk(lds, P, kc + 1, lane, aptr, alen, bptr, blen, ea, eb);
+                W::lds_wave_sync();
+            }
+            const uint32_t t_lo = kc * LEV_CH;
+            const uint32_t t_hi = (t_lo + LEV_CH < iters) ? t_lo + LEV_CH : iters;
+            uint32_t tp = t_lo;
+            // warm-up part: only the char windows move
+            for (; tp < t_hi && tp < Tw; tp++) {
+                U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));
+                U32 b_in = W::lds_u8(lds, b_slot + ((tp + db) & (LEV_RING - 1)));
+                advance_b(st, b_in, is_gl);
+                advance_a(st, a_in, is_g0);
+            }
+            // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase)
+            for (; tp < t_hi; tp++) {
+                U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));
+                U32 b_in = W::lds_u8(lds, b_slot + ((tp + db) & (LEV_RING - 1)));
+                phase<0>(st, P, is_g0, is_gl);
+                advance_b(st, b_in, is_gl);
+                phase<1>(st, P, is_g0, is_gl);
+                advance_a(st, a_in, is_g0);
+                Bool cap = (t_cap == tp);
+                if (W::any(cap)) {                 // the answer cell was written in this iteration
+                    U32 r = INF;
+#pragma unroll
+                    for (int q = 0; q < D; q++) r = W::sel(q_ans == (uint32_t)q, st.reg[q], r);
+                    ans = W::sel(cap, r, ans);
+                }
+            }
+        }
+
+        // the owning lane holds the distance; the pair's first lane writes the result
+        U32 d = W::shfl(ans, grp * L + g_ans);
+        Bool some = inband & (d <= P.k) & (d < INF);          // :539-541, :1166-1168
+        U32 res = W::sel(some, d, W::splat(0xFFFFFFFFu));
+        W::store_u32(P.out, pair, res, valid & is_g0);
+    }
+};
+
+}  // namespace ta

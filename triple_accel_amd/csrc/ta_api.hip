@@ -1,0 +1,370 @@
+// ta_api.hip -- the C ABI (include/triple_accel_amd.h): validation, launch planning, staging.
+// No CPU fallback lives here: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "ta_internal.h"
+
+namespace ta {
+
+static thread_local std::string g_last_error;
+static thread_local ta_launch_info g_last_launch = {};
+
+void set_last_error(const char *what, hipError_t e) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+void set_last_error_msg(const char *msg) { g_last_error = msg; }
+
+bool device_ready() {
+    static int state = -1;   // -1 unknown, 0 no, 1 yes
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (state < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        state = (e == hipSuccess && n > 0) ? 1 : 0;
+        if (!state) set_last_error_msg("no HIP device available (triple_accel_amd has no CPU fallback)");
+    }
+    if (!state) set_last_error_msg("no HIP device available (triple_accel_amd has no CPU fallback)");
+    return state == 1;
+}
+
+int Scratch::ensure(size_t bytes) {
+    if (bytes <= cap) return TA_OK;
+    if (dev) { (void)hipFree(dev); dev = nullptr; cap = 0; }
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+    TA_HIP(hipMalloc(&dev, want));
+    cap = want;
+    return TA_OK;
+}
+Scratch::~Scratch() { /* device memory is reclaimed at process exit; hipFree during TLS teardown is unsafe */ }
+Scratch &tls_scratch(int which) {
+    static thread_local Scratch s[6];
+    return s[which];
+}
+
+static inline int env_int(const char *name) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+static bool costs_ok(const ta_edit_costs *c) {   // EditCosts::new, src/levenshtein.rs:44-52
+    if (!c) return false;
+    if (!(c->mismatch_cost > 0) || !(c->gap_cost > 0)) return false;
+    if (c->has_transpose) {
+        if (!(c->transpose_cost > 0)) return false;
+        if (!((c->transpose_cost >> 1) < c->mismatch_cost)) return false;
+        if (!((c->transpose_cost >> 1) < c->gap_cost)) return false;
+    }
+    return true;
+}
+
+static StrView view_of(const ta_strings *s) { return StrView{s->blob, s->off, s->stride, s->len}; }
+
+// longest string of a batch side: given, implied (strided) or measured on the device
+static int side_max_len(const ta_strings *s, uint32_t n, hipStream_t st, uint64_t *out) {
+    if (!s->off) { *out = s->len; return TA_OK; }
+    if (s->max_len) { *out = s->max_len; return TA_OK; }
+    Scratch &sc = tls_scratch(3);
+    int rc = sc.ensure(16);
+    if (rc) return rc;
+    TA_HIP(hipMemsetAsync(sc.dev, 0, 4, st));
+    TA_HIP(strings_maxlen_launch(view_of(s), n, (uint32_t *)sc.dev, st));
+    uint32_t v = 0;
+    TA_HIP(hipMemcpyAsync(&v, sc.dev, 4, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    *out = v;
+    return TA_OK;
+}
+
+// One k-bounded distance pass over the batch (or over `subset`); the heart of every distance entry point.
+static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, const uint32_t *subset, uint32_t k,
+                    const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st) {
+    const uint32_t gc = c->gap_cost, sg = c->start_gap_cost;
+    LevPlan pl = lev_make_plan(k, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"));
+    LevParams P;
+    P.a = view_of(a); P.b = view_of(b);
+    P.subset = subset; P.out = out_dev; P.n = n_work; P.k = k;
+    P.mc = c->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = c->has_transpose ? c->transpose_cost : 0;
+    P.u = pl.u; P.o = pl.o;
+    const bool affine = sg > 0 || env_int("TA_FORCE_AFFINE"), trans = c->has_transpose != 0;
+    ta_launch_info li = {};
+    li.band_offset = pl.o; li.affine = affine; li.transpose = trans;
+    ta_lev_select sel;
+    ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
+    li.cell_bits = sel.cell_bits;
+    if (pl.ok && !env_int("TA_FORCE_WIDE")) {
+        P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave;
+        uint32_t grid = 0, lds = 0;
+        TA_HIP(lev_band_launch(P, pl, affine, trans, st, &grid, &lds));
+        li.kernel = 1; li.diags_per_lane = pl.D; li.lanes_per_pair = pl.L; li.pairs_per_wave = pl.PW;
+        li.grid = grid; li.lds_bytes = lds;
+    } else {
+        if (!lev_wide_fits(pl.need)) {
+            set_last_error_msg("band wider than the wide-band kernel supports (strings longer than 32767 bytes with an unbounded k)");
+            return TA_ERR_ARG;
+        }
+        P.L = 0; P.PW = 1; P.lds_per_wave = 0;
+        uint32_t grid = 0, lds = 0, threads = 0, dpt = 0;
+        TA_HIP(lev_wide_launch(P, trans, st, &grid, &lds, &threads, &dpt));
+        li.kernel = 2; li.diags_per_lane = dpt; li.lanes_per_pair = threads; li.pairs_per_wave = 0;
+        li.grid = grid; li.lds_bytes = lds; li.affine = 1;
+    }
+    if (env_int("TA_DEBUG"))
+        fprintf(stderr, "[triple_accel_amd] lev pass: n=%u k=%u u=%u kernel=%u D=%u L=%u pairs/wave=%u width=%u-bit grid=%u lds=%u\n",
+                n_work, k, pl.u, li.kernel, li.diags_per_lane, li.lanes_per_pair, li.pairs_per_wave, li.cell_bits, li.grid,
+                li.lds_bytes);
+    g_last_launch = li;
+    return TA_OK;
+}
+
+static int batch_max_len(const ta_strings *a, const ta_strings *b, uint32_t n, hipStream_t st, uint64_t *out) {
+    uint64_t ma = 0, mb = 0;
+    int rc = side_max_len(a, n, st, &ma);
+    if (rc) return rc;
+    rc = side_max_len(b, n, st, &mb);
+    if (rc) return rc;
+    *out = ma > mb ? ma : mb;
+    return TA_OK;
+}
+
+static int check_batch_args(const ta_strings *a, const ta_strings *b, size_t n, const void *out) {
+    if (!a || !b || (!out && n) || n > 0xFFFFFFF0ull) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    if (n && (!a->blob || !b->blob)) { set_last_error_msg("null blob"); return TA_ERR_ARG; }
+    return TA_OK;
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" {
+
+const char *ta_version(void) { return "triple_accel_amd 0.1 (gfx950)"; }
+
+const char *ta_status_str(int s) {
+    switch (s) {
+        case TA_OK: return "ok";
+        case TA_ERR_LEN_MISMATCH: return "length mismatch (reference: assert!(a.len() == b.len()))";
+        case TA_ERR_NULL_BYTE: return "No zero/null bytes allowed in the string!";
+        case TA_ERR_BAD_COSTS: return "invalid EditCosts";
+        case TA_ERR_HIP: return "HIP error / no device";
+        case TA_ERR_ARG: return "bad argument";
+        case TA_ERR_UNSUPPORTED: return "unsupported on the GPU path";
+        case TA_ERR_CAPACITY: return "output capacity exceeded";
+        default: return "unknown";
+    }
+}
+
+int ta_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ta_last_error(void) { return g_last_error.c_str(); }
+
+ta_edit_costs ta_levenshtein_costs(void) { ta_edit_costs c = {1, 1, 0, 0, 0}; return c; }
+ta_edit_costs ta_rdamerau_costs(void) { ta_edit_costs c = {1, 1, 0, 1, 1}; return c; }
+
+int ta_edit_costs_new(uint8_t mismatch, uint8_t gap, uint8_t start_gap, int has_transpose, uint8_t transpose,
+                      ta_edit_costs *out) {
+    ta_edit_costs c = {mismatch, gap, start_gap, (uint8_t)(has_transpose ? 1 : 0), (uint8_t)(has_transpose ? transpose : 0)};
+    if (!costs_ok(&c)) return TA_ERR_BAD_COSTS;
+    if (out) *out = c;
+    return TA_OK;
+}
+
+int ta_edit_costs_check_search(const ta_edit_costs *c) {   // src/levenshtein.rs:67-71
+    if (!c) return TA_ERR_ARG;
+    if (c->has_transpose && !((uint32_t)c->transpose_cost <= (uint32_t)c->start_gap_cost + (uint32_t)c->gap_cost))
+        return TA_ERR_BAD_COSTS;
+    return TA_OK;
+}
+
+// src/levenshtein.rs:731-791
+int ta_levenshtein_select(size_t a_len, size_t b_len, uint32_t k, const ta_edit_costs *c, ta_lev_select *out) {
+    if (!c || !out) return TA_ERR_ARG;
+    if (!costs_ok(c)) return TA_ERR_BAD_COSTS;
+    const uint32_t mn = (uint32_t)(a_len < b_len ? a_len : b_len), mx = (uint32_t)(a_len < b_len ? b_len : a_len);
+    const uint32_t mc = c->mismatch_cost, gc = c->gap_cost, sg = c->start_gap_cost;
+    uint32_t sub_all = mn * mc;
+    uint32_t gaps_all = (mn << 1) * gc + (mn == 0 ? 0u : sg + (mx == mn ? sg : 0u));
+    uint32_t bound = (sub_all < gaps_all ? sub_all : gaps_all) + (mx - mn) * gc + (mx == mn ? 0u : sg);
+    uint32_t max_k = k < bound ? k : bound;
+    uint32_t unit_k = lev_sat_sub(max_k, sg) / gc;
+    if (unit_k > mx) unit_k = mx;
+    out->max_k = max_k; out->unit_k = unit_k;
+    out->cell_bits = 32; out->ref_lanes = 0;
+    static const uint32_t ub[4] = {32, 64, 128, 256};
+    if (max_k <= 254u) {
+        for (int t = 0; t < 4; t++)
+            if (unit_k <= ub[t] - 2) { out->cell_bits = 8; out->ref_lanes = ub[t]; return TA_OK; }
+    }
+    if (max_k <= 65534u) out->cell_bits = 16;
+    return TA_OK;
+}
+
+int ta_last_launch_info(ta_launch_info *out) {
+    if (!out) return TA_ERR_ARG;
+    *out = g_last_launch;
+    return TA_OK;
+}
+
+void ta_free(void *p) { free(p); }
+
+/* ---------------------------------------------------------------- batch API */
+
+int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k,
+                           const ta_edit_costs *costs, uint32_t *out_dev, void *stream) {
+    int rc = check_batch_args(a, b, n, out_dev);
+    if (rc) return rc;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (n == 0) return TA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t max_len = 0;
+    rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
+    if (rc) return rc;
+    return lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st);
+}
+
+int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
+                             const ta_edit_costs *costs, uint32_t *out_dev, void *stream) {
+    int rc = check_batch_args(a, b, n, out_dev);
+    if (rc) return rc;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (n == 0) return TA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t max_len = 0;
+    rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
+    if (rc) return rc;
+    // subset ping-pong buffers + counter
+    Scratch &s0 = tls_scratch(4), &s1 = tls_scratch(5), &cnt = tls_scratch(3);
+    if ((rc = s0.ensure(n * 4)) || (rc = s1.ensure(n * 4)) || (rc = cnt.ensure(16))) return rc;
+    uint32_t *sub_in = nullptr, *bufs[2] = {(uint32_t *)s0.dev, (uint32_t *)s1.dev};
+    uint32_t n_work = (uint32_t)n;
+    uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
+    int flip = 0;
+    for (int round = 0; round < 40 && n_work > 0; round++) {
+        rc = lev_pass(a, b, n_work, sub_in, k, costs, max_len, out_dev, st);
+        if (rc) return rc;
+        TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
+        TA_HIP(compact_none_launch(out_dev, sub_in, n_work, bufs[flip], (uint32_t *)cnt.dev, st));
+        uint32_t left = 0;
+        TA_HIP(hipMemcpyAsync(&left, cnt.dev, 4, hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+        sub_in = bufs[flip];
+        flip ^= 1;
+        n_work = left;
+        k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
+    }
+    return TA_OK;
+}
+
+int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out_dev, void *stream) {
+    int rc = check_batch_args(a, b, n, out_dev);
+    if (rc) return rc;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (n == 0) return TA_OK;
+    TA_HIP(hamming_batch_launch(view_of(a), view_of(b), (uint32_t)n, out_dev, (hipStream_t)stream));
+    return TA_OK;
+}
+
+/* ---------------------------------------------------------------- single-call host API */
+
+// stage one (a, b) pair into thread-local device scratch: [a | slack | b | slack | out]
+static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                      ta_strings *sa, ta_strings *sb, uint32_t **out_dev) {
+    if ((!a && a_len) || (!b && b_len)) return TA_ERR_ARG;
+    if (a_len > 0xFFFFFFF0ull || b_len > 0xFFFFFFF0ull) return TA_ERR_ARG;
+    if (!device_ready()) return TA_ERR_HIP;
+    const size_t a_pad = (a_len + TA_BLOB_SLACK + 255) & ~(size_t)255, b_pad = (b_len + TA_BLOB_SLACK + 255) & ~(size_t)255;
+    Scratch &sc = tls_scratch(0);
+    int rc = sc.ensure(a_pad + b_pad + 256);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)sc.dev;
+    if (a_len) TA_HIP(hipMemcpyAsync(base, a, a_len, hipMemcpyHostToDevice, 0));
+    if (b_len) TA_HIP(hipMemcpyAsync(base + a_pad, b, b_len, hipMemcpyHostToDevice, 0));
+    *sa = ta_strings{base, nullptr, 0, a_len, a_len};
+    *sb = ta_strings{base + a_pad, nullptr, 0, b_len, b_len};
+    *out_dev = (uint32_t *)(base + a_pad + b_pad);
+    return TA_OK;
+}
+
+static int fetch_u32(uint32_t *dev, uint32_t *out) {
+    TA_HIP(hipMemcpyAsync(out, dev, 4, hipMemcpyDeviceToHost, 0));
+    TA_HIP(hipStreamSynchronize(0));
+    return TA_OK;
+}
+
+int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
+    if (!out) return TA_ERR_ARG;
+    if (a_len != b_len) return TA_ERR_LEN_MISMATCH;          // src/hamming.rs:318
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    if (rc) return rc;
+    rc = ta_hamming_batch(&sa, &sb, 1, od, 0);
+    if (rc) return rc;
+    return fetch_u32(od, out);
+}
+
+int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                                    uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out) {
+    if (!out) return TA_ERR_ARG;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (trace_on) return TA_ERR_UNSUPPORTED;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (a_len == 0 && b_len == 0) { *out = 0; return TA_OK; }   // src/levenshtein.rs:721-727
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    if (rc) return rc;
+    rc = ta_levenshtein_k_batch(&sa, &sb, 1, k, costs, od, 0);
+    if (rc) return rc;
+    return fetch_u32(od, out);
+}
+
+int ta_levenshtein_simd_k(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k, uint32_t *out) {
+    ta_edit_costs c = ta_levenshtein_costs();
+    return ta_levenshtein_simd_k_with_opts(a, a_len, b, b_len, k, 0, &c, out);
+}
+int ta_levenshtein(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
+    return ta_levenshtein_simd_k(a, a_len, b, b_len, 0xFFFFFFFFu, out);       // :1398
+}
+int ta_rdamerau(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
+    ta_edit_costs c = ta_rdamerau_costs();
+    return ta_levenshtein_simd_k_with_opts(a, a_len, b, b_len, 0xFFFFFFFFu, 0, &c, out);   // :1420
+}
+int ta_levenshtein_exp_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                                 int trace_on, const ta_edit_costs *costs, uint32_t *out) {
+    if (!out) return TA_ERR_ARG;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (trace_on) return TA_ERR_UNSUPPORTED;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (a_len == 0 && b_len == 0) { *out = 0; return TA_OK; }
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    if (rc) return rc;
+    rc = ta_levenshtein_exp_batch(&sa, &sb, 1, costs, od, 0);
+    if (rc) return rc;
+    return fetch_u32(od, out);
+}
+int ta_levenshtein_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
+    ta_edit_costs c = ta_levenshtein_costs();
+    return ta_levenshtein_exp_with_opts(a, a_len, b, b_len, 0, &c, out);
+}
+int ta_rdamerau_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
+    ta_edit_costs c = ta_rdamerau_costs();
+    return ta_levenshtein_exp_with_opts(a, a_len, b, b_len, 0, &c, out);
+}
+
+}  // extern "C"

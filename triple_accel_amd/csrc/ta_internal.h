@@ -1,0 +1,66 @@
+// ta_internal.h -- host-side plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/triple_accel_amd.h"
+#include "lev_band_body.h"
+#include "lev_plan.h"
+
+namespace ta {
+
+void set_last_error(const char *what, hipError_t e);
+void set_last_error_msg(const char *msg);
+
+#define TA_HIP(expr)                                        \
+    do {                                                    \
+        hipError_t e__ = (expr);                            \
+        if (e__ != hipSuccess) {                            \
+            ::ta::set_last_error(#expr, e__);               \
+            return TA_ERR_HIP;                              \
+        }                                                   \
+    } while (0)
+
+// Thread-local grow-only device scratch (single-call host API staging).
+struct Scratch {
+    void *dev = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);   // TA_OK / TA_ERR_HIP
+    ~Scratch();
+};
+Scratch &tls_scratch(int which);
+
+// true when a HIP device is usable (lazy, cached)
+bool device_ready();
+
+// kernels (defined in the .hip files)
+hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s,
+                           uint32_t *grid_out, uint32_t *lds_out);
+hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
+                           uint32_t *threads_out, uint32_t *dpt_out);
+bool lev_wide_fits(uint32_t need_diagonals);
+hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t *out, hipStream_t s);
+hipError_t strings_maxlen_launch(const StrView &s, uint32_t n, uint32_t *out_max /*device, pre-zeroed*/, hipStream_t st);
+hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out,
+                               uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
+hipError_t iota_launch(uint32_t *p, uint32_t n, hipStream_t st);
+
+struct SearchParams {
+    const uint8_t *hay;       // device
+    uint64_t hay_len;
+    uint8_t needle[256];      // by value (kernarg)
+    uint32_t needle_len;
+    uint32_t k, mc, gc, sg, tc;
+    uint32_t anchored;
+    uint32_t halo;            // bytes of left context each tile recomputes
+    uint32_t tile;            // haystack positions emitted per lane
+    uint64_t base, emit_from;
+    ta_match *hits;           // device
+    uint64_t cap;
+    unsigned long long *count;   // device
+};
+hipError_t lev_search_launch(const SearchParams &P, bool affine, bool trans, hipStream_t s);
+hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
+
+}  // namespace ta

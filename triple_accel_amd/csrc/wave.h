@@ -1,0 +1,126 @@
+// wave.h -- the tiny "wavefront" vocabulary the kernels are written in.
+//
+// Kernel bodies are templates over a wave policy W.  DevWave maps every operation to one
+// CDNA4 instruction (U32 = a VGPR, cross-lane = DPP wave_shr/wave_shl, LDS = ds_*).
+// EmuWave (emu/emu_wave.h, host only, TESTS ONLY) runs the same body with U32 = 64 lanes
+// in lock-step so the index math can be checked in a GPU-less container -- it is not a
+// product fallback and is never linked into libtriple_accel_amd.so.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TA_HD __host__ __device__
+#else
+#define TA_HD
+#endif
+
+namespace ta {
+
+struct StrView {            // device view of ta_strings (include/triple_accel_amd.h)
+    const uint8_t *blob;
+    const uint64_t *off;    // n+1 CSR offsets or nullptr (strided form)
+    uint64_t stride;
+    uint64_t len;
+};
+
+struct Q128 { uint32_t x, y, z, w; };
+
+#if defined(__HIPCC__)
+
+struct DevWave {
+    using U32 = uint32_t;
+    using Bool = bool;
+    using Ptr = const uint8_t *;
+
+    static __device__ __forceinline__ U32 lane() {
+        return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    }
+    static __device__ __forceinline__ U32 splat(uint32_t x) { return x; }
+    static __device__ __forceinline__ U32 sel(Bool c, U32 a, U32 b) { return c ? a : b; }
+    static __device__ __forceinline__ U32 umin(U32 a, U32 b) { return a < b ? a : b; }
+    static __device__ __forceinline__ U32 umin3(U32 a, U32 b, U32 c) { return umin(umin(a, b), c); }
+    static __device__ __forceinline__ U32 udiv(U32 a, uint32_t d) { return a / d; }
+    // ({hi,lo} >> 8*n)[31:0], n in 0..3  -> v_alignbyte_b32
+    template <int N> static __device__ __forceinline__ U32 alignbyte(U32 hi, U32 lo) {
+        return __builtin_amdgcn_alignbyte(hi, lo, N);
+    }
+    static __device__ __forceinline__ U32 mul24(U32 a, uint32_t b) { return __umul24(a, b); }
+    // byte N of x, zero-extended (folds into the consumer as an SDWA byte select)
+    static __device__ __forceinline__ U32 byte_of(U32 x, int n) { return (x >> (8 * n)) & 0xffu; }
+    // (a & mask) | (b & ~mask) -> v_bfi_b32
+    static __device__ __forceinline__ U32 bfi(uint32_t mask, U32 a, U32 b) { return (a & mask) | (b & ~mask); }
+
+    // lane i <- lane i-1 (lane 0 <- fill): DPP wave_shr:1
+    static __device__ __forceinline__ U32 from_lower(U32 x, U32 fill) {
+        return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
+    }
+    // lane i <- lane i+1 (lane 63 <- fill): DPP wave_shl:1
+    static __device__ __forceinline__ U32 from_upper(U32 x, U32 fill) {
+        return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130, 0xf, 0xf, false);
+    }
+    static __device__ __forceinline__ U32 shfl(U32 x, U32 src_lane) {
+        return (U32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)x);
+    }
+    static __device__ __forceinline__ Ptr shfl_ptr(Ptr p, U32 src_lane) {
+        uint64_t v = (uint64_t)p;
+        uint32_t lo = shfl((uint32_t)v, src_lane), hi = shfl((uint32_t)(v >> 32), src_lane);
+        return (Ptr)(((uint64_t)hi << 32) | lo);
+    }
+    static __device__ __forceinline__ bool any(Bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+    static __device__ __forceinline__ uint32_t wave_max(U32 x) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            U32 y = shfl(x, lane() ^ (uint32_t)m);
+            x = x > y ? x : y;
+        }
+        return __builtin_amdgcn_readfirstlane(x);
+    }
+
+    static __device__ __forceinline__ void load_str(const StrView &s, U32 idx, Bool valid, Ptr &p, U32 &len) {
+        if (valid) {
+            if (s.off) {
+                uint64_t o0 = s.off[idx], o1 = s.off[idx + 1];
+                p = s.blob + o0;
+                len = (uint32_t)(o1 - o0);
+            } else {
+                p = s.blob + (uint64_t)idx * s.stride;
+                len = (uint32_t)s.len;
+            }
+        } else {
+            p = s.blob;
+            len = 0;
+        }
+    }
+    static __device__ __forceinline__ U32 load_u32(const uint32_t *p, U32 idx, Bool valid, uint32_t dflt) {
+        return valid ? p[idx] : dflt;
+    }
+    static __device__ __forceinline__ void store_u32(uint32_t *p, U32 idx, U32 v, Bool pred) {
+        if (pred) p[idx] = v;
+    }
+    static __device__ __forceinline__ Ptr ptr_add(Ptr p, U32 off) { return p + off; }
+    static __device__ __forceinline__ Ptr sel_ptr(Bool c, Ptr a, Ptr b) { return c ? a : b; }
+    // 16 bytes from an arbitrarily aligned global address (zeros where !pred)
+    static __device__ __forceinline__ Q128 gload16(Ptr p, Bool pred) {
+        Q128 q = {0u, 0u, 0u, 0u};
+        if (pred) {
+            typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+            u32x4u v = *(const u32x4u *)p;
+            q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+        }
+        return q;
+    }
+    static __device__ __forceinline__ void lds_store16(uint8_t *lds, U32 off, Q128 q, Bool pred) {
+        if (pred) *(uint4 *)(lds + off) = make_uint4(q.x, q.y, q.z, q.w);
+    }
+    static __device__ __forceinline__ U32 lds_u8(const uint8_t *lds, U32 off) { return lds[off]; }
+    // this wave's LDS writes become visible to its own later LDS reads (same-wave DS ops are
+    // ordered in hardware; this only stops the compiler from moving them)
+    static __device__ __forceinline__ void lds_wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+#endif  // __HIPCC__
+
+}  // namespace ta
