@@ -55,7 +55,9 @@ struct EmuWave {
         for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> (8 * N));
         return r;
     }
-    static U32 mul24(const U32 &a, uint32_t b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & 0xffffffu) * (b & 0xffffffu); return r; }
+    static U32 dot4_byte(const U32 &x, int n, uint32_t m, const U32 &acc) {
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + ((x.v[i] >> (8 * n)) & 0xffu) * (m & 0xffu); return r;
+    }
     static U32 byte_of(const U32 &x, int n) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] >> (8 * n)) & 0xffu; return r; }
     static U32 bfi(uint32_t mask, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask); return r; }
     static U32 from_lower(const U32 &x, const U32 &fill) { V32 r; r.v[0] = fill.v[0]; for (int i = 1; i < 64; i++) r.v[i] = x.v[i - 1]; return r; }

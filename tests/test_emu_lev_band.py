@@ -47,7 +47,7 @@ def test_emu_lane_layouts(force_D, force_L):
     """cfg2-like band (k chosen so the needed diagonals fit the forced layout) on every (D, L) shape."""
     cap = force_D * (force_L if force_L else 64)
     k = min(32, max(0, (cap - 2) // 2))
-    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 2, 1, 3)]:
         a, b = make_pairs(7 + force_D, 70, 90, max(1, k), costs[3] is not None)
         got, plan = E.lev_band(a, b, k, costs, force_D=force_D, force_L=force_L)
         assert plan["D"] == force_D
@@ -98,7 +98,7 @@ def test_emu_null_bytes_and_edges():
     (tests/basic_tests.rs:503-537)."""
     a = [b"\0", b"ab\0de", b"\0b", b"\0", b"\0", b"\0\0b\0", b"x", b"", b"a" * 70, b"\0" * 40]
     b = [b"", b"a\0bde", b"b\0", b"\0\0", b"\0", b"\0b\0\0", b"x\0", b"\0\0\0", b"", b"\0" * 37 + b"a"]
-    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 2, 1, 3)]:
         for k in (0, 1, 2, 5, 100):
             got, plan = E.lev_band(a, b, k, costs)
             assert got == oracle(a, b, k, costs), (k, costs, plan)

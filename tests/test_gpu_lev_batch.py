@@ -44,7 +44,7 @@ def test_dpp_and_layouts(monkeypatch):
         monkeypatch.setenv("TA_FORCE_L", str(force_L))
         cap = force_D * (force_L if force_L else 64)
         k = min(32, max(0, (cap - 2) // 2))
-        for costs in [(1, 1, 0, None), (1, 1, 0, 1), (1, 1, 2, 2)]:
+        for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 2, 1, 3)]:
             got = gpu_k(a, b, k, costs)
             want = oracle_k(a, b, k, costs)
             assert np.array_equal(got, want), (force_D, force_L, k, costs, np.flatnonzero(got != want)[:10])
@@ -71,7 +71,7 @@ def test_cfg2_shape_100k():
     assert info["kernel"] == 1 and info["cell_bits"] == 8
     want = O.levenshtein_k_batch(O.csr_from_fixed(a), O.csr_from_fixed(b), 32)
     assert np.array_equal(out, want)
-    assert (want[: n // 2] == 0xFFFFFFFF).all() and (want[n // 2:] != 0xFFFFFFFF).mean() > 0.9
+    assert (want[: n // 2] == 0xFFFFFFFF).all() and (want[n // 2:] != 0xFFFFFFFF).mean() > 0.2
 
 
 def test_cfg4_shape_100k():

@@ -29,6 +29,7 @@ namespace ta {
 constexpr uint32_t LEV_INF = 0x3FFFFFFFu;   // "unreachable"; real costs stay far below (n+m < 2^22)
 constexpr int LEV_CH = 64;                  // iterations (= bytes per string) per streamed chunk
 constexpr int LEV_RING = 2 * LEV_CH;        // ring bytes per (pair, string) slot in LDS
+constexpr int LEV_SLOT = LEV_RING + 4;      // slot stride: odd number of dwords -> the per-pair byte reads hit distinct banks
 
 struct LevParams {
     StrView a, b;
@@ -86,19 +87,18 @@ struct LevBand {
             xr = W::from_upper(AFFINE ? st.HB[0] : st.HA[0], INF);
             xr = W::sel(is_gl, INF, xr);
         }
-        // per byte: (a != b) ? mismatch_cost : 0, four cells per VGPR (SWAR), so that each cell's
-        // substitution cost is ONE byte-select add (v_add_u32_sdwa)
+        // per byte: 1 where a != b, four cells per VGPR (SWAR); each cell's substitution cost is then ONE
+        // v_dot4_u32_u8 with a one-hot byte of mismatch_cost: reg + flag_byte * mc
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             U32 t = (X[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;      // bit 7 of each byte <- low 7 bits nonzero
-            t = ((t | X[w]) >> 7) & 0x01010101u;              // 1 per nonzero byte
-            X[w] = W::mul24(t, P.mc);                         // mc <= 255: no carry between bytes
+            X[w] = ((t | X[w]) >> 7) & 0x01010101u;           // 1 per nonzero byte
         }
 #pragma unroll
         for (int c = 0; c < Dh; c++) {
             const int q = 2 * c + PAR;
             const int byte = c + 1, w = byte >> 2;
-            U32 sub = st.reg[q] + W::byte_of(X[w], byte & 3);        // :471-475
+            U32 sub = W::dot4_byte(X[w], byte & 3, P.mc, st.reg[q]);              // :471-475
             U32 lft = (PAR == 0 && c == 0) ? xl : st.HA[q > 0 ? q - 1 : 0];                   // a_gap  :476-483
             U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[q + 1 < D ? q + 1 : D - 1] : st.HA[q + 1 < D ? q + 1 : D - 1]);   // b_gap :484-491
             U32 nv = W::umin3(sub, lft, rgt);                                     // :493-515
@@ -161,7 +161,7 @@ struct LevBand {
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
             auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, pb, pa), idx0), ok);
-            W::lds_store16(lds, slot * LEV_RING + (y0 & (LEV_RING - 1)), q, pred);
+            W::lds_store16(lds, slot * LEV_SLOT + (y0 & (LEV_RING - 1)), q, pred);
         }
     }
 
@@ -221,7 +221,7 @@ struct LevBand {
         }
         U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
 
-        const U32 a_slot = (grp * 2u) * LEV_RING, b_slot = (grp * 2u + 1u) * LEV_RING;
+        const U32 a_slot = (grp * 2u) * LEV_SLOT, b_slot = (grp * 2u + 1u) * LEV_SLOT;
 
         load_chunk(lds, P, 0, lane, aptr, alen, bptr, blen, ea, eb);
         load_chunk(lds, P, 1, lane, aptr, alen, bptr, blen, ea, eb);

@@ -43,7 +43,7 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t gc, uint32_t sg, uint64
         double cost = (5.0 * D + 24.0) / PW * (D > 40 ? 1.25 : 1.0);
         if (cost < best) { best = cost; p.D = D; p.L = L; p.PW = PW; p.ok = true; }
     }
-    if (p.ok) p.lds_per_wave = 2u * p.PW * 128u;   // LEV_RING bytes per (pair, string)
+    if (p.ok) p.lds_per_wave = (2u * p.PW * 132u + 15u) & ~15u;   // LEV_SLOT bytes per (pair, string)
     return p;
 }
 

@@ -44,7 +44,10 @@ struct DevWave {
     template <int N> static __device__ __forceinline__ U32 alignbyte(U32 hi, U32 lo) {
         return __builtin_amdgcn_alignbyte(hi, lo, N);
     }
-    static __device__ __forceinline__ U32 mul24(U32 a, uint32_t b) { return __umul24(a, b); }
+    // acc + byte n of x * m  (m <= 255)  -> v_dot4_u32_u8 with a one-hot multiplier
+    static __device__ __forceinline__ U32 dot4_byte(U32 x, int n, uint32_t m, U32 acc) {
+        return __builtin_amdgcn_udot4(x, m << (8 * n), acc, false);
+    }
     // byte N of x, zero-extended (folds into the consumer as an SDWA byte select)
     static __device__ __forceinline__ U32 byte_of(U32 x, int n) { return (x >> (8 * n)) & 0xffu; }
     // (a & mask) | (b & ~mask) -> v_bfi_b32
@@ -109,7 +112,10 @@ struct DevWave {
         return q;
     }
     static __device__ __forceinline__ void lds_store16(uint8_t *lds, U32 off, Q128 q, Bool pred) {
-        if (pred) *(uint4 *)(lds + off) = make_uint4(q.x, q.y, q.z, q.w);
+        if (pred) {   // 4-byte aligned only (slot stride is an odd number of dwords)
+            uint32_t *d = (uint32_t *)(lds + off);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
     }
     static __device__ __forceinline__ U32 lds_u8(const uint8_t *lds, U32 off) { return lds[off]; }
     // this wave's LDS writes become visible to its own later LDS reads (same-wave DS ops are
