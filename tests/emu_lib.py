@@ -19,6 +19,10 @@ def lib():
         L.emu_lev_band.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_lev_search.restype = C.c_int
+        L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
+                                     C.c_uint64, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -49,3 +53,28 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
         raise RuntimeError("emu_lev_band rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(D=int(plan[0]), L=int(plan[1]), PW=int(plan[2]), u=int(plan[3]), o=int(plan[4]))
+
+
+def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False, tile=64, halo=None):
+    """All-mode hits [(start, end, k)] of the tile function run over a tiled haystack (halo = n + unit_k + 2)."""
+    mc, gc, sg, tc = costs
+    n = len(needle)
+    if halo is None:
+        halo = n + max(0, k - sg) // gc + 2
+    hay = np.zeros(len(haystack) + 16, dtype=np.uint8)
+    hay[:len(haystack)] = np.frombuffer(haystack, dtype=np.uint8)
+    h = len(haystack)
+    if anchored:
+        h = min(h, n + max(0, k - sg) // gc)
+        tile, halo = 1 << 40, 0
+    cap = len(haystack) + 2
+    out = np.zeros((cap, 3), dtype=np.uint64)
+    cnt = C.c_uint64()
+    rc = lib().emu_lev_search(needle, n, hay.ctypes.data, h, k, mc, gc, sg, 0 if tc is None else 1,
+                              0 if tc is None else tc, int(anchored), tile, halo, out.ctypes.data, cap, C.byref(cnt))
+    if rc:
+        raise RuntimeError("emu_lev_search rc=%d" % rc)
+    res = []
+    for i in range(cnt.value):
+        res.append((int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))))
+    return res

@@ -1,0 +1,56 @@
+"""Search tile function (lev_search_body.h) on the host: tiled + halo == monolithic scalar oracle (All mode),
+for every cost family incl. transposition and affine gaps -- the empirical halo-equivalence proof SURVEY.md 8e asks for."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (3, 1, 0, None), (1, 1, 2, None), (2, 1, 2, None), (2, 2, 1, 3), (1, 2, 0, 1)]
+
+
+def oracle_all(needle, hay, k, costs, anchored=False):
+    hits = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, anchored)
+    return [h for h in hits if h[1] > 0]      # the end == 0 match is a host special case
+
+
+@pytest.mark.parametrize("costs", COSTS)
+def test_tiled_equals_monolithic(costs):
+    assert O.costs_valid(costs) and O.costs_valid_search(costs)
+    g = Dg.rng(41)
+    for n in (1, 3, 8, 13, 32):
+        needle = Dg.rand_str(g, n)
+        for k in (0, 1, n // 4 + 1, (n + 1) // 2):
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 1500, 60, max(1, k))
+            want = oracle_all(needle, hay, k, costs)
+            for tile in (1 << 30, 64, 97, 256):
+                tile = max(tile, 1)
+                got = E.lev_search_tiled(needle, hay, k, costs, tile=tile)
+                assert got == want, (n, k, tile, costs)
+
+
+def test_small_alphabet_ties():
+    """Binary-alphabet haystacks maximise cost ties, which is where the length tie rules (quirk Q2) bite."""
+    g = Dg.rng(8)
+    for costs in COSTS:
+        for _ in range(30):
+            n = int(g.integers(1, 9))
+            needle = g.integers(97, 99, size=n, dtype=np.uint8).tobytes()
+            hay = g.integers(97, 99, size=int(g.integers(0, 80)), dtype=np.uint8).tobytes()
+            k = int(g.integers(0, n + 1))
+            want = oracle_all(needle, hay, k, costs)
+            for tile in (1 << 30, 16, 33):
+                assert E.lev_search_tiled(needle, hay, k, costs, tile=tile) == want, (needle, hay, k, costs, tile)
+
+
+def test_anchored():
+    g = Dg.rng(3)
+    for costs in COSTS:
+        for _ in range(30):
+            n = int(g.integers(1, 12))
+            needle = Dg.rand_str(g, n)
+            hay = Dg.mutate(g, needle, 3, costs[3] is not None) + Dg.rand_str(g, 20)
+            k = int(g.integers(0, 6))
+            want = oracle_all(needle, hay, k, costs, anchored=True)
+            assert E.lev_search_tiled(needle, hay, k, costs, anchored=True) == want

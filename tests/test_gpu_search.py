@@ -1,0 +1,92 @@
+"""-m gpu: levenshtein_search / hamming_search kernels (through the C ABI) against the scalar oracle."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (3, 1, 0, None), (1, 1, 2, None), (2, 1, 2, None), (2, 2, 1, 3)]
+
+
+def prod_search(needle, hay, k, st, costs, anchored=False):
+    import triple_accel_amd as T
+    return [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, k, st, T.EditCosts(*costs), anchored)]
+
+
+@pytest.mark.parametrize("costs", COSTS)
+def test_search_all_and_best_vs_oracle(costs):
+    g = Dg.rng(41)
+    for n in (1, 3, 8, 13, 24, 32):
+        needle = Dg.rand_str(g, n)
+        for k in (0, 1, (n + 1) // 2):
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 20000, 150, max(1, k))
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (n, k, st, costs)
+
+
+def test_search_ties_small_alphabet():
+    g = Dg.rng(8)
+    for costs in COSTS:
+        for _ in range(15):
+            n = int(g.integers(1, 9))
+            needle = g.integers(97, 99, size=n, dtype=np.uint8).tobytes()
+            hay = g.integers(97, 99, size=int(g.integers(0, 300)), dtype=np.uint8).tobytes()
+            k = int(g.integers(0, n + 1))
+            for st in (O.ALL, O.BEST):
+                for anchored in (False, True):
+                    want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, anchored)
+                    assert prod_search(needle, hay, k, st, costs, anchored) == want, (needle, hay, k, st, anchored)
+
+
+def test_default_search_is_best_half_k():
+    import triple_accel_amd as T
+    needle = b"helllo world!!"
+    hay = Dg.planted_haystack(5, needle, 5000, 400, 3)
+    want = O.levenshtein_search_naive_with_opts(needle, hay, O.default_search_k(len(needle)), O.BEST)
+    assert [tuple(m) for m in T.levenshtein_search(needle, hay)] == want
+    assert [tuple(m) for m in T.levenshtein_search(b"", b"abc")] == []
+
+
+def test_search_cfg5_geometry_shard():
+    """BASELINE cfg5 geometry scaled to what the oracle finishes in seconds: 32 B needle, k = 16, Best,
+    a 4 MiB random shard with planted mutated copies."""
+    import triple_accel_amd as T
+    g = Dg.rng(0x7A05)
+    needle = Dg.random_bytes(g, 32).tobytes()
+    hay = bytearray(Dg.random_bytes(g, 4 << 20).tobytes())
+    for pos in range(10000, len(hay) - 100, 300000):
+        m = Dg.mutate(g, needle, 10)
+        hay[pos:pos + len(m)] = m
+    hay = bytes(hay)
+    for st in (O.ALL, O.BEST):
+        want = O.levenshtein_search_naive_with_opts(needle, hay, 16, st)
+        got = [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, 16, st, T.LEVENSHTEIN_COSTS, False)]
+        assert got == want and len(want) > 0
+
+
+def test_hamming_search():
+    import triple_accel_amd as T
+    g = Dg.rng(9)
+    for n in (1, 3, 4, 10, 33, 100):
+        needle = Dg.rand_str(g, n)
+        hay = bytearray(Dg.rand_str(g, 30000))
+        for pos in range(100, 29000, 777):
+            m = bytearray(needle)
+            for p in g.choice(n, size=min(n, 2), replace=False):
+                m[p] = 32
+            hay[pos:pos + n] = m
+        hay = bytes(hay)
+        for k in (0, 1, 3):
+            for st in (O.ALL, O.BEST):
+                want = O.hamming_search_simd_with_opts(needle, hay, k, st)
+                got = [tuple(m) for m in T.hamming_search_simd_with_opts(needle, hay, k, st)]
+                assert got == want, (n, k, st)
+    assert list(T.hamming_search(b"abc", b"ab")) == []
+    assert list(T.hamming_search(b"", b"ab")) == []
+    with pytest.raises(T.PanicError):
+        list(T.hamming_search(b"ab", b"a\x00b"))
+    want = O.hamming_search_simd_with_opts(b"abc", b"  abc  abb", O.default_search_k(3), O.BEST)
+    assert [tuple(m) for m in T.hamming_search(b"abc", b"  abc  abb")] == want

@@ -1,0 +1,101 @@
+// lev_search_body.h -- semi-global (free start in the haystack) Levenshtein search over one haystack tile.
+//
+// Replaces levenshtein_search_simd_core_* (src/levenshtein.rs:2157-2451); the per-cell recurrence,
+// the companion match-length and every tie rule follow the SCALAR text levenshtein_search_naive_with_opts
+// (src/levenshtein.rs:1709-1806), which is the bit-exactness target.
+//
+// One lane owns one tile of consecutive haystack end positions and keeps the whole DP column
+// (needle rows 0..n, cost + length + the needle-gap state) in VGPRs, advancing one haystack byte per
+// step; a tile starts `halo` bytes early with the fresh-start column so that every cell of cost <= k it
+// reports is exact (any alignment of cost <= k spans at most n + unit_k haystack bytes).
+// Plain host/device code (no cross-lane traffic), so tests run the same function on the CPU.
+#pragma once
+#include <stdint.h>
+
+#include "wave.h"
+
+namespace ta {
+
+constexpr uint32_t SRCH_INF = 0x3FFFFFFFu;
+
+struct SearchCosts {
+    uint32_t k, mc, gc, sg, tc;
+    uint32_t anchored;
+};
+
+// Emit(end_local_index_plus_1, length, cost) is called for every reported column in increasing order.
+template <int N, bool TRANS, class Emit>
+TA_HD inline void lev_search_tile(const uint8_t *hay, const uint8_t *needle, uint32_t n, const SearchCosts &C,
+                                  uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Emit emit) {
+    uint32_t dp1[N + 1], l1[N + 1], ng[N + 1], ngl[N + 1];
+    uint32_t dp0[TRANS ? N + 1 : 1], l0[TRANS ? N + 1 : 1];
+    const uint32_t sgc = C.sg + C.gc;
+#pragma unroll
+    for (int j = 0; j <= N; j++) {                       // the closure's first call, :1685-1690
+        dp1[j] = (uint32_t)j * C.gc + (j == 0 ? 0u : C.sg);
+        l1[j] = 0; ng[j] = SRCH_INF; ngl[j] = 0;
+        if (TRANS) { dp0[j] = 0; l0[j] = 0; }
+    }
+    if (col_begin >= col_end) return;
+    uint32_t c_prev = 0;
+    uint32_t c_next = hay[col_begin];
+    for (uint64_t i = col_begin; i < col_end; i++) {
+        const uint32_t c = c_next;
+        if (i + 1 < col_end) c_next = hay[i + 1];        // one-ahead prefetch of the lane's byte stream
+        const bool first_col = (i == col_begin);         // transposition needs a previous haystack byte (:1769)
+        // row 0  (:1710-1721)
+        const uint32_t c0 = C.anchored ? ((uint32_t)(i + 1)) * C.gc + C.sg : 0u;
+        uint32_t up_dp = c0, up_l = 0;                   // dp2[j-1], length2[j-1]
+        uint32_t diag_dp = dp1[0], diag_l = l1[0];       // dp1[j-1], length1[j-1]
+        uint32_t hg = SRCH_INF, hgl = 0;                 // haystack_gap_dp[j-1], haystack_gap_length[j-1]
+        uint32_t z1_dp = 0, z1_l = 0, z2_dp = 0, z2_l = 0;   // dp0[j-1], dp0[j-2] before they are overwritten
+        if (TRANS) { z1_dp = dp0[0]; z1_l = l0[0]; dp0[0] = dp1[0]; l0[0] = l1[0]; }
+        dp1[0] = c0; l1[0] = 0;
+#pragma unroll
+        for (int j = 1; j <= N; j++) {
+            if ((uint32_t)j <= n) {
+                const uint32_t nb = needle[j - 1];
+                const uint32_t old_dp = dp1[j], old_l = l1[j];
+                uint32_t sub = diag_dp + (nb != c ? C.mc : 0u);                          // :1724
+
+                uint32_t new_gap = old_dp + sgc;                                         // :1726-1737
+                uint32_t cont_gap = ng[j] + C.gc;
+                uint32_t g_l = (new_gap < cont_gap) ? old_l
+                             : (new_gap > cont_gap) ? ngl[j]
+                             : (old_l > ngl[j] ? old_l : ngl[j]);
+                ng[j] = new_gap < cont_gap ? new_gap : cont_gap;
+                ngl[j] = g_l + 1;
+
+                uint32_t new_gap2 = up_dp + sgc;                                         // :1739-1750
+                uint32_t cont_gap2 = hg + C.gc;
+                uint32_t h_l = (new_gap2 < cont_gap2) ? up_l
+                             : (new_gap2 > cont_gap2) ? hgl
+                             : (up_l > hgl ? up_l : hgl);
+                hg = new_gap2 < cont_gap2 ? new_gap2 : cont_gap2;
+                hgl = h_l;
+
+                uint32_t v = ng[j], vl = ngl[j];                                         // :1752-1753
+                if ((hg < v) || (hg == v && up_l > vl)) { v = hg; vl = hgl; }            // :1755-1760 (reads length2[j-1])
+                if ((sub < v) || (sub == v && (diag_l + 1) > vl)) { v = sub; vl = diag_l + 1; }   // :1762-1765
+                if (TRANS) {
+                    const uint32_t t_dp = z2_dp, t_l = z2_l;                             // dp0[j-2], length0[j-2]
+                    z2_dp = z1_dp; z2_l = z1_l;
+                    z1_dp = dp0[j]; z1_l = l0[j];
+                    dp0[j] = old_dp; l0[j] = old_l;
+                    if (j > 1 && !first_col && nb == c_prev && (uint32_t)needle[j - 2] == c) {   // :1767-1779
+                        uint32_t t = t_dp + C.tc;
+                        if (t <= v) { v = t; vl = t_l + 2; }
+                    }
+                }
+                dp1[j] = v; l1[j] = vl;
+                diag_dp = old_dp; diag_l = old_l;
+                up_dp = v; up_l = vl;
+            }
+        }
+        c_prev = c;
+        const uint32_t res = up_dp, len = up_l;          // dp2[len-1], length2[len-1] (:1782-1783)
+        if (res <= C.k && i >= emit_begin) emit(i + 1, len, res);     // :1792-1806
+    }
+}
+
+}  // namespace ta

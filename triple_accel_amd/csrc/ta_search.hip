@@ -1,17 +1,243 @@
-// ta_search.hip -- search entry points (placeholder until the kernels land).
+// ta_search.hip -- search entry points of the C ABI: special cases, haystack tiling, hit gathering,
+// and the order-dependent Best post-pass (host).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "ta_internal.h"
 
-extern "C" {
-int ta_levenshtein_search_simd_with_opts(const uint8_t *, size_t, const uint8_t *, size_t, uint32_t, int,
-                                         const ta_edit_costs *, int, ta_match **, size_t *) { return TA_ERR_UNSUPPORTED; }
-int ta_levenshtein_search(const uint8_t *, size_t, const uint8_t *, size_t, ta_match **, size_t *) { return TA_ERR_UNSUPPORTED; }
-int ta_hamming_search_simd_with_opts(const uint8_t *, size_t, const uint8_t *, size_t, uint32_t, int, ta_match **, size_t *) { return TA_ERR_UNSUPPORTED; }
-int ta_hamming_search(const uint8_t *, size_t, const uint8_t *, size_t, ta_match **, size_t *) { return TA_ERR_UNSUPPORTED; }
-int ta_levenshtein_search_dev(const uint8_t *, size_t, const uint8_t *, size_t, uint32_t, const ta_edit_costs *, int,
-                              uint64_t, uint64_t, ta_match *, size_t, uint64_t *, void *) { return TA_ERR_UNSUPPORTED; }
-int ta_hamming_search_dev(const uint8_t *, size_t, const uint8_t *, size_t, uint32_t, uint64_t, ta_match *, size_t,
-                          uint64_t *, void *) { return TA_ERR_UNSUPPORTED; }
-size_t ta_search_fold_best(ta_match *, size_t, uint32_t, int) { return 0; }
+namespace ta {
+hipError_t has_zero_byte_launch(const uint8_t *p, uint64_t len, uint32_t *flag, hipStream_t s);
+
+static bool search_costs_ok(const ta_edit_costs *c) {
+    if (!c || !(c->mismatch_cost > 0) || !(c->gap_cost > 0)) return false;
+    if (c->has_transpose) {
+        if (!(c->transpose_cost > 0) || !((c->transpose_cost >> 1) < c->mismatch_cost) ||
+            !((c->transpose_cost >> 1) < c->gap_cost))
+            return false;
+    }
+    return true;
 }
+
+// tile size: enough tiles to fill the chip (>= ~128K lanes) while keeping the halo overhead small
+static uint32_t pick_tile(uint64_t hay_len, uint32_t halo) {
+    uint64_t t = (hay_len + 131071) / 131072;
+    uint64_t lo = (uint64_t)halo * 2;
+    if (t < lo) t = lo;
+    if (t < 64) t = 64;
+    if (t > 65536) t = 65536;
+    return (uint32_t)t;
+}
+
+static void fill_params(SearchParams &P, const uint8_t *needle, size_t n, const uint8_t *hay, size_t h, uint32_t k,
+                        const ta_edit_costs *c, int anchored, uint64_t base, uint64_t emit_from, ta_match *hits,
+                        size_t cap, unsigned long long *count) {
+    memset(&P, 0, sizeof(P));
+    P.hay = hay; P.hay_len = h;
+    memcpy(P.needle, needle, n);
+    P.needle_len = (uint32_t)n;
+    P.k = k;
+    if (c) {
+        P.mc = c->mismatch_cost; P.gc = c->gap_cost; P.sg = c->start_gap_cost;
+        P.tc = c->has_transpose ? c->transpose_cost : 0;
+    }
+    P.anchored = anchored ? 1 : 0;
+    P.base = base; P.emit_from = emit_from; P.hits = hits; P.cap = cap; P.count = count;
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" {
+
+int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
+                              const uint8_t *haystack_dev, size_t haystack_len,
+                              uint32_t k, const ta_edit_costs *costs, int anchored,
+                              uint64_t base, uint64_t emit_from,
+                              ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+    if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+    if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;         // :1965
+    if (needle_len == 0) { set_last_error_msg("empty needle is handled by the host entry point"); return TA_ERR_ARG; }
+    if (needle_len > 32) {
+        set_last_error_msg("levenshtein_search on the GPU path supports needles up to 32 bytes in this round");
+        return TA_ERR_UNSUPPORTED;
+    }
+    if (!device_ready()) return TA_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch &cnt = tls_scratch(2);
+    int rc = cnt.ensure(16);
+    if (rc) return rc;
+    TA_HIP(hipMemsetAsync(cnt.dev, 0, 8, st));
+    SearchParams P;
+    size_t h = haystack_len;
+    const uint32_t unit_k = lev_sat_sub(k, costs->start_gap_cost) / costs->gap_cost;
+    if (anchored) {                                                                    // :1650-1658
+        uint64_t lim = (uint64_t)needle_len + unit_k;
+        if (lim < h) h = (size_t)lim;
+    }
+    fill_params(P, needle_host, needle_len, haystack_dev, h, k, costs, anchored, base, emit_from, hits_dev, cap,
+                (unsigned long long *)cnt.dev);
+    uint64_t halo64 = (uint64_t)needle_len + unit_k + 2;
+    if (halo64 > 0x7FFFFFFFull) halo64 = 0x7FFFFFFFull;
+    P.halo = (uint32_t)halo64;
+    P.tile = anchored ? 0x7FFFFFFFu : pick_tile(h, P.halo);
+    if (anchored) P.halo = 0;
+    TA_HIP(lev_search_launch(P, costs->start_gap_cost > 0, costs->has_transpose != 0, st));
+    unsigned long long c = 0;
+    TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    *count_host = c;
+    return c > cap ? TA_ERR_CAPACITY : TA_OK;
+}
+
+int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
+                          const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                          uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+    if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+    if (needle_len > 256) { set_last_error_msg("hamming_search on the GPU path supports needles up to 256 bytes"); return TA_ERR_UNSUPPORTED; }
+    if (!device_ready()) return TA_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    *count_host = 0;
+    if (needle_len == 0 || needle_len > haystack_len) return TA_OK;                     // src/hamming.rs:455-461
+    Scratch &cnt = tls_scratch(2);
+    int rc = cnt.ensure(16);
+    if (rc) return rc;
+    TA_HIP(hipMemsetAsync(cnt.dev, 0, 16, st));
+    TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, (uint32_t *)((uint8_t *)cnt.dev + 8), st));   // :463
+    SearchParams P;
+    fill_params(P, needle_host, needle_len, haystack_dev, haystack_len, k, nullptr, 0, base, 0, hits_dev, cap,
+                (unsigned long long *)cnt.dev);
+    TA_HIP(hamming_search_launch(P, st));
+    unsigned long long c[2] = {0, 0};
+    TA_HIP(hipMemcpyAsync(c, cnt.dev, 16, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    if ((uint32_t)c[1]) return TA_ERR_NULL_BYTE;
+    *count_host = c[0];
+    return c[0] > cap ? TA_ERR_CAPACITY : TA_OK;
+}
+
+// src/levenshtein.rs:1792-1796 + :1812-1835 (levenshtein) / src/hamming.rs:122-143 (overlap_fold = 0)
+size_t ta_search_fold_best(ta_match *hits, size_t n, uint32_t k, int overlap_fold) {
+    uint32_t curr_k = k;
+    size_t w = 0;
+    for (size_t r = 0; r < n; r++) {
+        if (hits[r].k > curr_k) continue;          // emitted only if res <= running curr_k
+        curr_k = hits[r].k;
+        if (overlap_fold && w > 0 && hits[r].start <= hits[w - 1].start) hits[w - 1] = hits[r];   // fully overlapping: replace
+        else hits[w++] = hits[r];
+    }
+    size_t o = 0;
+    for (size_t r = 0; r < w; r++)
+        if (hits[r].k == curr_k) hits[o++] = hits[r];
+    return o;
+}
+
+}  // extern "C"
+
+static int give(std::vector<ta_match> &v, ta_match **out, size_t *n_out) {
+    *n_out = v.size();
+    *out = nullptr;
+    if (!v.empty()) {
+        *out = (ta_match *)malloc(v.size() * sizeof(ta_match));
+        if (!*out) return TA_ERR_ARG;
+        memcpy(*out, v.data(), v.size() * sizeof(ta_match));
+    }
+    return TA_OK;
+}
+
+// stage a haystack into device scratch (with read slack) and collect the All-mode hits, sorted by end
+template <class Launch>
+static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::vector<ta_match> &hits, Launch launch) {
+    if (!device_ready()) return TA_ERR_HIP;
+    Scratch &hs = tls_scratch(0), &ob = tls_scratch(1);
+    int rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64);
+    if (rc) return rc;
+    size_t cap = haystack_len + 2;
+    if (cap > (1u << 26)) cap = (1u << 26);
+    if ((rc = ob.ensure(cap * sizeof(ta_match)))) return rc;
+    if (haystack_len) TA_HIP(hipMemcpyAsync(hs.dev, haystack, haystack_len, hipMemcpyHostToDevice, 0));
+    uint64_t count = 0;
+    rc = launch((const uint8_t *)hs.dev, (ta_match *)ob.dev, cap, &count);
+    if (rc) return rc;
+    hits.resize(count);
+    if (count) TA_HIP(hipMemcpy(hits.data(), ob.dev, count * sizeof(ta_match), hipMemcpyDeviceToHost));
+    std::sort(hits.begin(), hits.end(), [](const ta_match &x, const ta_match &y) {
+        return x.end != y.end ? x.end < y.end : x.start < y.start;
+    });
+    return TA_OK;
+}
+
+extern "C" {
+
+int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
+                                         const uint8_t *haystack, size_t haystack_len,
+                                         uint32_t k, int search_type, const ta_edit_costs *costs, int anchored,
+                                         ta_match **out, size_t *n_out) {
+    if (!out || !n_out || (!needle && needle_len) || (!haystack && haystack_len)) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    std::vector<ta_match> res;
+    if (needle_len == 0) {                                                 // src/levenshtein.rs:1919-1963
+        if (!anchored) return TA_OK;
+        res.push_back(ta_match{0, 0, 0, 0});
+        if (search_type == TA_SEARCH_ALL) {
+            uint32_t cost = costs->start_gap_cost;
+            for (size_t i = 0; i < haystack_len;) {
+                i += 1;
+                cost += costs->gap_cost;
+                if (cost <= k) res.push_back(ta_match{0, i, cost, 0}); else break;
+            }
+        }
+        return give(res, out, n_out);
+    }
+    if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;   // :1965
+    std::vector<ta_match> hits;
+    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt) {
+        if (haystack_len == 0) { *cnt = 0; return (int)TA_OK; }
+        return ta_levenshtein_search_dev(needle, needle_len, hd, haystack_len, k, costs, anchored, 0, 0, od, cap, cnt, 0);
+    });
+    if (rc) return rc;
+    // the match that ends before the first haystack byte (:1693-1706, SIMD :2394-2399)
+    const uint32_t whole_gap = (uint32_t)needle_len * costs->gap_cost + costs->start_gap_cost;
+    if (whole_gap <= k) res.push_back(ta_match{0, 0, whole_gap, 0});
+    res.insert(res.end(), hits.begin(), hits.end());
+    if (search_type == TA_SEARCH_BEST) res.resize(ta_search_fold_best(res.data(), res.size(), k, 1));
+    return give(res, out, n_out);
+}
+
+int ta_levenshtein_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                          ta_match **out, size_t *n_out) {                     // src/levenshtein.rs:1866-1878
+    ta_edit_costs c = ta_levenshtein_costs();
+    uint32_t k = (uint32_t)(needle_len >> 1) + ((uint32_t)needle_len & 1u);
+    return ta_levenshtein_search_simd_with_opts(needle, needle_len, haystack, haystack_len, k, TA_SEARCH_BEST, &c, 0,
+                                                out, n_out);
+}
+
+int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
+                                     const uint8_t *haystack, size_t haystack_len,
+                                     uint32_t k, int search_type, ta_match **out, size_t *n_out) {
+    if (!out || !n_out || (!needle && needle_len) || (!haystack && haystack_len)) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (needle_len > haystack_len) return TA_OK;                                // src/hamming.rs:455-457
+    if (needle_len == 0) return TA_OK;                                          // :459-461
+    std::vector<ta_match> hits;
+    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt) {
+        return ta_hamming_search_dev(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, 0);
+    });
+    if (rc) return rc;
+    if (search_type == TA_SEARCH_BEST) hits.resize(ta_search_fold_best(hits.data(), hits.size(), k, 0));
+    return give(hits, out, n_out);
+}
+
+int ta_hamming_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                      ta_match **out, size_t *n_out) {                         // src/hamming.rs:422-424
+    uint32_t k = ((uint32_t)needle_len >> 1) + ((uint32_t)needle_len & 1u);
+    return ta_hamming_search_simd_with_opts(needle, needle_len, haystack, haystack_len, k, TA_SEARCH_BEST, out, n_out);
+}
+
+}  // extern "C"
