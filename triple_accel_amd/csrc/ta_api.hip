@@ -44,7 +44,7 @@ int Scratch::ensure(size_t bytes) {
 }
 Scratch::~Scratch() { /* device memory is reclaimed at process exit; hipFree during TLS teardown is unsafe */ }
 Scratch &tls_scratch(int which) {
-    static thread_local Scratch s[6];
+    static thread_local Scratch s[8];
     return s[which];
 }
 
@@ -109,7 +109,8 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
             set_last_error_msg("band wider than the wide-band kernel supports (strings longer than 32767 bytes with an unbounded k)");
             return TA_ERR_ARG;
         }
-        P.L = 0; P.PW = 1; P.lds_per_wave = 0;
+        P.L = 0; P.PW = 1;
+        P.lds_per_wave = (uint32_t)((max_len + 2 > 0xFFFFFFF0ull) ? 0xFFFFFFF0ull : max_len + 2);   // boundary line length
         uint32_t grid = 0, lds = 0, threads = 0, dpt = 0;
         TA_HIP(lev_wide_launch(P, trans, st, &grid, &lds, &threads, &dpt));
         li.kernel = 2; li.diags_per_lane = dpt; li.lanes_per_pair = threads; li.pairs_per_wave = 0;
