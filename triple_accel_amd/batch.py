@@ -80,3 +80,53 @@ def hamming_batch(a: Strings, b: Strings, out=None):
     ca, cb = a._c(), b._c()
     _raise(_n.lib().ta_hamming_batch(_C.byref(ca), _C.byref(cb), a.n, out.data_ptr(), _stream()))
     return out
+
+
+# ---------------------------------------------------------------- search on a haystack shard resident in HBM
+def _hits_to_numpy(hits_t, count):
+    import numpy as np
+    arr = hits_t[: count * 3].cpu().numpy().reshape(-1, 3)          # (start, end, k|pad) as int64 triples
+    out = np.empty((count, 3), dtype=np.int64)
+    out[:, 0] = arr[:, 0]
+    out[:, 1] = arr[:, 1]
+    out[:, 2] = arr[:, 2] & 0xFFFFFFFF
+    order = np.lexsort((out[:, 0], out[:, 1]))                  # by end (unique per hit), then start
+    return out[order]
+
+
+def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchored=False, base=0, emit_from=0, cap=None):
+    """All-mode hits of levenshtein_search_simd_with_opts over a uint8 CUDA tensor (with >= 16 B of read slack
+    after `length`): int64 array of rows (start, end, k) sorted by end.  `base` offsets the positions,
+    hits with end <= emit_from are suppressed (left-halo positions of a sharded haystack)."""
+    hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
+    assert hay.dtype == torch.uint8 and hay.is_cuda and hay.is_contiguous()
+    needle = bytes(needle)
+    cap = cap or min(length + 2, 1 << 24)
+    hits = torch.empty(cap * 3, dtype=torch.int64, device=hay.device)
+    count = _C.c_uint64()
+    cc = _costs(costs)._c()
+    rc = _n.lib().ta_levenshtein_search_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), int(anchored),
+                                            base, emit_from, hits.data_ptr(), cap, _C.byref(count), _stream())
+    _raise(rc)
+    return _hits_to_numpy(hits, int(count.value))
+
+
+def hamming_search_dev(needle, haystack, k, base=0, cap=None):
+    hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
+    needle = bytes(needle)
+    cap = cap or min(length + 2, 1 << 24)
+    hits = torch.empty(cap * 3, dtype=torch.int64, device=hay.device)
+    count = _C.c_uint64()
+    rc = _n.lib().ta_hamming_search_dev(needle, len(needle), hay.data_ptr(), length, k, base, hits.data_ptr(), cap,
+                                        _C.byref(count), _stream())
+    _raise(rc)
+    return _hits_to_numpy(hits, int(count.value))
+
+
+def haystack_tensor(data, device="cuda"):
+    """bytes / uint8 array -> (CUDA tensor with read slack, length)."""
+    import numpy as np
+    arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.asarray(data, dtype=np.uint8)
+    t = torch.zeros(arr.size + SLACK, dtype=torch.uint8, device=device)
+    t[: arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    return t, arr.size
