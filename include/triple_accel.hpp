@@ -1,0 +1,95 @@
+// triple_accel.hpp -- header-only C++ mirror of triple_accel's public Rust API (src/lib.rs:121-127 and the
+// `levenshtein` / `hamming` modules) over the C ABI of triple_accel_amd.h.  Same names, argument order and
+// meaning; Option<T> -> std::optional<T>, panic!/assert! -> triple_accel::panic_error, the boxed Match
+// iterator -> std::vector<Match>.  (The Rust shim itself is in INTEGRATION.md; Rust is not in this image.)
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "triple_accel_amd.h"
+
+namespace triple_accel {
+
+struct panic_error : std::runtime_error { using std::runtime_error::runtime_error; };   // where Rust panics
+struct device_error : std::runtime_error { using std::runtime_error::runtime_error; };  // HIP failure / no GPU (no CPU fallback)
+struct unsupported_error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct Match { std::size_t start, end; std::uint32_t k; bool operator==(const Match &o) const { return start == o.start && end == o.end && k == o.k; } };   // src/lib.rs:135-142
+enum class SearchType { All = 0, Best = 1 };                                            // src/lib.rs:171-174
+using bytes = std::basic_string_view<std::uint8_t>;
+
+inline void check_(int rc) {
+    switch (rc) {
+        case TA_OK: return;
+        case TA_ERR_LEN_MISMATCH: throw panic_error("assertion failed: a.len() == b.len()");
+        case TA_ERR_NULL_BYTE: throw panic_error("No zero/null bytes allowed in the string!");
+        case TA_ERR_BAD_COSTS: throw panic_error("invalid EditCosts");
+        case TA_ERR_UNSUPPORTED: throw unsupported_error(ta_status_str(rc));
+        default: throw device_error(std::string(ta_status_str(rc)) + ": " + ta_last_error());
+    }
+}
+
+// src/levenshtein.rs:20-71
+class EditCosts {
+public:
+    EditCosts(std::uint8_t mismatch_cost, std::uint8_t gap_cost, std::uint8_t start_gap_cost, std::optional<std::uint8_t> transpose_cost) {
+        check_(ta_edit_costs_new(mismatch_cost, gap_cost, start_gap_cost, transpose_cost.has_value(), transpose_cost.value_or(0), &c_));
+    }
+    const ta_edit_costs *raw() const { return &c_; }
+private:
+    ta_edit_costs c_;
+};
+inline const EditCosts LEVENSHTEIN_COSTS{1, 1, 0, std::nullopt};   // :76-81
+inline const EditCosts RDAMERAU_COSTS{1, 1, 0, std::uint8_t{1}};   // :84-89
+
+inline std::optional<std::uint32_t> opt_(std::uint32_t v) { return v == TA_NONE ? std::nullopt : std::optional<std::uint32_t>(v); }
+
+inline std::uint32_t hamming(bytes a, bytes b) {                                          // src/hamming.rs:390
+    std::uint32_t o; check_(ta_hamming(a.data(), a.size(), b.data(), b.size(), &o)); return o;
+}
+inline std::optional<std::uint32_t> levenshtein_simd_k(bytes a, bytes b, std::uint32_t k) {   // src/levenshtein.rs:677
+    std::uint32_t o; check_(ta_levenshtein_simd_k(a.data(), a.size(), b.data(), b.size(), k, &o)); return opt_(o);
+}
+// :714 -- (distance, traceback); trace_on = true is not on the GPU path yet (unsupported_error)
+inline std::optional<std::pair<std::uint32_t, std::nullopt_t>> levenshtein_simd_k_with_opts(bytes a, bytes b, std::uint32_t k, bool trace_on, const EditCosts &costs) {
+    std::uint32_t o; check_(ta_levenshtein_simd_k_with_opts(a.data(), a.size(), b.data(), b.size(), k, trace_on, costs.raw(), &o));
+    if (o == TA_NONE) return std::nullopt;
+    return std::make_pair(o, std::nullopt);
+}
+inline std::uint32_t levenshtein(bytes a, bytes b) { std::uint32_t o; check_(ta_levenshtein(a.data(), a.size(), b.data(), b.size(), &o)); return o; }          // :1397
+inline std::uint32_t rdamerau(bytes a, bytes b) { std::uint32_t o; check_(ta_rdamerau(a.data(), a.size(), b.data(), b.size(), &o)); return o; }                // :1419
+inline std::uint32_t levenshtein_exp(bytes a, bytes b) { std::uint32_t o; check_(ta_levenshtein_exp(a.data(), a.size(), b.data(), b.size(), &o)); return o; }  // :1445
+inline std::uint32_t rdamerau_exp(bytes a, bytes b) { std::uint32_t o; check_(ta_rdamerau_exp(a.data(), a.size(), b.data(), b.size(), &o)); return o; }        // :1516
+
+inline std::vector<Match> take_(ta_match *m, std::size_t n) {
+    std::vector<Match> v; v.reserve(n);
+    for (std::size_t i = 0; i < n; i++) v.push_back(Match{(std::size_t)m[i].start, (std::size_t)m[i].end, m[i].k});
+    ta_free(m);
+    return v;
+}
+inline std::vector<Match> levenshtein_search_simd_with_opts(bytes needle, bytes haystack, std::uint32_t k, SearchType st, const EditCosts &costs, bool anchored) {   // :1911
+    ta_match *m; std::size_t n;
+    check_(ta_levenshtein_search_simd_with_opts(needle.data(), needle.size(), haystack.data(), haystack.size(), k, (int)st, costs.raw(), anchored, &m, &n));
+    return take_(m, n);
+}
+inline std::vector<Match> levenshtein_search(bytes needle, bytes haystack) {             // :2508
+    ta_match *m; std::size_t n;
+    check_(ta_levenshtein_search(needle.data(), needle.size(), haystack.data(), haystack.size(), &m, &n));
+    return take_(m, n);
+}
+inline std::vector<Match> hamming_search_simd_with_opts(bytes needle, bytes haystack, std::uint32_t k, SearchType st) {   // src/hamming.rs:454
+    ta_match *m; std::size_t n;
+    check_(ta_hamming_search_simd_with_opts(needle.data(), needle.size(), haystack.data(), haystack.size(), k, (int)st, &m, &n));
+    return take_(m, n);
+}
+inline std::vector<Match> hamming_search(bytes needle, bytes haystack) {                 // src/hamming.rs:588
+    ta_match *m; std::size_t n;
+    check_(ta_hamming_search(needle.data(), needle.size(), haystack.data(), haystack.size(), &m, &n));
+    return take_(m, n);
+}
+
+}  // namespace triple_accel
