@@ -55,6 +55,7 @@ struct EmuWave {
         for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> (8 * N));
         return r;
     }
+    static U32 opaque(const U32 &x) { return x; }
     static U32 dot4_byte(const U32 &x, int n, uint32_t m, const U32 &acc) {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + ((x.v[i] >> (8 * n)) & 0xffu) * (m & 0xffu); return r;
     }
@@ -62,6 +63,8 @@ struct EmuWave {
     static U32 bfi(uint32_t mask, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask); return r; }
     static U32 from_lower(const U32 &x, const U32 &fill) { V32 r; r.v[0] = fill.v[0]; for (int i = 1; i < 64; i++) r.v[i] = x.v[i - 1]; return r; }
     static U32 from_upper(const U32 &x, const U32 &fill) { V32 r; r.v[63] = fill.v[63]; for (int i = 0; i < 63; i++) r.v[i] = x.v[i + 1]; return r; }
+    static U32 from_lower0(const U32 &x) { return from_lower(x, V32(0xDEADBEEFu)); }   // edge value must not matter
+    static U32 from_upper0(const U32 &x) { return from_upper(x, V32(0xDEADBEEFu)); }
     static U32 shfl(const U32 &x, const U32 &src) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[src.v[i] & 63]; return r; }
     static Ptr shfl_ptr(const Ptr &p, const U32 &src) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[src.v[i] & 63]; return r; }
     static bool any(const Bool &c) { for (int i = 0; i < 64; i++) if (c.v[i]) return true; return false; }

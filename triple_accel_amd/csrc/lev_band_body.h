@@ -79,12 +79,15 @@ struct LevBand {
                 Z[w] = (st.AW[w] ^ b_up) | (a_dn ^ st.BW[w]);
             }
         }
+        // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
+        // cells, or as their own diagonal predecessor), odd-q cells raw with HA = dp + 2gc for their even
+        // neighbours -- one add per TWO cells instead of one per cell.
         U32 xl = INF, xr = INF;
         if (PAR == 0) {
-            xl = W::from_lower(st.HA[D - 1], INF);
+            xl = W::from_lower0(st.HA[D - 1]);
             xl = W::sel(is_g0, INF, xl);            // band edge: nothing left of the pair's first diagonal
         } else {
-            xr = W::from_upper(AFFINE ? st.HB[0] : st.HA[0], INF);
+            xr = W::from_upper0(AFFINE ? st.HB[0] : st.reg[0]);
             xr = W::sel(is_gl, INF, xr);
         }
         // per byte: 1 where a != b, four cells per VGPR (SWAR); each cell's substitution cost is then ONE
@@ -92,15 +95,16 @@ struct LevBand {
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             U32 t = (X[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;      // bit 7 of each byte <- low 7 bits nonzero
-            X[w] = ((t | X[w]) >> 7) & 0x01010101u;           // 1 per nonzero byte
+            X[w] = W::opaque((t | X[w]) & 0x80808080u) >> 7;  // 1 per nonzero byte (opaque: keep the and fused with the or)
         }
 #pragma unroll
         for (int c = 0; c < Dh; c++) {
             const int q = 2 * c + PAR;
             const int byte = c + 1, w = byte >> 2;
             U32 sub = W::dot4_byte(X[w], byte & 3, P.mc, st.reg[q]);              // :471-475
-            U32 lft = (PAR == 0 && c == 0) ? xl : st.HA[q > 0 ? q - 1 : 0];                   // a_gap  :476-483
-            U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[q + 1 < D ? q + 1 : D - 1] : st.HA[q + 1 < D ? q + 1 : D - 1]);   // b_gap :484-491
+            const int ql = q > 0 ? q - 1 : 0, qr = q + 1 < D ? q + 1 : D - 1;
+            U32 lft = (PAR == 0 && c == 0) ? xl : ((AFFINE || PAR == 0) ? st.HA[ql] : st.reg[ql]);          // a_gap  :476-483
+            U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : (PAR == 0 ? st.HA[qr] : st.reg[qr]));   // b_gap :484-491
             U32 nv = W::umin3(sub, lft, rgt);                                     // :493-515
             if (TRANS) {
                 U32 t = st.PV[q] + P.tc;                                          // :523-525 (<= : min)
@@ -113,8 +117,8 @@ struct LevBand {
                 U32 go = nv + (P.sg + P.gc);                                      // open a gap from this cell
                 st.HA[q] = W::umin(go, lft + P.gc);                               // or extend the one that reached it
                 st.HB[q] = W::umin(go, rgt + P.gc);
-            } else {
-                st.HA[q] = nv + P.gc;
+            } else if (PAR == 1) {
+                st.HA[q] = nv + 2u * P.gc;
             }
         }
     }
@@ -123,7 +127,7 @@ struct LevBand {
     static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in, Bool is_g0) {
         constexpr int sb = Dh;   // byte Dh = cell Dh-1 = the char the next lane needs
         U32 t = st.AW[sb >> 2] >> (8 * (sb & 3));
-        t = W::from_lower(t, W::splat(0));
+        t = W::from_lower0(t);
         t = W::sel(is_g0, a_in, t);
         st.AW[0] = W::bfi(0xffu, t, st.AW[0]);
 #pragma unroll
@@ -133,7 +137,7 @@ struct LevBand {
     // b-window: every char moves one cell down (new column enters at cell Dh-1) -- :1033-1037
     static TA_HD inline __attribute__((always_inline)) void advance_b(State &st, U32 b_in, Bool is_gl) {
         U32 t = st.BW[0] >> 8;   // byte 1 = cell 0
-        t = W::from_upper(t, W::splat(0));
+        t = W::from_upper0(t);
         t = W::sel(is_gl, b_in, t);
         constexpr int ib = Dh + 1, iw = ib >> 2, ish = 8 * (ib & 3);
         st.BW[iw] = W::bfi(0xffu << ish, t << ish, st.BW[iw]);
@@ -142,25 +146,23 @@ struct LevBand {
         st.BW[NW - 1] = st.BW[NW - 1] >> 8;
     }
 
-    // Stream chunk kc (iterations [kc*CH, kc*CH+CH)) of every pair's two strings into the LDS ring.
-    static TA_HD inline void load_chunk(uint8_t *lds, const LevParams &P, uint32_t kc, U32 lane,
+    // Stream chunk kc (iterations [kc*CH, kc*CH+CH)) of every pair's two strings into the LDS ring.  The 8 pieces
+    // (2 strings x 4 x 16 B) of a pair are fetched by the pair's own L lanes, so no pointer ever crosses lanes.
+    static TA_HD inline void load_chunk(uint8_t *lds, const LevParams &P, uint32_t kc, U32 grp, U32 g, Bool active,
                                   Ptr aptr, U32 alen, Ptr bptr, U32 blen, uint32_t ea, uint32_t eb) {
-        const uint32_t npieces = 2u * P.PW * (LEV_CH / 16);
-        for (uint32_t base = 0; base < npieces; base += 64) {
-            U32 l = lane + base;
-            Bool pred = l < npieces;
-            U32 slot = l >> 2;                 // LEV_CH/16 == 4 pieces per slot
-            U32 piece = l & 3u;
-            U32 src = (slot >> 1) * P.L;       // first lane of the owning pair
-            Bool isb = (slot & 1u) != 0u;
-            Ptr pa = W::shfl_ptr(aptr, src), pb = W::shfl_ptr(bptr, src);
-            U32 la = W::shfl(alen, src), lb = W::shfl(blen, src);
-            U32 len = W::sel(isb, lb, la);
+        constexpr uint32_t PIECES = 2u * (LEV_CH / 16);
+        for (uint32_t base = 0; base < PIECES; base += P.L) {
+            U32 pc = g + base;                   // piece index within the pair: [0,4) = a, [4,8) = b
+            Bool pred = active & (pc < PIECES);
+            Bool isb = pc >= (uint32_t)(LEV_CH / 16);
+            U32 piece = pc & 3u;
+            U32 len = W::sel(isb, blen, alen);
             U32 e = W::sel(isb, W::splat(eb), W::splat(ea));
-            U32 y0 = piece * 16u + kc * LEV_CH;          // ring position (absolute)
+            U32 y0 = piece * 16u + kc * LEV_CH;  // ring position (absolute)
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
-            auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, pb, pa), idx0), ok);
+            auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, bptr, aptr), idx0), ok);
+            U32 slot = grp * 2u + W::sel(isb, W::splat(1), W::splat(0));
             W::lds_store16(lds, slot * LEV_SLOT + (y0 & (LEV_RING - 1)), q, pred);
         }
     }
@@ -215,7 +217,7 @@ struct LevBand {
             for (int q = 1; q < D; q += 2) {
                 Bool hit = seed_lane & (W::splat(qs) == (uint32_t)q);
                 st.reg[q] = W::sel(hit, W::splat(0), st.reg[q]);
-                st.HA[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HA[q]);
+                st.HA[q] = W::sel(hit, W::splat(AFFINE ? P.sg + P.gc : 2u * P.gc), st.HA[q]);
                 if (AFFINE) st.HB[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HB[q]);
             }
         }
@@ -223,13 +225,13 @@ struct LevBand {
 
         const U32 a_slot = (grp * 2u) * LEV_SLOT, b_slot = (grp * 2u + 1u) * LEV_SLOT;
 
-        load_chunk(lds, P, 0, lane, aptr, alen, bptr, blen, ea, eb);
-        load_chunk(lds, P, 1, lane, aptr, alen, bptr, blen, ea, eb);
+        load_chunk(lds, P, 0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        load_chunk(lds, P, 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         W::lds_wave_sync();
 
         for (uint32_t kc = 0; kc * LEV_CH < iters; kc++) {
             if (kc >= 1) {
-                load_chunk(lds, P, kc + 1, lane, aptr, alen, bptr, blen, ea, eb);
+                load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
                 W::lds_wave_sync();
             }
             const uint32_t t_lo = kc * LEV_CH;
@@ -255,6 +257,7 @@ struct LevBand {
                     U32 r = INF;
 #pragma unroll
                     for (int q = 0; q < D; q++) r = W::sel(q_ans == (uint32_t)q, st.reg[q], r);
+                    if (!AFFINE) r = r - W::sel((q_ans & 1u) == 0u, W::splat(P.gc), W::splat(0));   // un-bias an even-q cell
                     ans = W::sel(cap, r, ans);
                 }
             }

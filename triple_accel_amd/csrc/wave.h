@@ -44,6 +44,8 @@ struct DevWave {
     template <int N> static __device__ __forceinline__ U32 alignbyte(U32 hi, U32 lo) {
         return __builtin_amdgcn_alignbyte(hi, lo, N);
     }
+    // value barrier: stops instcombine from re-associating across it
+    static __device__ __forceinline__ U32 opaque(U32 x) { asm volatile("" : "+v"(x)); return x; }
     // acc + byte n of x * m  (m <= 255)  -> v_dot4_u32_u8 with a one-hot multiplier
     static __device__ __forceinline__ U32 dot4_byte(U32 x, int n, uint32_t m, U32 acc) {
         return __builtin_amdgcn_udot4(x, m << (8 * n), acc, false);
@@ -61,6 +63,9 @@ struct DevWave {
     static __device__ __forceinline__ U32 from_upper(U32 x, U32 fill) {
         return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130, 0xf, 0xf, false);
     }
+    // same moves when the edge lane's value is overridden by the caller anyway: no tied `old` operand
+    static __device__ __forceinline__ U32 from_lower0(U32 x) { return (U32)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xf, 0xf, true); }
+    static __device__ __forceinline__ U32 from_upper0(U32 x) { return (U32)__builtin_amdgcn_mov_dpp((int)x, 0x130, 0xf, 0xf, true); }
     static __device__ __forceinline__ U32 shfl(U32 x, U32 src_lane) {
         return (U32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)x);
     }
