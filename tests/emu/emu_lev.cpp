@@ -9,13 +9,18 @@
 
 using namespace ta;
 
-template <int D> static void run_d(const LevParams &P, bool affine, bool trans, uint32_t waves) {
+template <int D> static void run_d(const LevParams &P, bool affine, int trans, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     for (uint32_t w = 0; w < waves; w++) {
-        if (affine && trans) LevBand<EmuWave, D, true, true>::run(P, w, lds);
-        else if (affine) LevBand<EmuWave, D, true, false>::run(P, w, lds);
-        else if (trans) LevBand<EmuWave, D, false, true>::run(P, w, lds);
-        else LevBand<EmuWave, D, false, false>::run(P, w, lds);
+        if (affine) {
+            if (trans == 1) LevBand<EmuWave, D, true, 1>::run(P, w, lds);
+            else if (trans == 2) LevBand<EmuWave, D, true, 2>::run(P, w, lds);
+            else LevBand<EmuWave, D, true, 0>::run(P, w, lds);
+        } else {
+            if (trans == 1) LevBand<EmuWave, D, false, 1>::run(P, w, lds);
+            else if (trans == 2) LevBand<EmuWave, D, false, 2>::run(P, w, lds);
+            else LevBand<EmuWave, D, false, 0>::run(P, w, lds);
+        }
     }
     free(lds);
 }
@@ -34,7 +39,8 @@ extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const 
     P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave;
     if (plan_out) { plan_out[0] = pl.D; plan_out[1] = pl.L; plan_out[2] = pl.PW; plan_out[3] = pl.u; plan_out[4] = pl.o; }
     uint32_t waves = (n + pl.PW - 1) / pl.PW;
-    bool affine = sg > 0 || force_affine, trans = has_t != 0;
+    bool affine = sg > 0 || force_affine;
+    int trans = !has_t ? 0 : ((2u * mc <= 255u + tc && !(force_affine & 2)) ? 1 : 2);   // force_affine bit 1: force the select form
     switch (pl.D) {
 #define CASE(d) case d: run_d<d>(P, affine, trans, waves); break;
         CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(28)

@@ -37,7 +37,7 @@ def pack(strings):
     return blob, off
 
 
-def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False):
+def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False):
     """-> (list of dist|None, plan dict)"""
     n = len(a_list)
     ab, ao = pack(a_list)
@@ -48,7 +48,7 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
     mc, gc, sg, tc = costs
     rc = lib().emu_lev_band(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, mc, gc, sg,
                             0 if tc is None else 1, 0 if tc is None else tc, max_len, force_D, force_L,
-                            int(force_affine), out.ctypes.data, plan.ctypes.data)
+                            int(force_affine) | (2 if force_trans_select else 0), out.ctypes.data, plan.ctypes.data)
     if rc:
         raise RuntimeError("emu_lev_band rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]

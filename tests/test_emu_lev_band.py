@@ -111,3 +111,15 @@ def test_emu_affine_kernel_on_linear_costs():
         g1, _ = E.lev_band(a, b, 9, costs)
         g2, _ = E.lev_band(a, b, 9, costs, force_affine=True)
         assert g1 == g2 == oracle(a, b, 9, costs)
+
+
+def test_emu_transposition_forms_agree():
+    """The dot4-penalty form and the select form of the transposition must agree; big mismatch costs
+    (2*mc > 255 + tc) take the select form by themselves."""
+    a, b = make_pairs(9, 120, 50, 8, True)
+    for costs in [(1, 1, 0, 1), (2, 2, 1, 3), (100, 90, 3, 150), (200, 130, 0, 255), (255, 255, 255, 255)]:
+        assert O.costs_valid(costs)
+        for k in (3, 40, 700):
+            want = oracle(a, b, k, costs)
+            assert E.lev_band(a, b, k, costs)[0] == want, (costs, k)
+            assert E.lev_band(a, b, k, costs, force_trans_select=True)[0] == want, (costs, k)

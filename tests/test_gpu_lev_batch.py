@@ -170,3 +170,15 @@ def test_hamming_batch():
     assert out[0] == 0xFFFFFFFF
     with pytest.raises(T.PanicError):
         T.hamming(b"ab", b"abc")
+
+
+def test_transposition_forms(monkeypatch):
+    """dot4-penalty form vs select form of the transposition (big mismatch costs take the select form)."""
+    a, b = ragged_pairs(9, 4000, 60, 8, True)
+    for costs in [(1, 1, 0, 1), (2, 2, 1, 3), (100, 90, 3, 150), (200, 130, 0, 255), (255, 255, 255, 255)]:
+        for k in (3, 40, 700):
+            want = oracle_k(a, b, k, costs)
+            monkeypatch.delenv("TA_FORCE_TRANS_SELECT", raising=False)
+            assert np.array_equal(gpu_k(a, b, k, costs), want), (costs, k)
+            monkeypatch.setenv("TA_FORCE_TRANS_SELECT", "1")
+            assert np.array_equal(gpu_k(a, b, k, costs), want), (costs, k)

@@ -8,7 +8,7 @@ namespace ta {
 
 constexpr int LEV_WAVES_PER_BLOCK = 4;
 
-template <int D, bool AFFINE, bool TRANS>
+template <int D, bool AFFINE, int TRANS>
 __global__ __launch_bounds__(64 * LEV_WAVES_PER_BLOCK) void lev_band_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
@@ -16,17 +16,17 @@ __global__ __launch_bounds__(64 * LEV_WAVES_PER_BLOCK) void lev_band_kernel(LevP
 }
 
 template <int D>
-static hipError_t launch_d(const LevParams &P, bool affine, bool trans, uint32_t grid, size_t lds, hipStream_t s) {
+static hipError_t launch_d(const LevParams &P, bool affine, int trans, uint32_t grid, size_t lds, hipStream_t s) {
     dim3 g(grid), b(64 * LEV_WAVES_PER_BLOCK);
-    if (affine && trans) hipLaunchKernelGGL((lev_band_kernel<D, true, true>), g, b, lds, s, P);
-    else if (affine) hipLaunchKernelGGL((lev_band_kernel<D, true, false>), g, b, lds, s, P);
-    else if (trans) hipLaunchKernelGGL((lev_band_kernel<D, false, true>), g, b, lds, s, P);
-    else hipLaunchKernelGGL((lev_band_kernel<D, false, false>), g, b, lds, s, P);
+#define TA_L(A, T) hipLaunchKernelGGL((lev_band_kernel<D, A, T>), g, b, lds, s, P)
+    if (affine) { if (trans == 1) TA_L(true, 1); else if (trans == 2) TA_L(true, 2); else TA_L(true, 0); }
+    else { if (trans == 1) TA_L(false, 1); else if (trans == 2) TA_L(false, 2); else TA_L(false, 0); }
+#undef TA_L
     return hipGetLastError();
 }
 
 // Launches the kernel for plan `pl`; returns the grid size through *grid_out.
-hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s,
+hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, int trans, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out) {
     const uint32_t waves = (P.n + pl.PW - 1) / pl.PW;
     const uint32_t grid = (waves + LEV_WAVES_PER_BLOCK - 1) / LEV_WAVES_PER_BLOCK;

@@ -45,7 +45,8 @@ struct LevParams {
     uint32_t lds_per_wave;    // bytes
 };
 
-template <class W, int D, bool AFFINE, bool TRANS>
+// TRANS: 0 = no transposition, 1 = transposition as a dot4 penalty (needs 2*mc <= 255 + tc), 2 = as a select
+template <class W, int D, bool AFFINE, int TRANS>
 struct LevBand {
     static_assert(D % 2 == 0 && D >= 2, "D must be even");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
@@ -77,6 +78,10 @@ struct LevBand {
                 U32 b_up = W::template alignbyte<3>(st.BW[w], w ? st.BW[w - 1] : W::splat(0));          // byte c+1 <- b byte c
                 U32 a_dn = W::template alignbyte<1>(w + 1 < NW ? st.AW[w + 1] : W::splat(0), st.AW[w]); // byte c+1 <- a byte c+2
                 Z[w] = (st.AW[w] ^ b_up) | (a_dn ^ st.BW[w]);
+                if (TRANS == 1) {   // 1 per cell whose transposition test FAILS (non-zero byte)
+                    U32 t = (Z[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+                    Z[w] = W::opaque((t | Z[w]) & 0x80808080u) >> 7;
+                }
             }
         }
         // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
@@ -106,9 +111,15 @@ struct LevBand {
             U32 lft = (PAR == 0 && c == 0) ? xl : ((AFFINE || PAR == 0) ? st.HA[ql] : st.reg[ql]);          // a_gap  :476-483
             U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : (PAR == 0 ? st.HA[qr] : st.reg[qr]));   // b_gap :484-491
             U32 nv = W::umin3(sub, lft, rgt);                                     // :493-515
-            if (TRANS) {
-                U32 t = st.PV[q] + P.tc;                                          // :523-525 (<= : min)
-                st.PV[q] = st.reg[q];
+            if (TRANS == 1) {
+                // PV holds dp(i-2,j-2) + tc.  A failed test adds 255, which lifts the candidate above nv:
+                // nv <= dp(i-1,j-1) + mc <= dp(i-2,j-2) + 2 mc <= dp(i-2,j-2) + tc + 255 (host guarantees the last step).
+                U32 tq = W::dot4_byte(Z[w], byte & 3, 255u, st.PV[q]);                // :523-525 (<= : min)
+                st.PV[q] = st.reg[q] + P.tc;
+                nv = W::umin(nv, tq);
+            } else if (TRANS == 2) {
+                U32 t = st.PV[q];
+                st.PV[q] = st.reg[q] + P.tc;
                 Bool tz = W::byte_of(Z[w], byte & 3) == 0u;
                 nv = W::sel(tz, W::umin(nv, t), nv);
             }

@@ -101,7 +101,8 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     if (pl.ok && !env_int("TA_FORCE_WIDE")) {
         P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave;
         uint32_t grid = 0, lds = 0;
-        TA_HIP(lev_band_launch(P, pl, affine, trans, st, &grid, &lds));
+        const int tmode = !trans ? 0 : ((2u * P.mc <= 255u + P.tc && !env_int("TA_FORCE_TRANS_SELECT")) ? 1 : 2);
+        TA_HIP(lev_band_launch(P, pl, affine, tmode, st, &grid, &lds));
         li.kernel = 1; li.diags_per_lane = pl.D; li.lanes_per_pair = pl.L; li.pairs_per_wave = pl.PW;
         li.grid = grid; li.lds_bytes = lds;
     } else {

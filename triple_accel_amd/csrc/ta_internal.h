@@ -35,7 +35,8 @@ Scratch &tls_scratch(int which);
 bool device_ready();
 
 // kernels (defined in the .hip files)
-hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s,
+// trans: 0 none, 1 dot4-penalty form (2*mc <= 255 + tc), 2 select form
+hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, int trans, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
                            uint32_t *threads_out, uint32_t *dpt_out);
