@@ -43,6 +43,7 @@ struct LevParams {
     uint32_t L;               // lanes per pair
     uint32_t PW;              // pairs per wave = 64 / L
     uint32_t lds_per_wave;    // bytes
+    uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
 };
 
 // TRANS: 0 = no transposition, 1 = transposition as a dot4 penalty (needs 2*mc <= 255 + tc), 2 = as a select
@@ -203,10 +204,10 @@ struct LevBand {
         const U32 g_ans = W::udiv(p_ans, (uint32_t)D);
         const U32 q_ans = p_ans - g_ans * (uint32_t)D;
 
-        const uint32_t Tw = L * Dh;                            // warm-up iterations: windows fill up
+        const uint32_t Tw = P.Tw;                              // warm-up iterations: windows fill up (>= L*Dh)
         const uint32_t h = (P.o + 1) >> 1;
         // iteration t' = tau + Tw feeds a[t' - ca] into lane 0 and b[t' - cb] into lane L-1
-        const uint32_t ca = Tw - h, cb = h;
+        const uint32_t ca = Tw - h, cb = Tw - L * Dh + h;
         const uint32_t da = (16u - (ca & 15u)) & 15u, db = (16u - (cb & 15u)) & 15u;
         const uint32_t ea = ca + da, eb = cb + db;             // multiples of 16: pieces never straddle index 0
         const uint32_t iters = Tw + W::wave_max((s_ans + 1u) >> 1);
@@ -236,18 +237,20 @@ struct LevBand {
 
         const U32 a_slot = (grp * 2u) * LEV_SLOT, b_slot = (grp * 2u + 1u) * LEV_SLOT;
 
-        load_chunk(lds, P, 0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
-        load_chunk(lds, P, 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        // iterations before min(ca, cb) would only shift zeros into zero windows: start there
+        const uint32_t tp0 = ca < cb ? ca : cb, kc0 = tp0 / LEV_CH;
+        load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         W::lds_wave_sync();
 
-        for (uint32_t kc = 0; kc * LEV_CH < iters; kc++) {
-            if (kc >= 1) {
+        for (uint32_t kc = kc0; kc * LEV_CH < iters; kc++) {
+            if (kc > kc0) {
                 load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
                 W::lds_wave_sync();
             }
             const uint32_t t_lo = kc * LEV_CH;
             const uint32_t t_hi = (t_lo + LEV_CH < iters) ? t_lo + LEV_CH : iters;
-            uint32_t tp = t_lo;
+            uint32_t tp = t_lo > tp0 ? t_lo : tp0;
             // warm-up part: only the char windows move
             for (; tp < t_hi && tp < Tw; tp++) {
                 U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));

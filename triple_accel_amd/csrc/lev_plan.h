@@ -14,6 +14,7 @@ struct LevPlan {
     int D;                   // diagonals per lane
     uint32_t L, PW;          // lanes per pair, pairs per wave
     uint32_t lds_per_wave;
+    uint32_t Tw;             // warm-up iterations
     bool ok;                 // false: band too wide for one wavefront (needs the wide-band kernel)
 };
 
@@ -43,7 +44,18 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t gc, uint32_t sg, uint64
         double cost = (5.0 * D + 24.0) / PW * (D > 40 ? 1.25 : 1.0);
         if (cost < best) { best = cost; p.D = D; p.L = L; p.PW = PW; p.ok = true; }
     }
-    if (p.ok) p.lds_per_wave = (2u * p.PW * 132u + 15u) & ~15u;   // LEV_SLOT bytes per (pair, string)
+    if (p.ok) {
+        p.lds_per_wave = (2u * p.PW * 132u + 15u) & ~15u;   // LEV_SLOT bytes per (pair, string)
+        // The ring chunk of iteration block kc holds a[64 kc - ea ..) and b[64 kc - eb ..), ea = (Tw - h) rounded up to
+        // 16, eb likewise.  Pad the warm-up so that both are multiples of 64: every 64-byte chunk then maps onto ONE
+        // 64-byte line of a line-aligned string instead of straddling two (which costs a second HBM fetch when the line
+        // has left L2 by the next refill).
+        const uint32_t base = p.L * (uint32_t)(p.D / 2), h = (p.o + 1) >> 1;
+        auto lined = [](uint32_t c) { uint32_t r = c & 63u; return r == 0 || r >= 49; };   // 16-byte round-up reaches a multiple of 64
+        p.Tw = base;
+        for (uint32_t w = 0; w < 64; w++)
+            if (lined(base + w - h) && lined(w + h)) { p.Tw = base + w; break; }
+    }
     return p;
 }
 

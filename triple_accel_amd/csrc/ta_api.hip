@@ -99,7 +99,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
     li.cell_bits = sel.cell_bits;
     if (pl.ok && !env_int("TA_FORCE_WIDE")) {
-        P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave;
+        P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw;
         uint32_t grid = 0, lds = 0;
         const int tmode = !trans ? 0 : ((2u * P.mc <= 255u + P.tc && !env_int("TA_FORCE_TRANS_SELECT")) ? 1 : 2);
         TA_HIP(lev_band_launch(P, pl, affine, tmode, st, &grid, &lds));
@@ -110,7 +110,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
             set_last_error_msg("band wider than the wide-band kernel supports (strings longer than 32767 bytes with an unbounded k)");
             return TA_ERR_ARG;
         }
-        P.L = 0; P.PW = 1;
+        P.L = 0; P.PW = 1; P.Tw = 0;
         P.lds_per_wave = (uint32_t)((max_len + 2 > 0xFFFFFFF0ull) ? 0xFFFFFFF0ull : max_len + 2);   // boundary line length
         uint32_t grid = 0, lds = 0, threads = 0, dpt = 0;
         TA_HIP(lev_wide_launch(P, trans, st, &grid, &lds, &threads, &dpt));

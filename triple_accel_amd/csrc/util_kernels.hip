@@ -22,37 +22,44 @@ __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {
     return __builtin_popcount(t);
 }
 
-// hamming(a, b) for a batch: one wavefront per pair, 16 B per lane per trip, coalesced.
+// hamming(a, b) for a batch: G = 2^g lanes per pair (G*16 >= the longest string, at most one wavefront),
+// 64/G pairs per wavefront, 16 B per lane per trip, coalesced.
 // Replaces hamming_simd_parallel / Avx::count_mismatches (src/hamming.rs:317, src/jewel.rs:2320-2365);
 // result contract hamming_naive (src/hamming.rs:36-47): mismatching positions, None on length mismatch.
-__global__ __launch_bounds__(256) void hamming_batch_kernel(StrView a, StrView b, uint32_t n, uint32_t *out) {
+__global__ __launch_bounds__(256) void hamming_batch_kernel(StrView a, StrView b, uint32_t n, uint32_t *out, uint32_t G) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t pair = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (pair >= n) return;
-    const uint8_t *pa, *pb;
-    uint64_t la, lb;
-    dev_str(a, pair, pa, la);
-    dev_str(b, pair, pb, lb);
-    if (la != lb) {                                   // assert!(len == b.len())  src/hamming.rs:38
-        if (lane == 0) out[pair] = 0xFFFFFFFFu;
-        return;
-    }
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t ppw = 64u / G;
+    const uint32_t pair = wave * ppw + lane / G;
+    const uint32_t g = lane & (G - 1);
+    const bool valid = pair < n;
+    const uint8_t *pa = a.blob, *pb = b.blob;
+    uint64_t la = 0, lb = 0;
+    if (valid) { dev_str(a, pair, pa, la); dev_str(b, pair, pb, lb); }
+    const bool same = (la == lb);
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
     uint32_t cnt = 0;
-    const uint64_t full = la & ~(uint64_t)15;
-    for (uint64_t i = (uint64_t)lane * 16; i < full; i += 64 * 16) {
-        u32x4u x = *(const u32x4u *)(pa + i);
-        u32x4u y = *(const u32x4u *)(pb + i);
-        cnt += nz_bytes(x.x ^ y.x) + nz_bytes(x.y ^ y.y) + nz_bytes(x.z ^ y.z) + nz_bytes(x.w ^ y.w);
+    if (valid && same) {
+        const uint64_t full = la & ~(uint64_t)15;
+        for (uint64_t i = (uint64_t)g * 16; i < full; i += (uint64_t)G * 16) {
+            u32x4u x = *(const u32x4u *)(pa + i);
+            u32x4u y = *(const u32x4u *)(pb + i);
+            cnt += nz_bytes(x.x ^ y.x) + nz_bytes(x.y ^ y.y) + nz_bytes(x.z ^ y.z) + nz_bytes(x.w ^ y.w);
+        }
+        for (uint64_t i = full + g; i < la; i += G) cnt += (pa[i] != pb[i]);
     }
-    for (uint64_t i = full + lane; i < la; i += 64) cnt += (pa[i] != pb[i]);
-    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
-    if (lane == 0) out[pair] = cnt;
+    for (uint32_t m = G >> 1; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+    if (valid && g == 0) out[pair] = same ? cnt : 0xFFFFFFFFu;                    // assert!(len == b.len())  src/hamming.rs:38
 }
 
 hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(hamming_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a, b, n, out);
+    // strided batches know their length; CSR batches use a full wavefront per pair
+    uint64_t len = a.off ? 1024 : a.len;
+    uint32_t G = 1;
+    while (G < 64 && (uint64_t)G * 16 < len) G <<= 1;
+    const uint32_t ppw = 64 / G, waves = (n + ppw - 1) / ppw;
+    hipLaunchKernelGGL(hamming_batch_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a, b, n, out, G);
     return hipGetLastError();
 }
 
