@@ -54,3 +54,16 @@ def test_anchored():
             k = int(g.integers(0, 6))
             want = oracle_all(needle, hay, k, costs, anchored=True)
             assert E.lev_search_tiled(needle, hay, k, costs, anchored=True) == want
+
+
+def test_long_needles_memory_backed_column():
+    """Needles beyond the register kernel's 32 rows use the memory-backed column (lev_search_tile_mem)."""
+    g = Dg.rng(77)
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 2, None), (2, 2, 1, 3)]:
+        for n in (33, 40, 97, 260):
+            needle = Dg.rand_str(g, n)
+            k = n // 5
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 4 * n + 900, 3 * n, max(1, k))
+            want = oracle_all(needle, hay, k, costs)
+            for tile in (1 << 30, 257):
+                assert E.lev_search_tiled(needle, hay, k, costs, tile=tile) == want, (n, k, tile, costs)

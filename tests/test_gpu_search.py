@@ -90,3 +90,25 @@ def test_hamming_search():
         list(T.hamming_search(b"ab", b"a\x00b"))
     want = O.hamming_search_simd_with_opts(b"abc", b"  abc  abb", O.default_search_k(3), O.BEST)
     assert [tuple(m) for m in T.hamming_search(b"abc", b"  abc  abb")] == want
+
+
+def test_long_needles_and_long_hamming_needles():
+    """levenshtein_search with needles > 32 B (memory-backed column kernel) and hamming_search with needles > 256 B."""
+    import triple_accel_amd as T
+    g = Dg.rng(177)
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 2, None)]:
+        for n in (33, 64, 150, 400):
+            needle = Dg.rand_str(g, n)
+            k = n // 6
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 30000, 5000, max(1, k))
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (n, st, costs)
+    needle = Dg.rand_str(g, 700)
+    hay = bytearray(Dg.rand_str(g, 20000))
+    hay[5000:5700] = needle
+    hay[9000:9700] = needle[:350] + b"!" + needle[351:]
+    hay = bytes(hay)
+    for k in (0, 1, 5):
+        want = O.hamming_search_simd_with_opts(needle, hay, k, O.ALL)
+        assert [tuple(m) for m in T.hamming_search_simd_with_opts(needle, hay, k, O.ALL)] == want and len(want) >= 1

@@ -27,6 +27,29 @@ __global__ __launch_bounds__(256) void lev_search_kernel(SearchParams P) {
                               });
 }
 
+// long needles: the column lives in HBM scratch, element-major so that a wavefront's accesses coalesce
+__global__ __launch_bounds__(256) void lev_search_mem_kernel(SearchParams P, uint64_t tiles) {
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= tiles) return;
+    const uint64_t emit_begin = tile * P.tile;
+    if (emit_begin >= P.hay_len) return;
+    uint64_t emit_end = emit_begin + P.tile;
+    if (emit_end > P.hay_len) emit_end = P.hay_len;
+    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+    SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, P.anchored};
+    ta_match *hits = P.hits;
+    unsigned long long *count = P.count;
+    const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
+    lev_search_tile_mem(P.hay, P.needle_dev, P.needle_len, C, P.tc != 0, P.col_scratch + tile, tiles,
+                        col_begin, emit_begin, emit_end,
+                        [=](uint64_t end, uint32_t len, uint32_t cost) {
+                            const uint64_t gend = base + end;
+                            if (gend <= emit_from) return;
+                            unsigned long long idx = atomicAdd(count, 1ull);
+                            if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
+                        });
+}
+
 template <int N>
 static hipError_t launch_n(const SearchParams &P, bool trans, uint32_t grid, hipStream_t s) {
     if (trans) hipLaunchKernelGGL((lev_search_kernel<N, true>), dim3(grid), dim3(256), 0, s, P);
@@ -44,7 +67,8 @@ hipError_t lev_search_launch(const SearchParams &P, bool /*affine*/, bool trans,
     if (n <= 16) return launch_n<16>(P, trans, grid, s);
     if (n <= 24) return launch_n<24>(P, trans, grid, s);
     if (n <= 32) return launch_n<32>(P, trans, grid, s);
-    return hipErrorNotSupported;
+    hipLaunchKernelGGL(lev_search_mem_kernel, dim3(grid), dim3(256), 0, s, P, tiles);
+    return hipGetLastError();
 }
 
 // hamming_search: one lane per haystack offset, needle (kernarg) compared 4 bytes at a time.
@@ -58,10 +82,10 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P) {
     uint32_t j = 0;
     typedef uint32_t u32u __attribute__((aligned(1)));
     for (; j + 4 <= n; j += 4) {
-        uint32_t x = *(const u32u *)(h + j) ^ *(const u32u *)(P.needle + j);
+        uint32_t x = *(const u32u *)(h + j) ^ *(const u32u *)(P.needle_dev + j);
         cnt += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
     }
-    for (; j < n; j++) cnt += (h[j] != P.needle[j]);
+    for (; j < n; j++) cnt += (h[j] != P.needle_dev[j]);
     if (cnt <= P.k) {
         unsigned long long idx = atomicAdd(P.count, 1ull);
         if (idx < P.cap) P.hits[idx] = ta_match{P.base + i, P.base + i + n, cnt, 0u};

@@ -98,4 +98,72 @@ TA_HD inline void lev_search_tile(const uint8_t *hay, const uint8_t *needle, uin
     }
 }
 
+// Same recurrence with the DP column kept in memory (needles longer than the register kernel's 32 rows).
+// Element j of array `arr` of this tile lives at col[(arr * (n + 1) + j) * stride] -- on the GPU `stride` is the
+// number of tiles so that neighbouring lanes touch neighbouring addresses (coalesced); arrays: 0 dp1, 1 l1,
+// 2 ng, 3 ngl, 4 dp0, 5 l0.
+template <class Emit>
+TA_HD inline void lev_search_tile_mem(const uint8_t *hay, const uint8_t *needle, uint32_t n, const SearchCosts &C,
+                                      bool trans, uint32_t *col, uint64_t stride,
+                                      uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Emit emit) {
+    const uint32_t sgc = C.sg + C.gc;
+    const uint64_t rows = (uint64_t)n + 1;
+    auto at = [&](uint32_t arr, uint32_t j) -> uint32_t & { return col[((uint64_t)arr * rows + j) * stride]; };
+    for (uint32_t j = 0; j <= n; j++) {
+        at(0, j) = j * C.gc + (j == 0 ? 0u : C.sg);
+        at(1, j) = 0; at(2, j) = SRCH_INF; at(3, j) = 0;
+        if (trans) { at(4, j) = 0; at(5, j) = 0; }
+    }
+    if (col_begin >= col_end) return;
+    uint32_t c_prev = 0;
+    for (uint64_t i = col_begin; i < col_end; i++) {
+        const uint32_t c = hay[i];
+        const bool first_col = (i == col_begin);
+        const uint32_t c0 = C.anchored ? ((uint32_t)(i + 1)) * C.gc + C.sg : 0u;
+        uint32_t up_dp = c0, up_l = 0;
+        uint32_t diag_dp = at(0, 0), diag_l = at(1, 0);
+        uint32_t hg = SRCH_INF, hgl = 0;
+        uint32_t z1_dp = 0, z1_l = 0, z2_dp = 0, z2_l = 0;
+        if (trans) { z1_dp = at(4, 0); z1_l = at(5, 0); at(4, 0) = diag_dp; at(5, 0) = diag_l; }
+        at(0, 0) = c0; at(1, 0) = 0;
+        uint32_t nb_prev = 0;
+        for (uint32_t j = 1; j <= n; j++) {
+            const uint32_t nb = needle[j - 1];
+            const uint32_t old_dp = at(0, j), old_l = at(1, j);
+            const uint32_t ngj = at(2, j), nglj = at(3, j);
+            uint32_t sub = diag_dp + (nb != c ? C.mc : 0u);
+
+            uint32_t new_gap = old_dp + sgc, cont_gap = ngj + C.gc;
+            uint32_t g_l = (new_gap < cont_gap) ? old_l : (new_gap > cont_gap) ? nglj : (old_l > nglj ? old_l : nglj);
+            const uint32_t ng_new = new_gap < cont_gap ? new_gap : cont_gap, ngl_new = g_l + 1;
+            at(2, j) = ng_new; at(3, j) = ngl_new;
+
+            uint32_t new_gap2 = up_dp + sgc, cont_gap2 = hg + C.gc;
+            uint32_t h_l = (new_gap2 < cont_gap2) ? up_l : (new_gap2 > cont_gap2) ? hgl : (up_l > hgl ? up_l : hgl);
+            hg = new_gap2 < cont_gap2 ? new_gap2 : cont_gap2;
+            hgl = h_l;
+
+            uint32_t v = ng_new, vl = ngl_new;
+            if ((hg < v) || (hg == v && up_l > vl)) { v = hg; vl = hgl; }
+            if ((sub < v) || (sub == v && (diag_l + 1) > vl)) { v = sub; vl = diag_l + 1; }
+            if (trans) {
+                const uint32_t t_dp = z2_dp, t_l = z2_l;
+                z2_dp = z1_dp; z2_l = z1_l;
+                z1_dp = at(4, j); z1_l = at(5, j);
+                at(4, j) = old_dp; at(5, j) = old_l;
+                if (j > 1 && !first_col && nb == c_prev && nb_prev == c) {
+                    uint32_t t = t_dp + C.tc;
+                    if (t <= v) { v = t; vl = t_l + 2; }
+                }
+            }
+            at(0, j) = v; at(1, j) = vl;
+            diag_dp = old_dp; diag_l = old_l;
+            up_dp = v; up_l = vl;
+            nb_prev = nb;
+        }
+        c_prev = c;
+        if (up_dp <= C.k && i >= emit_begin) emit(i + 1, up_l, up_dp);
+    }
+}
+
 }  // namespace ta

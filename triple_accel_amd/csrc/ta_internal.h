@@ -50,7 +50,9 @@ hipError_t iota_launch(uint32_t *p, uint32_t n, hipStream_t st);
 struct SearchParams {
     const uint8_t *hay;       // device
     uint64_t hay_len;
-    uint8_t needle[256];      // by value (kernarg)
+    uint8_t needle[32];       // by value (kernarg) for the register kernel (needles <= 32)
+    const uint8_t *needle_dev;   // device copy (any length)
+    uint32_t *col_scratch;    // memory-backed column (long needles)
     uint32_t needle_len;
     uint32_t k, mc, gc, sg, tc;
     uint32_t anchored;

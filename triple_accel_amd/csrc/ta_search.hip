@@ -37,7 +37,7 @@ static void fill_params(SearchParams &P, const uint8_t *needle, size_t n, const 
                         size_t cap, unsigned long long *count) {
     memset(&P, 0, sizeof(P));
     P.hay = hay; P.hay_len = h;
-    memcpy(P.needle, needle, n);
+    memcpy(P.needle, needle, n < sizeof(P.needle) ? n : sizeof(P.needle));
     P.needle_len = (uint32_t)n;
     P.k = k;
     if (c) {
@@ -63,10 +63,7 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
     if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;         // :1965
     if (needle_len == 0) { set_last_error_msg("empty needle is handled by the host entry point"); return TA_ERR_ARG; }
-    if (needle_len > 32) {
-        set_last_error_msg("levenshtein_search on the GPU path supports needles up to 32 bytes in this round");
-        return TA_ERR_UNSUPPORTED;
-    }
+    if (needle_len > 0xFFFFu) { set_last_error_msg("needle longer than 65535 bytes"); return TA_ERR_ARG; }
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     Scratch &cnt = tls_scratch(2);
@@ -87,6 +84,23 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     P.halo = (uint32_t)halo64;
     P.tile = anchored ? 0x7FFFFFFFu : pick_tile(h, P.halo);
     if (anchored) P.halo = 0;
+    if (needle_len > 32) {
+        // memory-backed column: needle on the device, 6 arrays of (n+1) u32 per tile; keep the scratch <= ~256 MB
+        Scratch &nd = tls_scratch(7), &cs = tls_scratch(6);
+        if ((rc = nd.ensure(needle_len + 16))) return rc;
+        TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
+        P.needle_dev = (const uint8_t *)nd.dev;
+        const uint64_t per_tile = 6ull * (needle_len + 1) * 4ull;
+        uint64_t max_tiles = (256ull << 20) / per_tile;
+        if (max_tiles < 64) max_tiles = 64;
+        if (!anchored) {
+            uint64_t t = (h + max_tiles - 1) / max_tiles;
+            if (t > P.tile) P.tile = (uint32_t)(t > 0x7FFFFFFFull ? 0x7FFFFFFFull : t);
+        }
+        const uint64_t tiles = (h + P.tile - 1) / P.tile;
+        if ((rc = cs.ensure((size_t)(per_tile * (tiles ? tiles : 1))))) return rc;
+        P.col_scratch = (uint32_t *)cs.dev;
+    }
     TA_HIP(lev_search_launch(P, costs->start_gap_cost > 0, costs->has_transpose != 0, st));
     unsigned long long c = 0;
     TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
@@ -99,7 +113,6 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
                           const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
                           uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
     if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
-    if (needle_len > 256) { set_last_error_msg("hamming_search on the GPU path supports needles up to 256 bytes"); return TA_ERR_UNSUPPORTED; }
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     *count_host = 0;
@@ -112,6 +125,10 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
     SearchParams P;
     fill_params(P, needle_host, needle_len, haystack_dev, haystack_len, k, nullptr, 0, base, 0, hits_dev, cap,
                 (unsigned long long *)cnt.dev);
+    Scratch &nd = tls_scratch(7);
+    if ((rc = nd.ensure(needle_len + 16))) return rc;
+    TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
+    P.needle_dev = (const uint8_t *)nd.dev;
     TA_HIP(hamming_search_launch(P, st));
     unsigned long long c[2] = {0, 0};
     TA_HIP(hipMemcpyAsync(c, cnt.dev, 16, hipMemcpyDeviceToHost, st));
