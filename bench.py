@@ -120,7 +120,7 @@ def main():
         def run():
             hits = B.levenshtein_search_dev(needle, hay, k, costs)                 # All-mode hits (kernel + gather + sort)
             holder["hits"] = hits
-            holder["best"] = TD.fold_best([tuple(r) for r in hits], k, True)       # the sequential Best pass (host)
+            holder["best"] = TD.fold_best(hits, k, True)                           # the sequential Best pass (host)
         desc = "levenshtein_search 32B needle over a %d MiB random haystack shard per GPU, k=16, Best" % mib
         unit_name, dtype = "haystack bytes", "u8 cost+length cells computed in u32 lanes"
         cpu_sample = 8 << 20

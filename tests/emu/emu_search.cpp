@@ -11,6 +11,9 @@ using namespace ta;
 
 struct Hit { uint64_t start, end; uint32_t k, pad; };
 
+static bool g_packed = false;
+extern "C" void emu_search_set_packed(int on) { g_packed = on != 0; }
+
 template <int N>
 static void run_tiles(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, const SearchCosts &C,
                       bool trans, uint64_t tile, uint64_t halo, std::vector<Hit> &hits) {
@@ -18,8 +21,13 @@ static void run_tiles(const uint8_t *needle, uint32_t n, const uint8_t *hay, uin
         uint64_t ee = eb + tile < h ? eb + tile : h;
         uint64_t cb = eb > halo ? eb - halo : 0;
         auto emit = [&](uint64_t end, uint32_t len, uint32_t cost) { hits.push_back(Hit{end - len, end, cost, 0}); };
-        if (trans) lev_search_tile<N, true>(hay, needle, n, C, cb, eb, ee, emit);
-        else lev_search_tile<N, false>(hay, needle, n, C, cb, eb, ee, emit);
+        if (g_packed) {
+            if (trans) lev_search_tile_packed<N, true>(hay, needle, n, C, cb, eb, ee, emit);
+            else lev_search_tile_packed<N, false>(hay, needle, n, C, cb, eb, ee, emit);
+        } else {
+            if (trans) lev_search_tile<N, true>(hay, needle, n, C, cb, eb, ee, emit);
+            else lev_search_tile<N, false>(hay, needle, n, C, cb, eb, ee, emit);
+        }
     }
 }
 
@@ -44,7 +52,15 @@ extern "C" int emu_lev_search(const uint8_t *needle, uint32_t n, const uint8_t *
     std::vector<Hit> hits;
     if (n == 0) return 1;
     if (n > 32) run_tiles_mem(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
-    else if (n <= 8) run_tiles<8>(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
+    else if (g_packed) {
+        switch (n) {
+#define TA_N(x) case x: run_tiles<x>(needle, n, hay, h, C, has_t != 0, tile, halo, hits); break;
+            TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)
+            TA_N(13) TA_N(14) TA_N(15) TA_N(16) TA_N(17) TA_N(18) TA_N(19) TA_N(20) TA_N(21) TA_N(22) TA_N(23) TA_N(24)
+            TA_N(25) TA_N(26) TA_N(27) TA_N(28) TA_N(29) TA_N(30) TA_N(31) TA_N(32)
+#undef TA_N
+        }
+    } else if (n <= 8) run_tiles<8>(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
     else if (n <= 16) run_tiles<16>(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
     else run_tiles<32>(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
     *count = hits.size();

@@ -55,7 +55,7 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
     return res, dict(D=int(plan[0]), L=int(plan[1]), PW=int(plan[2]), u=int(plan[3]), o=int(plan[4]))
 
 
-def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False, tile=64, halo=None):
+def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False, tile=64, halo=None, packed=False):
     """All-mode hits [(start, end, k)] of the tile function run over a tiled haystack (halo = n + unit_k + 2)."""
     mc, gc, sg, tc = costs
     n = len(needle)
@@ -67,6 +67,7 @@ def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False,
     if anchored:
         h = min(h, n + max(0, k - sg) // gc)
         tile, halo = 1 << 40, 0
+    lib().emu_search_set_packed(int(packed))
     cap = len(haystack) + 2
     out = np.zeros((cap, 3), dtype=np.uint64)
     cnt = C.c_uint64()

@@ -26,8 +26,9 @@ def test_tiled_equals_monolithic(costs):
             want = oracle_all(needle, hay, k, costs)
             for tile in (1 << 30, 64, 97, 256):
                 tile = max(tile, 1)
-                got = E.lev_search_tiled(needle, hay, k, costs, tile=tile)
-                assert got == want, (n, k, tile, costs)
+                for packed in (False, True):
+                    got = E.lev_search_tiled(needle, hay, k, costs, tile=tile, packed=packed)
+                    assert got == want, (n, k, tile, costs, packed)
 
 
 def test_small_alphabet_ties():
@@ -41,7 +42,8 @@ def test_small_alphabet_ties():
             k = int(g.integers(0, n + 1))
             want = oracle_all(needle, hay, k, costs)
             for tile in (1 << 30, 16, 33):
-                assert E.lev_search_tiled(needle, hay, k, costs, tile=tile) == want, (needle, hay, k, costs, tile)
+                for packed in (False, True):
+                    assert E.lev_search_tiled(needle, hay, k, costs, tile=tile, packed=packed) == want, (needle, hay, k, costs, tile, packed)
 
 
 def test_anchored():
@@ -53,7 +55,8 @@ def test_anchored():
             hay = Dg.mutate(g, needle, 3, costs[3] is not None) + Dg.rand_str(g, 20)
             k = int(g.integers(0, 6))
             want = oracle_all(needle, hay, k, costs, anchored=True)
-            assert E.lev_search_tiled(needle, hay, k, costs, anchored=True) == want
+            for packed in (False, True):
+                assert E.lev_search_tiled(needle, hay, k, costs, anchored=True, packed=packed) == want
 
 
 def test_long_needles_memory_backed_column():

@@ -112,3 +112,25 @@ def test_long_needles_and_long_hamming_needles():
     for k in (0, 1, 5):
         want = O.hamming_search_simd_with_opts(needle, hay, k, O.ALL)
         assert [tuple(m) for m in T.hamming_search_simd_with_opts(needle, hay, k, O.ALL)] == want and len(want) >= 1
+
+
+def test_unpacked_register_kernel_still_agrees(monkeypatch):
+    """TA_SEARCH_UNPACKED=1 selects the 32-bit cost / 32-bit length register kernel (used when costs or tiles do
+    not fit the packed 16+16 form); it must give the same matches."""
+    monkeypatch.setenv("TA_SEARCH_UNPACKED", "1")
+    g = Dg.rng(5)
+    for costs in COSTS[:4]:
+        needle = Dg.rand_str(g, 20)
+        hay = Dg.planted_haystack(11, needle, 20000, 300, 6)
+        for st in (O.ALL, O.BEST):
+            assert prod_search(needle, hay, 6, st, costs) == O.levenshtein_search_naive_with_opts(needle, hay, 6, st, costs, False)
+
+
+def test_big_k_takes_the_unpacked_kernel():
+    g = Dg.rng(6)
+    needle = Dg.rand_str(g, 10)
+    hay = Dg.rand_str(g, 3000)
+    costs = (255, 255, 255, None)
+    for k in (40000, 70000):
+        want = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, False)
+        assert prod_search(needle, hay, k, O.ALL, costs) == want

@@ -94,6 +94,18 @@ def _hits_to_numpy(hits_t, count):
     return out[order]
 
 
+_hit_bufs = {}
+
+
+def _hit_buffer(device, cap):
+    """Reused device buffer for hit records (24 B each)."""
+    key = (str(device), cap)
+    if key not in _hit_bufs:
+        _hit_bufs.clear()
+        _hit_bufs[key] = torch.empty(cap * 3, dtype=torch.int64, device=device)
+    return _hit_bufs[key]
+
+
 def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchored=False, base=0, emit_from=0, cap=None):
     """All-mode hits of levenshtein_search_simd_with_opts over a uint8 CUDA tensor (with >= 16 B of read slack
     after `length`): int64 array of rows (start, end, k) sorted by end.  `base` offsets the positions,
@@ -101,8 +113,8 @@ def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchore
     hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
     assert hay.dtype == torch.uint8 and hay.is_cuda and hay.is_contiguous()
     needle = bytes(needle)
-    cap = cap or min(length + 2, 1 << 24)
-    hits = torch.empty(cap * 3, dtype=torch.int64, device=hay.device)
+    cap = cap or min(length + 2, 1 << 22)
+    hits = _hit_buffer(hay.device, cap)
     count = _C.c_uint64()
     cc = _costs(costs)._c()
     rc = _n.lib().ta_levenshtein_search_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), int(anchored),
@@ -114,8 +126,8 @@ def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchore
 def hamming_search_dev(needle, haystack, k, base=0, cap=None):
     hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
     needle = bytes(needle)
-    cap = cap or min(length + 2, 1 << 24)
-    hits = torch.empty(cap * 3, dtype=torch.int64, device=hay.device)
+    cap = cap or min(length + 2, 1 << 22)
+    hits = _hit_buffer(hay.device, cap)
     count = _C.c_uint64()
     rc = _n.lib().ta_hamming_search_dev(needle, len(needle), hay.data_ptr(), length, k, base, hits.data_ptr(), cap,
                                         _C.byref(count), _stream())

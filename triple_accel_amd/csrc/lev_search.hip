@@ -6,7 +6,7 @@
 
 namespace ta {
 
-template <int N, bool TRANS>
+template <int N, bool TRANS, bool PACKED>
 __global__ __launch_bounds__(256) void lev_search_kernel(SearchParams P) {
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t emit_begin = tile * P.tile;
@@ -18,13 +18,14 @@ __global__ __launch_bounds__(256) void lev_search_kernel(SearchParams P) {
     ta_match *hits = P.hits;
     unsigned long long *count = P.count;
     const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
-    lev_search_tile<N, TRANS>(P.hay, P.needle, P.needle_len, C, col_begin, emit_begin, emit_end,
-                              [=](uint64_t end, uint32_t len, uint32_t cost) {
-                                  const uint64_t gend = base + end;
-                                  if (gend <= emit_from) return;
-                                  unsigned long long idx = atomicAdd(count, 1ull);
-                                  if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
-                              });
+    auto emit = [=](uint64_t end, uint32_t len, uint32_t cost) {
+        const uint64_t gend = base + end;
+        if (gend <= emit_from) return;
+        unsigned long long idx = atomicAdd(count, 1ull);
+        if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
+    };
+    if (PACKED) lev_search_tile_packed<N, TRANS>(P.hay, P.needle, P.needle_len, C, col_begin, emit_begin, emit_end, emit);
+    else lev_search_tile<N, TRANS>(P.hay, P.needle, P.needle_len, C, col_begin, emit_begin, emit_end, emit);
 }
 
 // long needles: the column lives in HBM scratch, element-major so that a wavefront's accesses coalesce
@@ -51,22 +52,36 @@ __global__ __launch_bounds__(256) void lev_search_mem_kernel(SearchParams P, uin
 }
 
 template <int N>
-static hipError_t launch_n(const SearchParams &P, bool trans, uint32_t grid, hipStream_t s) {
-    if (trans) hipLaunchKernelGGL((lev_search_kernel<N, true>), dim3(grid), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((lev_search_kernel<N, false>), dim3(grid), dim3(256), 0, s, P);
+static hipError_t launch_n(const SearchParams &P, bool trans, bool packed, uint32_t grid, hipStream_t s) {
+    if (packed) {
+        if (trans) hipLaunchKernelGGL((lev_search_kernel<N, true, true>), dim3(grid), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((lev_search_kernel<N, false, true>), dim3(grid), dim3(256), 0, s, P);
+    } else if constexpr (N % 8 == 0) {
+        if (trans) hipLaunchKernelGGL((lev_search_kernel<N, true, false>), dim3(grid), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((lev_search_kernel<N, false, false>), dim3(grid), dim3(256), 0, s, P);
+    }
     return hipGetLastError();
 }
 
-hipError_t lev_search_launch(const SearchParams &P, bool /*affine*/, bool trans, hipStream_t s) {
+// packed: cost and length in one VGPR (see lev_search_tile_packed for the validity conditions, checked by the caller)
+hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hipStream_t s) {
     if (P.hay_len == 0) return hipSuccess;
     const uint64_t tiles = (P.hay_len + P.tile - 1) / P.tile;
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
     const uint32_t n = P.needle_len;
-    if (n <= 4) return launch_n<4>(P, trans, grid, s);
-    if (n <= 8) return launch_n<8>(P, trans, grid, s);
-    if (n <= 16) return launch_n<16>(P, trans, grid, s);
-    if (n <= 24) return launch_n<24>(P, trans, grid, s);
-    if (n <= 32) return launch_n<32>(P, trans, grid, s);
+    if (packed && n <= 32) {              // one instantiation per needle length: straight-line column code
+        switch (n) {
+#define TA_N(x) case x: return launch_n<x>(P, trans, true, grid, s);
+            TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)
+            TA_N(13) TA_N(14) TA_N(15) TA_N(16) TA_N(17) TA_N(18) TA_N(19) TA_N(20) TA_N(21) TA_N(22) TA_N(23) TA_N(24)
+            TA_N(25) TA_N(26) TA_N(27) TA_N(28) TA_N(29) TA_N(30) TA_N(31) TA_N(32)
+#undef TA_N
+        }
+    }
+    if (n <= 8) return launch_n<8>(P, trans, false, grid, s);
+    if (n <= 16) return launch_n<16>(P, trans, false, grid, s);
+    if (n <= 24) return launch_n<24>(P, trans, false, grid, s);
+    if (n <= 32) return launch_n<32>(P, trans, false, grid, s);
     hipLaunchKernelGGL(lev_search_mem_kernel, dim3(grid), dim3(256), 0, s, P, tiles);
     return hipGetLastError();
 }

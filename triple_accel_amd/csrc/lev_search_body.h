@@ -98,6 +98,76 @@ TA_HD inline void lev_search_tile(const uint8_t *hay, const uint8_t *needle, uin
     }
 }
 
+// Packed form: cost and match length share one VGPR, key = (cost << 16) | (0xFFFF - length), so the reference's
+// "cheaper wins, on a tie the LONGER match wins" (src/levenshtein.rs:1726-1750, 1762-1765) is ONE v_min_u32, and
+// "length + 1" is "key - 1".  The one rule that is not a plain min -- the haystack-gap candidate is compared with
+// length2[j-1] but delivers haystack_gap_length[j] (:1755-1760, quirk Q2) -- splices the two 16-bit fields with a
+// v_bfi before the compare.  Valid while every cost stays below 2^16 and lengths below 0xFFFF: the host selects this
+// kernel for needle_len <= 32, k <= 30000 and tiles + halo <= 60000 columns (costs are bounded by
+// min(j*mc, j*gc+sg) + k <= 8415 + k there), anything else takes lev_search_tile / lev_search_tile_mem.
+template <int N, bool TRANS, class Emit>
+TA_HD inline void lev_search_tile_packed(const uint8_t *hay, const uint8_t *needle, uint32_t /*n == N*/, const SearchCosts &C,
+                                         uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Emit emit) {
+    uint32_t dp1[N + 1], ng[N + 1], dp0[TRANS ? N + 1 : 1];
+    const uint32_t SGC = (C.sg + C.gc) << 16, GC = C.gc << 16;
+    const uint32_t SUB_MIS = (C.mc << 16) - 1u, SUB_EQ = 0xFFFFFFFFu;   // (+mc, length+1) and (+0, length+1)
+    const uint32_t TCK = (C.tc << 16) - 2u;                              // (+tc, length+2)
+    constexpr uint32_t KINF = (0x7000u << 16) | 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j <= N; j++) {
+        dp1[j] = (((uint32_t)j * C.gc + (j == 0 ? 0u : C.sg)) << 16) | 0xFFFFu;
+        ng[j] = KINF;
+        if (TRANS) dp0[j] = 0xFFFFu;
+    }
+    if (col_begin >= col_end) return;
+    uint32_t c_prev = 0;
+    uint32_t c_next = hay[col_begin];
+    for (uint64_t i = col_begin; i < col_end; i++) {
+        const uint32_t c = c_next;
+        if (i + 1 < col_end) c_next = hay[i + 1];
+        const bool later_col = (i != col_begin);
+        const uint32_t c0 = C.anchored ? ((((uint32_t)(i + 1)) * C.gc + C.sg) << 16) | 0xFFFFu : 0xFFFFu;
+        uint32_t up = c0;                 // dp2[j-1] with its length
+        uint32_t diag = dp1[0];           // dp1[j-1]
+        uint32_t hg = KINF;               // haystack_gap_dp[j-1] with haystack_gap_length[j-1]
+        uint32_t z1 = 0, z2 = 0;
+        if (TRANS) { z1 = dp0[0]; dp0[0] = dp1[0]; }
+        dp1[0] = c0;
+#pragma unroll
+        for (int j = 1; j <= N; j++) {
+          {                                 // N == needle length exactly (one instantiation per length): no row test
+            const uint32_t nb = needle[j - 1 < 32 ? j - 1 : 31];
+            const uint32_t old = dp1[j];
+            // needle gap (consumes the haystack byte): open from dp1[j] or extend; length + 1          :1726-1737
+            uint32_t a1 = old + SGC, a2 = ng[j] + GC;
+            const uint32_t ngk = (a1 < a2 ? a1 : a2) - 1u;
+            ng[j] = ngk;
+            // haystack gap (skips a needle char): open from dp2[j-1] or extend; length unchanged        :1739-1750
+            uint32_t h1 = up + SGC, h2 = hg + GC;
+            hg = h1 < h2 ? h1 : h2;
+            uint32_t v = ngk;                                                                            // :1752-1753
+            const uint32_t hq = (hg & 0xFFFF0000u) | (up & 0xFFFFu);     // cost of the gap, length2[j-1]  (Q2)
+            v = (hq < v) ? hg : v;                                                                       // :1755-1760
+            const uint32_t subk = diag + ((nb != c) ? SUB_MIS : SUB_EQ);                                 // :1724
+            v = subk < v ? subk : v;                                                                     // :1762-1765
+            if (TRANS) {
+                const uint32_t t = z2 + TCK;                              // dp0[j-2] + tc, length0[j-2] + 2
+                z2 = z1; z1 = dp0[j]; dp0[j] = old;
+                const bool cond = (j > 1) & later_col & (nb == c_prev) & ((uint32_t)needle[j >= 2 ? j - 2 : 0] == c);
+                v = (cond & ((t & 0xFFFF0000u) <= v)) ? t : v;                                          // :1767-1779 (<=)
+            }
+            dp1[j] = v;
+            diag = old;
+            up = v;
+          }
+        }
+        c_prev = c;
+        const uint32_t res_key = up;      // dp2[needle_len] with its length
+        const uint32_t res = res_key >> 16;
+        if (res <= C.k && i >= emit_begin) emit(i + 1, 0xFFFFu - (res_key & 0xFFFFu), res);             // :1792-1806
+    }
+}
+
 // Same recurrence with the DP column kept in memory (needles longer than the register kernel's 32 rows).
 // Element j of array `arr` of this tile lives at col[(arr * (n + 1) + j) * stride] -- on the GPU `stride` is the
 // number of tiles so that neighbouring lanes touch neighbouring addresses (coalesced); arrays: 0 dp1, 1 l1,

@@ -63,7 +63,7 @@ struct SearchParams {
     uint64_t cap;
     unsigned long long *count;   // device
 };
-hipError_t lev_search_launch(const SearchParams &P, bool affine, bool trans, hipStream_t s);
+hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
 
 }  // namespace ta

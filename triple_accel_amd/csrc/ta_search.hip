@@ -24,11 +24,12 @@ static bool search_costs_ok(const ta_edit_costs *c) {
 
 // tile size: enough tiles to fill the chip (>= ~128K lanes) while keeping the halo overhead small
 static uint32_t pick_tile(uint64_t hay_len, uint32_t halo) {
-    uint64_t t = (hay_len + 131071) / 131072;
+    if (const char *e = getenv("TA_SEARCH_TILE")) { long v = atol(e); if (v > 0) return (uint32_t)v; }
+    uint64_t t = (hay_len + 524287) / 524288;          // ~2 full sets of resident lanes (256 CUs x 32 waves x 64)
     uint64_t lo = (uint64_t)halo * 2;
     if (t < lo) t = lo;
     if (t < 64) t = 64;
-    if (t > 65536) t = 65536;
+    if (t > 32768) t = 32768;
     return (uint32_t)t;
 }
 
@@ -101,7 +102,10 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         if ((rc = cs.ensure((size_t)(per_tile * (tiles ? tiles : 1))))) return rc;
         P.col_scratch = (uint32_t *)cs.dev;
     }
-    TA_HIP(lev_search_launch(P, costs->start_gap_cost > 0, costs->has_transpose != 0, st));
+    // packed cost/length kernel whenever every cost and length provably fits 16 bits
+    bool packed = needle_len <= 32 && k <= 30000u && (uint64_t)P.tile + P.halo <= 60000u && !getenv("TA_SEARCH_UNPACKED");
+    if (anchored) packed = needle_len <= 32 && k <= 30000u && h <= 60000u && !getenv("TA_SEARCH_UNPACKED");
+    TA_HIP(lev_search_launch(P, packed, costs->has_transpose != 0, st));
     unsigned long long c = 0;
     TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
     TA_HIP(hipStreamSynchronize(st));

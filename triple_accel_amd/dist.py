@@ -45,14 +45,19 @@ def all_gather_results(local, group=None):
     return torch.cat([o[: int(c.item())] for o, c in zip(outs, counts)])
 
 
+_MATCH_DT = np.dtype([("start", "<u8"), ("end", "<u8"), ("k", "<u4"), ("pad_", "<u4")])
+
+
 def fold_best(hits, k, overlap_fold=True):
-    """Sequential Best pass (src/levenshtein.rs:1792-1835) over (start, end, k) rows sorted by end."""
-    n = len(hits)
-    arr = (_n.MatchC * max(n, 1))()
-    for i, (s, e, kk) in enumerate(hits):
-        arr[i].start, arr[i].end, arr[i].k = int(s), int(e), int(kk)
-    m = _n.lib().ta_search_fold_best(arr, n, k, int(overlap_fold))
-    return [(int(arr[i].start), int(arr[i].end), int(arr[i].k)) for i in range(m)]
+    """Sequential Best pass (src/levenshtein.rs:1792-1835) over (start, end, k) rows sorted by end
+    (list of tuples or an (n, 3) integer array)."""
+    rows = np.asarray(hits, dtype=np.int64).reshape(-1, 3)
+    arr = np.zeros(max(len(rows), 1), dtype=_MATCH_DT)
+    arr["start"][: len(rows)] = rows[:, 0]
+    arr["end"][: len(rows)] = rows[:, 1]
+    arr["k"][: len(rows)] = rows[:, 2]
+    m = _n.lib().ta_search_fold_best(arr.ctypes.data_as(_C.POINTER(_n.MatchC)), len(rows), k, int(overlap_fold))
+    return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in arr[:m]]
 
 
 def _gpu_local_search(needle, hay_ext, k, costs, base, emit_from):
