@@ -40,7 +40,7 @@ typedef enum {
     TA_ERR_BAD_COSTS = 3,    /* EditCosts::new / check_search    src/levenshtein.rs:44-52,67-71 */
     TA_ERR_HIP = 4,          /* HIP runtime failure / no device (no CPU fallback) */
     TA_ERR_ARG = 5,          /* null pointer, size over the documented limit */
-    TA_ERR_UNSUPPORTED = 6,  /* trace_on=true (not on the GPU path yet) */
+    TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. traceback of a band wider than 4224 diagonals) */
     TA_ERR_CAPACITY = 7      /* caller-provided match buffer too small; *n_out holds the need */
 } ta_status;
 
@@ -60,6 +60,14 @@ typedef struct {
     uint32_t k;
     uint32_t pad_;
 } ta_match;
+
+/* Edit / EditType, src/lib.rs:148-165 */
+typedef enum { TA_EDIT_MATCH = 0, TA_EDIT_MISMATCH = 1, TA_EDIT_AGAP = 2, TA_EDIT_BGAP = 3, TA_EDIT_TRANSPOSE = 4 } ta_edit_type;
+typedef struct {
+    uint32_t edit;   /* ta_edit_type */
+    uint32_t pad_;
+    uint64_t count;
+} ta_edit;
 
 /* SearchType, src/lib.rs:171-174 */
 typedef enum { TA_SEARCH_ALL = 0, TA_SEARCH_BEST = 1 } ta_search_type;
@@ -114,9 +122,18 @@ int ta_last_launch_info(ta_launch_info *out);
 int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
 
 /* levenshtein_simd_k_with_opts(a, b, k, trace_on, costs), src/levenshtein.rs:714-720.
- * *out = distance, or TA_NONE when the distance exceeds k.  trace_on != 0 -> TA_ERR_UNSUPPORTED. */
+ * *out = distance, or TA_NONE when the distance exceeds k.  trace_on != 0 -> TA_ERR_UNSUPPORTED here: the traceback
+ * has its own entry point, ta_levenshtein_trace, because it returns an edit script. */
 int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                                     uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out);
+/* levenshtein_simd_k_with_opts(a, b, k, true, costs): distance + run-length traceback (library-owned, ta_free).
+ * 2-bit argmin codes come from the band-wavefront kernel; the walk is host code.  Bands wider than 4224 diagonals
+ * (unit_k > ~2100) return TA_ERR_UNSUPPORTED. */
+int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k,
+                         const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits);
+/* levenshtein_exp_with_opts(a, b, true, costs), src/levenshtein.rs:1480-1494 */
+int ta_levenshtein_exp_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                             const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits);
 /* levenshtein_simd_k, src/levenshtein.rs:677-684 */
 int ta_levenshtein_simd_k(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k, uint32_t *out);
 /* levenshtein, src/levenshtein.rs:1397 ; rdamerau :1419 */

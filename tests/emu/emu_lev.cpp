@@ -34,7 +34,7 @@ extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const 
     LevParams P;
     P.a = StrView{a_blob, a_off, 0, 0};
     P.b = StrView{b_blob, b_off, 0, 0};
-    P.subset = nullptr; P.out = out; P.n = n; P.k = k;
+    P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = mc; P.gc = gc; P.sg = sg; P.tc = tc;
     P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw;
     if (plan_out) { plan_out[0] = pl.D; plan_out[1] = pl.L; plan_out[2] = pl.PW; plan_out[3] = pl.u; plan_out[4] = pl.o; }

@@ -4,7 +4,7 @@ import triple_accel_amd as T
 
 
 class Product:
-    supports_trace = False
+    supports_trace = True
 
     @staticmethod
     def hamming(a, b):
@@ -17,12 +17,14 @@ class Product:
     @staticmethod
     def levenshtein_k_with_opts(a, b, k, trace_on, costs):
         r = T.levenshtein_simd_k_with_opts(a, b, k, trace_on, T.EditCosts(*costs))
-        return (None, None) if r is None else r
+        if r is None:
+            return (None, None)
+        return (r[0], None if r[1] is None else [tuple(e) for e in r[1]])
 
     @staticmethod
     def levenshtein_full(a, b, trace_on, costs):
         r = T.levenshtein_simd_k_with_opts(a, b, 0xFFFFFFFF, trace_on, T.EditCosts(*costs))
-        return r
+        return (r[0], None if r[1] is None else [tuple(e) for e in r[1]])
 
     levenshtein = staticmethod(T.levenshtein)
     rdamerau = staticmethod(T.rdamerau)
@@ -31,7 +33,8 @@ class Product:
 
     @staticmethod
     def levenshtein_exp_with_opts(a, b, trace_on, costs):
-        return T.levenshtein_exp_with_opts(a, b, trace_on, T.EditCosts(*costs))
+        r = T.levenshtein_exp_with_opts(a, b, trace_on, T.EditCosts(*costs))
+        return (r[0], None if r[1] is None else [tuple(e) for e in r[1]])
 
     @staticmethod
     def levenshtein_search_with_opts(needle, haystack, k, search_type, costs, anchored):

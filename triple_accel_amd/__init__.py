@@ -75,7 +75,7 @@ def _raise(rc):
     if rc == _n.TA_ERR_BAD_COSTS:
         raise PanicError("invalid EditCosts")
     if rc == _n.TA_ERR_UNSUPPORTED:
-        raise NotImplementedError("triple_accel_amd: not on the GPU path yet (trace_on=true, SURVEY.md 8f)")
+        raise NotImplementedError("triple_accel_amd: not on the GPU path (" + _n.lib().ta_last_error().decode() + ")")
     _n.check(rc)
 
 
@@ -125,11 +125,29 @@ hamming_search = hamming_search_simd   # src/hamming.rs:588
 
 
 # ---------------------------------------------------------------- levenshtein (src/levenshtein.rs)
+_EDIT_NAMES = [EditType.Match, EditType.Mismatch, EditType.AGap, EditType.BGap, EditType.Transpose]
+
+
+def _trace(fn, *args):
+    out = _C.c_uint32()
+    ep = _C.POINTER(_n.EditC)()
+    cnt = _C.c_size_t()
+    _raise(fn(*args, _C.byref(out), _C.byref(ep), _C.byref(cnt)))
+    try:
+        edits = [Edit(_EDIT_NAMES[ep[i].edit], int(ep[i].count)) for i in range(cnt.value)]
+    finally:
+        if ep:
+            _n.lib().ta_free(ep)
+    return (None, None) if out.value == _n.NONE else (int(out.value), edits)
+
+
 def levenshtein_simd_k_with_opts(a, b, k, trace_on, costs):
-    """src/levenshtein.rs:714 -> None | (distance, None).  trace_on=True is not on the GPU path yet."""
+    """src/levenshtein.rs:714 -> None | (distance, None | [Edit])."""
     a, b = _b(a), _b(b)
-    d = _u32(_n.lib().ta_levenshtein_simd_k_with_opts, a, len(a), b, len(b), k, int(bool(trace_on)),
-             _C.byref(_costs(costs)._c()))
+    if trace_on:
+        d, edits = _trace(_n.lib().ta_levenshtein_trace, a, len(a), b, len(b), k, _C.byref(_costs(costs)._c()))
+        return None if d is None else (d, edits)
+    d = _u32(_n.lib().ta_levenshtein_simd_k_with_opts, a, len(a), b, len(b), k, 0, _C.byref(_costs(costs)._c()))
     return None if d is None else (d, None)
 
 
@@ -153,10 +171,11 @@ rdamerau_exp = _dist("ta_rdamerau_exp")          # :1516
 
 
 def levenshtein_exp_with_opts(a, b, trace_on, costs):
-    """src/levenshtein.rs:1480 -> (distance, None)"""
+    """src/levenshtein.rs:1480 -> (distance, None | [Edit])"""
     a, b = _b(a), _b(b)
-    d = _u32(_n.lib().ta_levenshtein_exp_with_opts, a, len(a), b, len(b), int(bool(trace_on)),
-             _C.byref(_costs(costs)._c()))
+    if trace_on:
+        return _trace(_n.lib().ta_levenshtein_exp_trace, a, len(a), b, len(b), _C.byref(_costs(costs)._c()))
+    d = _u32(_n.lib().ta_levenshtein_exp_with_opts, a, len(a), b, len(b), 0, _C.byref(_costs(costs)._c()))
     return (d, None)
 
 

@@ -17,7 +17,8 @@ TA_OK, TA_ERR_LEN_MISMATCH, TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS, TA_ERR_HIP, TA_E
 ABI_SYMBOLS = [
     "ta_levenshtein_costs", "ta_rdamerau_costs", "ta_edit_costs_new", "ta_edit_costs_check_search",
     "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_levenshtein_select",
-    "ta_last_launch_info", "ta_hamming", "ta_levenshtein_simd_k_with_opts", "ta_levenshtein_simd_k",
+    "ta_last_launch_info", "ta_hamming", "ta_levenshtein_simd_k_with_opts", "ta_levenshtein_trace",
+    "ta_levenshtein_exp_trace", "ta_levenshtein_simd_k",
     "ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_levenshtein_exp_with_opts", "ta_rdamerau_exp",
     "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
     "ta_hamming_search", "ta_free", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
@@ -32,6 +33,10 @@ class EditCostsC(C.Structure):
 
 class MatchC(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("k", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+class EditC(C.Structure):
+    _fields_ = [("edit", C.c_uint32), ("pad_", C.c_uint32), ("count", C.c_uint64)]
 
 
 class LevSelectC(C.Structure):
@@ -90,6 +95,9 @@ def lib():
     sig("ta_last_launch_info", i32, [C.POINTER(LaunchInfoC)])
     sig("ta_hamming", i32, [u8p, sz, u8p, sz, u32p])
     sig("ta_levenshtein_simd_k_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, cp, u32p])
+    epp = C.POINTER(C.POINTER(EditC))
+    sig("ta_levenshtein_trace", i32, [u8p, sz, u8p, sz, u32, cp, u32p, epp, szp])
+    sig("ta_levenshtein_exp_trace", i32, [u8p, sz, u8p, sz, cp, u32p, epp, szp])
     sig("ta_levenshtein_simd_k", i32, [u8p, sz, u8p, sz, u32, u32p])
     for n in ("ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_rdamerau_exp"):
         sig(n, i32, [u8p, sz, u8p, sz, u32p])

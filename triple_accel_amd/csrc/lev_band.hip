@@ -43,4 +43,27 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     }
 }
 
+// Trace kernels (single-pair traceback, trace_on = true): D = 16 (bands up to 1024 diagonals) or D = 66.
+template <int D, bool AFFINE, int TRANS>
+__global__ __launch_bounds__(64) void lev_band_trace_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    LevBand<DevWave, D, AFFINE, TRANS, true>::run(P, blockIdx.x, lds);
+}
+
+hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s) {
+    const uint32_t waves = (P.n + pl.PW - 1) / pl.PW;
+    dim3 g(waves), b(64);
+    const size_t lds = pl.lds_per_wave;
+#define TA_T(D_) \
+    if (affine) { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<D_, true, 2>), g, b, lds, s, P); \
+                  else hipLaunchKernelGGL((lev_band_trace_kernel<D_, true, 0>), g, b, lds, s, P); } \
+    else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 2>), g, b, lds, s, P); \
+           else hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 0>), g, b, lds, s, P); }
+    if (pl.D == 16) { TA_T(16) }
+    else if (pl.D == 66) { TA_T(66) }
+    else return hipErrorInvalidValue;
+#undef TA_T
+    return hipGetLastError();
+}
+
 }  // namespace ta

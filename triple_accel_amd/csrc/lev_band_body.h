@@ -44,10 +44,14 @@ struct LevParams {
     uint32_t PW;              // pairs per wave = 64 / L
     uint32_t lds_per_wave;    // bytes
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
+    uint32_t *trace;          // TRACE kernels: 2-bit argmin codes, word w of (iteration tau, phase, lane) at
+                              // ((tau*2 + phase)*64 + lane)*LEV_TRACE_WORDS(D) + w, cell c in bits [2c, 2c+2)
 };
 
+constexpr int lev_trace_words(int D) { return (D + 31) / 32; }   // 2 bits x D/2 cells per phase
+
 // TRANS: 0 = no transposition, 1 = transposition as a dot4 penalty (needs 2*mc <= 255 + tc), 2 = as a select
-template <class W, int D, bool AFFINE, int TRANS>
+template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false>
 struct LevBand {
     static_assert(D % 2 == 0 && D >= 2, "D must be even");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
@@ -67,9 +71,15 @@ struct LevBand {
 
     // One anti-diagonal step for the cells q = 2c + PAR of every lane.
     template <int PAR>
-    static TA_HD inline __attribute__((always_inline)) void phase(State &st, const LevParams &P, Bool is_g0, Bool is_gl) {
+    static TA_HD inline __attribute__((always_inline)) void phase(State &st, const LevParams &P, Bool is_g0, Bool is_gl,
+                                                                  uint32_t tau, U32 lane) {
         const U32 INF = W::splat(LEV_INF);
         U32 X[NW], Z[NW];
+        U32 tcodes[lev_trace_words(D)];
+        if (TRACE) {
+#pragma unroll
+            for (int w = 0; w < lev_trace_words(D); w++) tcodes[w] = W::splat(0);
+        }
 #pragma unroll
         for (int w = 0; w < NW; w++) X[w] = st.AW[w] ^ st.BW[w];
         if (TRANS) {
@@ -112,6 +122,11 @@ struct LevBand {
             U32 lft = (PAR == 0 && c == 0) ? xl : ((AFFINE || PAR == 0) ? st.HA[ql] : st.reg[ql]);          // a_gap  :476-483
             U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : (PAR == 0 ? st.HA[qr] : st.reg[qr]));   // b_gap :484-491
             U32 nv = W::umin3(sub, lft, rgt);                                     // :493-515
+            U32 code = W::splat(0);
+            if (TRACE) {   // argmin code with the scalar tie order: sub, then a_gap (<), then b_gap (<)   :493-515
+                U32 m1 = W::umin(sub, lft);
+                code = W::sel(rgt < m1, W::splat(2), W::sel(lft < sub, W::splat(1), W::splat(0)));
+            }
             if (TRANS == 1) {
                 // PV holds dp(i-2,j-2) + tc.  A failed test adds 255, which lifts the candidate above nv:
                 // nv <= dp(i-1,j-1) + mc <= dp(i-2,j-2) + 2 mc <= dp(i-2,j-2) + tc + 255 (host guarantees the last step).
@@ -122,8 +137,10 @@ struct LevBand {
                 U32 t = st.PV[q];
                 st.PV[q] = st.reg[q] + P.tc;
                 Bool tz = W::byte_of(Z[w], byte & 3) == 0u;
+                if (TRACE) code = W::sel(tz & (t <= nv), W::splat(3), code);            // transpose wins ties (<=)
                 nv = W::sel(tz, W::umin(nv, t), nv);
             }
+            if (TRACE) tcodes[(2 * c) >> 5] = tcodes[(2 * c) >> 5] | (code << ((2 * c) & 31));
             st.reg[q] = nv;
             if (AFFINE) {
                 U32 go = nv + (P.sg + P.gc);                                      // open a gap from this cell
@@ -132,6 +149,13 @@ struct LevBand {
             } else if (PAR == 1) {
                 st.HA[q] = nv + 2u * P.gc;
             }
+        }
+        if (TRACE) {
+            static_assert(!TRACE || TRANS != 1, "trace kernels use the select form of the transposition");
+#pragma unroll
+            for (int w = 0; w < lev_trace_words(D); w++)
+                W::store_u32(P.trace, (lane + (tau * 2u + (uint32_t)PAR) * 64u) * (uint32_t)lev_trace_words(D) + (uint32_t)w,
+                             tcodes[w], lane == lane);
         }
     }
 
@@ -262,9 +286,9 @@ struct LevBand {
             for (; tp < t_hi; tp++) {
                 U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));
                 U32 b_in = W::lds_u8(lds, b_slot + ((tp + db) & (LEV_RING - 1)));
-                phase<0>(st, P, is_g0, is_gl);
+                phase<0>(st, P, is_g0, is_gl, tp - Tw, lane);
                 advance_b(st, b_in, is_gl);
-                phase<1>(st, P, is_g0, is_gl);
+                phase<1>(st, P, is_g0, is_gl, tp - Tw, lane);
                 advance_a(st, a_in, is_g0);
                 Bool cap = (t_cap == tp);
                 if (W::any(cap)) {                 // the answer cell was written in this iteration

@@ -89,7 +89,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     LevPlan pl = lev_make_plan(k, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"));
     LevParams P;
     P.a = view_of(a); P.b = view_of(b);
-    P.subset = subset; P.out = out_dev; P.n = n_work; P.k = k;
+    P.subset = subset; P.trace = nullptr; P.out = out_dev; P.n = n_work; P.k = k;
     P.mc = c->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = c->has_transpose ? c->transpose_cost : 0;
     P.u = pl.u; P.o = pl.o;
     const bool affine = sg > 0 || env_int("TA_FORCE_AFFINE"), trans = c->has_transpose != 0;
@@ -332,6 +332,85 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
     rc = ta_levenshtein_k_batch(&sa, &sb, 1, k, costs, od, 0);
     if (rc) return rc;
     return fetch_u32(od, out);
+}
+
+/* levenshtein_simd_k_with_opts(..., trace_on = true): distance + run-length edit script.
+ * The band-wavefront kernel stores a 2-bit argmin code per cell (tie order of src/levenshtein.rs:493-532);
+ * the walk from (n, m) back to (0, 0) is the host part (:561-606). */
+int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k,
+                         const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits) {
+    if (!out || !edits || !n_edits) return TA_ERR_ARG;
+    *edits = nullptr; *n_edits = 0;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (a_len == 0 && b_len == 0) { *out = 0; return TA_OK; }                   // :721-727 (Some(vec![]))
+    const bool swap = a_len > b_len;                                            // :386-390
+    const uint8_t *x = swap ? b : a, *y = swap ? a : b;
+    const size_t n = swap ? b_len : a_len, m = swap ? a_len : b_len;
+    ta_lev_select sel;
+    ta_levenshtein_select(n, m, k, costs, &sel);
+    const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
+    LevPlan pl = lev_make_plan(sel.max_k, gc, sg, m, 16, 0);
+    if (!pl.ok) pl = lev_make_plan(sel.max_k, gc, sg, m, 66, 0);
+    if (!pl.ok) { set_last_error_msg("traceback band wider than 4224 diagonals is not on the GPU path yet"); return TA_ERR_UNSUPPORTED; }
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    if (rc) return rc;
+    const uint32_t tw = (uint32_t)lev_trace_words(pl.D);
+    const size_t taus = (n + m + 1) / 2 + 1;
+    const size_t trace_words = taus * 2 * 64 * tw;
+    Scratch &ts = tls_scratch(6);
+    if ((rc = ts.ensure(trace_words * 4))) return rc;
+    LevParams P;
+    P.a = view_of(&sa); P.b = view_of(&sb);
+    P.subset = nullptr; P.out = od; P.n = 1; P.k = k;
+    P.mc = costs->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = costs->has_transpose ? costs->transpose_cost : 0;
+    P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw;
+    P.trace = (uint32_t *)ts.dev;
+    TA_HIP(lev_band_trace_launch(P, pl, sg > 0, costs->has_transpose != 0, 0));
+    uint32_t d = 0;
+    rc = fetch_u32(od, &d);
+    if (rc) return rc;
+    *out = d;
+    if (d == TA_NONE) return TA_OK;
+    std::vector<uint32_t> tr(trace_words);
+    TA_HIP(hipMemcpy(tr.data(), ts.dev, trace_words * 4, hipMemcpyDeviceToHost));
+    std::vector<ta_edit> res;
+    size_t i = n, j = m;
+    while (i > 0 || j > 0) {                                                    // :561-603
+        const uint32_t s = (uint32_t)(i + j), p = (uint32_t)(j + pl.o - i);
+        const uint32_t g = p / (uint32_t)pl.D, q = p % (uint32_t)pl.D, par = q & 1u, c = q >> 1, tau = (s - 1) >> 1;
+        const uint32_t word = tr[(((size_t)tau * 2 + par) * 64 + g) * tw + ((2 * c) >> 5)];
+        const uint32_t code = (word >> ((2 * c) & 31)) & 3u;
+        uint32_t e;
+        switch (code) {
+            case 0: i--; j--; e = (x[i] == y[j]) ? TA_EDIT_MATCH : TA_EDIT_MISMATCH; break;
+            case 1: j--; e = swap ? TA_EDIT_BGAP : TA_EDIT_AGAP; break;
+            case 2: i--; e = swap ? TA_EDIT_AGAP : TA_EDIT_BGAP; break;
+            default: i -= 2; j -= 2; e = TA_EDIT_TRANSPOSE; break;
+        }
+        if (!res.empty() && res.back().edit == e) res.back().count++;
+        else res.push_back(ta_edit{e, 0u, 1u});
+    }
+    *n_edits = res.size();
+    if (!res.empty()) {
+        *edits = (ta_edit *)malloc(res.size() * sizeof(ta_edit));
+        for (size_t t = 0; t < res.size(); t++) (*edits)[t] = res[res.size() - 1 - t];   // :605 reverse
+    }
+    return TA_OK;
+}
+
+/* levenshtein_exp_with_opts(..., trace_on = true), src/levenshtein.rs:1480-1494 */
+int ta_levenshtein_exp_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                             const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits) {
+    uint32_t k = 30;
+    for (int round = 0; round < 40; round++) {
+        int rc = ta_levenshtein_trace(a, a_len, b, b_len, k, costs, out, edits, n_edits);
+        if (rc != TA_OK || *out != TA_NONE) return rc;
+        k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;
+    }
+    return TA_OK;
 }
 
 int ta_levenshtein_simd_k(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k, uint32_t *out) {
