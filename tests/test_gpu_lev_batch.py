@@ -182,3 +182,13 @@ def test_transposition_forms(monkeypatch):
             assert np.array_equal(gpu_k(a, b, k, costs), want), (costs, k)
             monkeypatch.setenv("TA_FORCE_TRANS_SELECT", "1")
             assert np.array_equal(gpu_k(a, b, k, costs), want), (costs, k)
+
+
+def test_str_front_end_and_aliases():
+    import triple_accel_amd as T
+    assert T.levenshtein_simd_k_str("abc", "ab", 1) == 1            # src/levenshtein.rs:637-639 doc-test
+    assert T.levenshtein_simd_k_str("héllo wörld", "hello world", 3) == 2
+    assert T.levenshtein_simd_k_str("日本語テキスト", "日本語テスト", 1) is None
+    assert T.levenshtein_simd_k_str("日本語テキスト", "日本語テスト", 2) == 2
+    assert T.levenshtein_simd_k_str("".join(chr(0x100 + i) for i in range(300)), "x", 2) is None
+    assert T.hamming_words_64(b"abc", b"abd") == T.hamming_simd_movemask(b"abc", b"abd") == 1

@@ -214,3 +214,56 @@ def device_count():
 
 def version():
     return _n.lib().ta_version().decode()
+
+
+# ---------------------------------------------------------------- host-only front ends and same-result variants
+def levenshtein_simd_k_str(a: str, b: str, k):
+    """src/levenshtein.rs:641-651: UTF-8 front end.  ASCII goes through as bytes; otherwise every distinct char is
+    remapped to one byte (`translate_str`, :609-624) -- None if the two strings use more than 256 distinct chars."""
+    if a.isascii() and b.isascii():
+        return levenshtein_simd_k(a.encode("ascii"), b.encode("ascii"), k)
+    table = {}
+
+    def translate(s):
+        out = bytearray()
+        for ch in s:
+            if ch not in table:
+                if len(table) >= 256:
+                    return None
+                table[ch] = len(table)
+            out.append(table[ch])
+        return bytes(out)
+
+    ta = translate(a)
+    if ta is None:
+        return None
+    tb = translate(b)
+    if tb is None:
+        return None
+    return levenshtein_simd_k(ta, tb, k)
+
+
+def alloc_str(length):
+    """src/lib.rs:197-205 (16-byte aligned/padded buffer in the reference; alignment is irrelevant here)."""
+    return bytearray(length)
+
+
+def fill_str(dest, src):
+    """src/lib.rs:229-235"""
+    if len(dest) < len(src):
+        raise PanicError("assertion failed: dest.len() >= src.len()")
+    dest[: len(src)] = src
+
+
+# The reference's other Hamming routines (src/hamming.rs:176-367) are CPU tricks with the same result contract as
+# `hamming`; on the GPU they are the same kernel.
+hamming_simd_parallel = hamming
+hamming_simd_movemask = hamming
+hamming_words_64 = hamming
+hamming_words_128 = hamming
+
+
+def rdamerau_simd_k(a, b, k):
+    """convenience: levenshtein_simd_k_with_opts(a, b, k, false, RDAMERAU_COSTS) -> Option<u32>"""
+    r = levenshtein_simd_k_with_opts(a, b, k, False, RDAMERAU_COSTS)
+    return None if r is None else r[0]
