@@ -188,7 +188,40 @@ def test_str_front_end_and_aliases():
     import triple_accel_amd as T
     assert T.levenshtein_simd_k_str("abc", "ab", 1) == 1            # src/levenshtein.rs:637-639 doc-test
     assert T.levenshtein_simd_k_str("héllo wörld", "hello world", 3) == 2
-    assert T.levenshtein_simd_k_str("日本語テキスト", "日本語テスト", 1) is None
-    assert T.levenshtein_simd_k_str("日本語テキスト", "日本語テスト", 2) == 2
+    assert T.levenshtein_simd_k_str("日本語テキスト", "日本語テスト", 1) == 1
+    assert T.levenshtein_simd_k_str("日本語テキスト", "英語のテスト", 2) is None
+    assert T.levenshtein_simd_k_str("日本語テキスト", "英語のテスト", 9) == 4
     assert T.levenshtein_simd_k_str("".join(chr(0x100 + i) for i in range(300)), "x", 2) is None
     assert T.hamming_words_64(b"abc", b"abd") == T.hamming_simd_movemask(b"abc", b"abd") == 1
+
+
+def test_csr_without_max_len_hint_and_unaligned_views():
+    """CSR batches whose longest string the library has to measure itself; blobs that start at odd addresses."""
+    import torch
+    from triple_accel_amd import batch as B
+    a, b = ragged_pairs(21, 2000, 120, 9, False)
+    sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+    sa.max_len = 0; sb.max_len = 0
+    got = B.levenshtein_k_batch(sa, sb, 12).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, oracle_k(a, b, 12, (1, 1, 0, None)))
+    # same data shifted by 3 bytes inside a bigger allocation (interior pointer, nothing 16-byte aligned)
+    big_a = torch.zeros(sa.blob.numel() + 64, dtype=torch.uint8, device="cuda"); big_a[3:3 + sa.blob.numel()] = sa.blob
+    big_b = torch.zeros(sb.blob.numel() + 64, dtype=torch.uint8, device="cuda"); big_b[5:5 + sb.blob.numel()] = sb.blob
+    va = B.Strings(big_a[3:], sa.off, max_len=120); vb = B.Strings(big_b[5:], sb.off, max_len=120)
+    got = B.levenshtein_k_batch(va, vb, 12).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, oracle_k(a, b, 12, (1, 1, 0, None)))
+
+
+def test_u32_width_class_long_strings():
+    """max_k > 65534 selects the reference's 32-bit cell class (src/levenshtein.rs:789); distances above 65535 must
+    come out exact (wide kernel, 33 row stripes)."""
+    import triple_accel_amd as T
+    g = Dg.rng(44)
+    x = Dg.rand_str(g, 33500)
+    y = Dg.rand_str(g, 33400)
+    costs = (3, 2, 1, None)
+    assert T.levenshtein_select(len(x), len(y), 0xFFFFFFFF, costs)[2] == 32
+    r = T.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, False, T.EditCosts(*costs))
+    want = O.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, False, costs)
+    assert r[0] == want[0] and want[0] > 65535
+    assert T.last_launch_info()["cell_bits"] == 32
