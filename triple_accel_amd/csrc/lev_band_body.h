@@ -67,6 +67,8 @@ struct LevBand {
         U32 PV[D];    // dp value one cell earlier on the diagonal = dp(i-2,j-2) for the next update (TRANS)
         U32 AW[NW];   // byte c+1 = a[i-1] for this lane's cell c (reversed window), byte 0 = intake
         U32 BW[NW];   // byte c+1 = b[j-1] for cell c, byte 0 = b[j-2] of cell 0, byte Dh+1 = intake
+        U32 AWp[NW];  // TRANS: the a-window before its last advance = AW moved one cell down (a[i-2] under a[i-1])
+        U32 BWp[NW];  // TRANS: the b-window before its last advance = BW moved one cell up   (b[j-2] under b[j-1])
     };
 
     // One anti-diagonal step for the cells q = 2c + PAR of every lane.
@@ -86,9 +88,8 @@ struct LevBand {
             // a[i-1]==b[j-2] && a[i-2]==b[j-1]  (src/levenshtein.rs:517-521) as one zero byte per cell
 #pragma unroll
             for (int w = 0; w < NW; w++) {
-                U32 b_up = W::template alignbyte<3>(st.BW[w], w ? st.BW[w - 1] : W::splat(0));          // byte c+1 <- b byte c
-                U32 a_dn = W::template alignbyte<1>(w + 1 < NW ? st.AW[w + 1] : W::splat(0), st.AW[w]); // byte c+1 <- a byte c+2
-                Z[w] = (st.AW[w] ^ b_up) | (a_dn ^ st.BW[w]);
+                // b[j-2] and a[i-2] are exactly what the windows held before their last advance: no re-alignment needed
+                Z[w] = (st.AW[w] ^ st.BWp[w]) | (st.AWp[w] ^ st.BW[w]);
                 if (TRANS == 1) {   // 1 per cell whose transposition test FAILS (non-zero byte)
                     U32 t = (Z[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
                     Z[w] = W::opaque((t | Z[w]) & 0x80808080u) >> 7;
@@ -162,6 +163,10 @@ struct LevBand {
     // a-window: every char moves one cell up (new row enters at cell 0) -- src/levenshtein.rs:1027-1031
     static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in, Bool is_g0) {
         constexpr int sb = Dh;   // byte Dh = cell Dh-1 = the char the next lane needs
+        if (TRANS) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) st.AWp[w] = st.AW[w];
+        }
         U32 t = st.AW[sb >> 2] >> (8 * (sb & 3));
         t = W::from_lower0(t);
         t = W::sel(is_g0, a_in, t);
@@ -172,6 +177,10 @@ struct LevBand {
     }
     // b-window: every char moves one cell down (new column enters at cell Dh-1) -- :1033-1037
     static TA_HD inline __attribute__((always_inline)) void advance_b(State &st, U32 b_in, Bool is_gl) {
+        if (TRANS) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) st.BWp[w] = st.BW[w];
+        }
         U32 t = st.BW[0] >> 8;   // byte 1 = cell 0
         t = W::from_upper0(t);
         t = W::sel(is_gl, b_in, t);
@@ -245,7 +254,7 @@ struct LevBand {
             if (TRANS) st.PV[q] = INF;
         }
 #pragma unroll
-        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(0); st.BW[w] = W::splat(0); }
+        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(0); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(0); st.BWp[w] = W::splat(0); }
         {   // seed dp(0,0) = 0 on diagonal p = o  (:450-452 row 0 then grows through the a_gap chain)
             const uint32_t gs = P.o / D, qs = P.o % D;
             const Bool seed_lane = (g == gs);
