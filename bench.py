@@ -79,13 +79,13 @@ def main():
             cells_unit = L
             run = lambda: B.hamming_batch(sa, sb, out=out)
             oracle = lambda lo, hi, th: O.hamming_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), threads=th)
-            desc, unit_name, dtype = "hamming() on 10K random 1KiB pairs (GPU batch kernel)", "byte pairs", "u8 compare, u32 count"
+            desc, unit_name, dtype = "hamming() on 10K random 1KiB pairs (GPU batch kernel)", "byte pairs", "u8"
             cpu_sample = n
         elif wl == "cfg3":
             cells_unit = L * L                                     # the answer's work: the full matrix
             run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
             oracle = lambda lo, hi, th: O.levenshtein_exp_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), costs, threads=th)
-            desc, unit_name, dtype = "levenshtein_exp full distance on 100K random 4KiB pairs", "pairs", "u8/u16 cell classes in u32 lanes"
+            desc, unit_name, dtype = "levenshtein_exp full distance on 100K random 4KiB pairs", "pairs", "u32"
             cpu_sample = max(cores, 64)
         else:
             cells_unit = O.band_cells(L, L, k, costs)              # cells the scalar banded path visits
@@ -93,7 +93,7 @@ def main():
             oracle = lambda lo, hi, th: O.levenshtein_k_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), k, costs, threads=th)
             desc = {"cfg2": "levenshtein_simd_k k=32, 1M random 256B pairs, u8 cells",
                     "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)"}[wl]
-            unit_name, dtype = "pairs", "u8 cells (reference width rule) computed in u32 lanes"
+            unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select), arithmetic in 32-bit VGPR lanes
             cpu_sample = min(n, 20000 * max(1, cores // 2))
         units = n
 
@@ -122,7 +122,7 @@ def main():
             holder["hits"] = hits
             holder["best"] = TD.fold_best(hits, k, True)                           # the sequential Best pass (host)
         desc = "levenshtein_search 32B needle over a %d MiB random haystack shard per GPU, k=16, Best" % mib
-        unit_name, dtype = "haystack bytes", "u8 cost+length cells computed in u32 lanes"
+        unit_name, dtype = "haystack bytes", "u16+u16 (cost|length packed in a u32 lane)"
         cpu_sample = 8 << 20
 
         def oracle_search(lo, hi, th):

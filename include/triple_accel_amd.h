@@ -189,7 +189,8 @@ int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_
  * SearchType::All; the order-dependent Best fold is a sequential host pass, ta_search_fold_best).
  * `base` is added to start/end (global offset of this shard inside a larger haystack);
  * `emit_from` suppresses hits whose end <= emit_from (left-halo positions).
- * hits_dev holds up to `cap` records sorted by end; *count_dev receives the total found
+ * hits_dev receives up to `cap` records in NO particular order (atomic cursor): sort them by `end` -- unique per
+ * hit -- before ta_search_fold_best; *count_host receives the total found
  * (may exceed cap => TA_ERR_CAPACITY after sync).  Synchronises the stream. */
 int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
                               const uint8_t *haystack_dev, size_t haystack_len,

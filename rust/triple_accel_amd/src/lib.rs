@@ -1,0 +1,185 @@
+//! `triple_accel` public API (v0.4.0 surface: crate root re-exports + the `hamming` and `levenshtein` modules)
+//! backed by the MI355X engine through its C ABI (`include/triple_accel_amd.h`).
+//!
+//! Callers keep `use triple_accel::*;` unchanged.  Differences, all documented in INTEGRATION.md:
+//! * search functions return an eager iterator (the GPU scans the whole haystack at once);
+//! * there is no CPU fallback below this layer: without a usable GPU the calls panic with the HIP status;
+//! * tracebacks of bands wider than 4,224 diagonals are not on the GPU path (`levenshtein_*_with_opts` panics there).
+use std::os::raw::{c_int, c_void};
+
+#[derive(Debug, PartialEq)]
+pub struct Match { pub start: usize, pub end: usize, pub k: u32 }
+#[derive(Debug, PartialEq, Copy, Clone)]
+pub enum EditType { Match, Mismatch, AGap, BGap, Transpose }
+#[derive(Debug, PartialEq)]
+pub struct Edit { pub edit: EditType, pub count: usize }
+#[derive(Debug, PartialEq, Copy, Clone)]
+pub enum SearchType { All, Best }
+
+mod ffi {
+    use super::*;
+    #[repr(C)] #[derive(Copy, Clone)]
+    pub struct TaEditCosts { pub mismatch_cost: u8, pub gap_cost: u8, pub start_gap_cost: u8, pub has_transpose: u8, pub transpose_cost: u8 }
+    #[repr(C)] pub struct TaMatch { pub start: u64, pub end: u64, pub k: u32, pub pad_: u32 }
+    #[repr(C)] pub struct TaEdit { pub edit: u32, pub pad_: u32, pub count: u64 }
+    pub const TA_NONE: u32 = 0xFFFF_FFFF;
+    #[link(name = "triple_accel_amd")]
+    extern "C" {
+        pub fn ta_edit_costs_new(mismatch: u8, gap: u8, start_gap: u8, has_transpose: c_int, transpose: u8, out: *mut TaEditCosts) -> c_int;
+        pub fn ta_edit_costs_check_search(c: *const TaEditCosts) -> c_int;
+        pub fn ta_hamming(a: *const u8, a_len: usize, b: *const u8, b_len: usize, out: *mut u32) -> c_int;
+        pub fn ta_levenshtein_simd_k_with_opts(a: *const u8, a_len: usize, b: *const u8, b_len: usize, k: u32, trace_on: c_int,
+                                               costs: *const TaEditCosts, out: *mut u32) -> c_int;
+        pub fn ta_levenshtein_trace(a: *const u8, a_len: usize, b: *const u8, b_len: usize, k: u32, costs: *const TaEditCosts,
+                                    out: *mut u32, edits: *mut *mut TaEdit, n_edits: *mut usize) -> c_int;
+        pub fn ta_levenshtein_exp_with_opts(a: *const u8, a_len: usize, b: *const u8, b_len: usize, trace_on: c_int,
+                                            costs: *const TaEditCosts, out: *mut u32) -> c_int;
+        pub fn ta_levenshtein_exp_trace(a: *const u8, a_len: usize, b: *const u8, b_len: usize, costs: *const TaEditCosts,
+                                        out: *mut u32, edits: *mut *mut TaEdit, n_edits: *mut usize) -> c_int;
+        pub fn ta_levenshtein_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
+                                                    search_type: c_int, costs: *const TaEditCosts, anchored: c_int,
+                                                    out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
+        pub fn ta_hamming_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
+                                                search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
+        pub fn ta_free(p: *mut c_void);
+    }
+    /// status codes -> the reference's panics (src/hamming.rs:318, src/lib.rs:240, src/levenshtein.rs:44-52,69)
+    pub fn check(rc: c_int) {
+        match rc {
+            0 => (),
+            1 => panic!("assertion failed: a.len() == b.len()"),
+            2 => panic!("No zero/null bytes allowed in the string!"),
+            3 => panic!("invalid EditCosts"),
+            _ => panic!("triple_accel_amd: status {} (no CPU fallback below the C ABI)", rc),
+        }
+    }
+    pub unsafe fn take_matches(p: *mut TaMatch, n: usize) -> Vec<Match> {
+        let v = (0..n).map(|i| { let m = &*p.add(i); Match { start: m.start as usize, end: m.end as usize, k: m.k } }).collect();
+        ta_free(p as *mut c_void);
+        v
+    }
+    pub unsafe fn take_edits(p: *mut TaEdit, n: usize) -> Vec<Edit> {
+        const T: [EditType; 5] = [EditType::Match, EditType::Mismatch, EditType::AGap, EditType::BGap, EditType::Transpose];
+        let v = (0..n).map(|i| { let e = &*p.add(i); Edit { edit: T[e.edit as usize], count: e.count as usize } }).collect();
+        ta_free(p as *mut c_void);
+        v
+    }
+}
+
+pub mod hamming {
+    use super::ffi::*;
+    use super::*;
+
+    /// src/hamming.rs:390
+    pub fn hamming(a: &[u8], b: &[u8]) -> u32 {
+        let mut out = 0u32;
+        check(unsafe { ta_hamming(a.as_ptr(), a.len(), b.as_ptr(), b.len(), &mut out) });
+        out
+    }
+    /// same result contract as `hamming` (src/hamming.rs:317, :354): one GPU kernel serves them all
+    pub fn hamming_simd_parallel(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+    pub fn hamming_simd_movemask(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+
+    /// src/hamming.rs:454
+    pub fn hamming_search_simd_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType)
+        -> Box<dyn Iterator<Item = Match> + 'a> {
+        let (mut p, mut n) = (std::ptr::null_mut::<TaMatch>(), 0usize);
+        check(unsafe { ta_hamming_search_simd_with_opts(needle.as_ptr(), needle.len(), haystack.as_ptr(), haystack.len(), k,
+                                                        (search_type == SearchType::Best) as c_int, &mut p, &mut n) });
+        Box::new(unsafe { take_matches(p, n) }.into_iter())
+    }
+    /// src/hamming.rs:422
+    pub fn hamming_search_simd<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        hamming_search_simd_with_opts(needle, haystack, ((needle.len() as u32) >> 1) + ((needle.len() as u32) & 1), SearchType::Best)
+    }
+    /// src/hamming.rs:588
+    pub fn hamming_search<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        hamming_search_simd(needle, haystack)
+    }
+}
+
+pub mod levenshtein {
+    use super::ffi::*;
+    use super::*;
+
+    /// src/levenshtein.rs:20-26
+    #[derive(Copy, Clone, Debug)]
+    pub struct EditCosts { mismatch_cost: u8, gap_cost: u8, start_gap_cost: u8, transpose_cost: Option<u8> }
+
+    impl EditCosts {
+        /// src/levenshtein.rs:38-60 (the asserts run inside the library: TA_ERR_BAD_COSTS -> panic)
+        pub fn new(mismatch_cost: u8, gap_cost: u8, start_gap_cost: u8, transpose_cost: Option<u8>) -> Self {
+            let mut raw = TaEditCosts { mismatch_cost: 0, gap_cost: 0, start_gap_cost: 0, has_transpose: 0, transpose_cost: 0 };
+            check(unsafe { ta_edit_costs_new(mismatch_cost, gap_cost, start_gap_cost, transpose_cost.is_some() as c_int,
+                                             transpose_cost.unwrap_or(0), &mut raw) });
+            Self { mismatch_cost, gap_cost, start_gap_cost, transpose_cost }
+        }
+        pub(crate) fn raw(&self) -> TaEditCosts {
+            TaEditCosts { mismatch_cost: self.mismatch_cost, gap_cost: self.gap_cost, start_gap_cost: self.start_gap_cost,
+                          has_transpose: self.transpose_cost.is_some() as u8, transpose_cost: self.transpose_cost.unwrap_or(0) }
+        }
+    }
+    /// src/levenshtein.rs:76-89
+    pub const LEVENSHTEIN_COSTS: EditCosts = EditCosts { mismatch_cost: 1, gap_cost: 1, start_gap_cost: 0, transpose_cost: None };
+    pub const RDAMERAU_COSTS: EditCosts = EditCosts { mismatch_cost: 1, gap_cost: 1, start_gap_cost: 0, transpose_cost: Some(1) };
+
+    /// src/levenshtein.rs:714
+    pub fn levenshtein_simd_k_with_opts(a: &[u8], b: &[u8], k: u32, trace_on: bool, costs: EditCosts)
+        -> Option<(u32, Option<Vec<Edit>>)> {
+        let (mut out, c) = (0u32, costs.raw());
+        if trace_on {
+            let (mut p, mut n) = (std::ptr::null_mut::<TaEdit>(), 0usize);
+            check(unsafe { ta_levenshtein_trace(a.as_ptr(), a.len(), b.as_ptr(), b.len(), k, &c, &mut out, &mut p, &mut n) });
+            if out == TA_NONE { return None; }
+            return Some((out, Some(unsafe { take_edits(p, n) })));
+        }
+        check(unsafe { ta_levenshtein_simd_k_with_opts(a.as_ptr(), a.len(), b.as_ptr(), b.len(), k, 0, &c, &mut out) });
+        if out == TA_NONE { None } else { Some((out, None)) }
+    }
+    /// src/levenshtein.rs:677
+    pub fn levenshtein_simd_k(a: &[u8], b: &[u8], k: u32) -> Option<u32> {
+        levenshtein_simd_k_with_opts(a, b, k, false, LEVENSHTEIN_COSTS).map(|r| r.0)
+    }
+    /// src/levenshtein.rs:1397
+    pub fn levenshtein(a: &[u8], b: &[u8]) -> u32 { levenshtein_simd_k(a, b, u32::MAX).unwrap() }
+    /// src/levenshtein.rs:1419
+    pub fn rdamerau(a: &[u8], b: &[u8]) -> u32 { levenshtein_simd_k_with_opts(a, b, u32::MAX, false, RDAMERAU_COSTS).unwrap().0 }
+    /// src/levenshtein.rs:1480
+    pub fn levenshtein_exp_with_opts(a: &[u8], b: &[u8], trace_on: bool, costs: EditCosts) -> (u32, Option<Vec<Edit>>) {
+        let (mut out, c) = (0u32, costs.raw());
+        if trace_on {
+            let (mut p, mut n) = (std::ptr::null_mut::<TaEdit>(), 0usize);
+            check(unsafe { ta_levenshtein_exp_trace(a.as_ptr(), a.len(), b.as_ptr(), b.len(), &c, &mut out, &mut p, &mut n) });
+            return (out, Some(unsafe { take_edits(p, n) }));
+        }
+        check(unsafe { ta_levenshtein_exp_with_opts(a.as_ptr(), a.len(), b.as_ptr(), b.len(), 0, &c, &mut out) });
+        (out, None)
+    }
+    /// src/levenshtein.rs:1445
+    pub fn levenshtein_exp(a: &[u8], b: &[u8]) -> u32 { levenshtein_exp_with_opts(a, b, false, LEVENSHTEIN_COSTS).0 }
+    /// src/levenshtein.rs:1516
+    pub fn rdamerau_exp(a: &[u8], b: &[u8]) -> u32 { levenshtein_exp_with_opts(a, b, false, RDAMERAU_COSTS).0 }
+
+    /// src/levenshtein.rs:1911
+    pub fn levenshtein_search_simd_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType,
+                                                  costs: EditCosts, anchored: bool) -> Box<dyn Iterator<Item = Match> + 'a> {
+        let (mut p, mut n, c) = (std::ptr::null_mut::<TaMatch>(), 0usize, costs.raw());
+        check(unsafe { ta_levenshtein_search_simd_with_opts(needle.as_ptr(), needle.len(), haystack.as_ptr(), haystack.len(), k,
+                                                            (search_type == SearchType::Best) as c_int, &c, anchored as c_int,
+                                                            &mut p, &mut n) });
+        Box::new(unsafe { take_matches(p, n) }.into_iter())
+    }
+    /// src/levenshtein.rs:1866
+    pub fn levenshtein_search_simd<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        levenshtein_search_simd_with_opts(needle, haystack, ((needle.len() >> 1) as u32) + ((needle.len() as u32) & 1),
+                                          SearchType::Best, LEVENSHTEIN_COSTS, false)
+    }
+    /// src/levenshtein.rs:2508
+    pub fn levenshtein_search<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        levenshtein_search_simd(needle, haystack)
+    }
+}
+
+// src/lib.rs:126-127
+pub use hamming::{hamming, hamming_search};
+pub use levenshtein::{levenshtein, levenshtein_exp, levenshtein_search, rdamerau, rdamerau_exp};
