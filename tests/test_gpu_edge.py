@@ -1,0 +1,73 @@
+"""-m gpu: edge cases -- empty and tiny inputs, maximum costs, very long strings with a narrow band, big batches."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_k(a_list, b_list, k, costs=(1, 1, 0, None)):
+    from triple_accel_amd import batch as B
+    out = B.levenshtein_k_batch(B.Strings.from_list(a_list), B.Strings.from_list(b_list), k, costs)
+    return out.cpu().numpy().view(np.uint32)
+
+
+def oracle_k(a_list, b_list, k, costs=(1, 1, 0, None)):
+    return O.levenshtein_k_batch(O.csr_from_list(a_list), O.csr_from_list(b_list), k, costs)
+
+
+def test_empty_batch_and_single_pairs():
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    assert gpu_k([], [], 3).size == 0
+    assert T.levenshtein(b"", b"") == 0 and T.levenshtein(b"", b"abc") == 3 and T.levenshtein(b"a", b"") == 1
+    assert T.levenshtein_simd_k(b"", b"abc", 2) is None
+    assert T.hamming(b"", b"") == 0
+    for n in (1, 15, 16, 17, 63, 64, 65):
+        x = bytes(range(1, n + 1)); y = bytes((v + (i % 3 == 0)) & 0xFF or 1 for i, v in enumerate(x))
+        assert T.hamming(x, y) == sum(p != q for p, q in zip(x, y))
+    assert list(T.levenshtein_search(b"abc", b"")) == []
+    assert list(T.levenshtein_search(b"abcdef", b"ab")) == [tuple(m) for m in O.levenshtein_search_naive_with_opts(b"abcdef", b"ab", 3, O.BEST)]
+    assert [tuple(m) for m in T.levenshtein_search(b"a", b"xxaxx")] == O.levenshtein_search_naive_with_opts(b"a", b"xxaxx", 1, O.BEST)
+
+
+def test_k_zero_and_max_costs():
+    g = Dg.rng(1)
+    a = [Dg.rand_str(g, int(g.integers(0, 30))) for _ in range(500)]
+    b = [x if i % 2 else Dg.mutate(g, x, 2) for i, x in enumerate(a)]
+    assert np.array_equal(gpu_k(a, b, 0), oracle_k(a, b, 0))
+    for costs in [(255, 255, 255, None), (255, 255, 0, 255), (1, 255, 255, None), (255, 1, 0, 1)]:
+        assert O.costs_valid(costs)
+        for k in (0, 255, 1000, 70000, 0xFFFFFFFF):
+            assert np.array_equal(gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)), (costs, k)
+
+
+def test_very_long_strings_narrow_band():
+    """200 KB strings, k = 24: thousands of stream chunks per pair, band of 51 diagonals."""
+    g = Dg.rng(2)
+    a, b = [], []
+    for _ in range(6):
+        x = Dg.rand_str(g, 200_000)
+        a.append(x); b.append(Dg.mutate(g, x, 20))
+    a.append(a[0]); b.append(Dg.rand_str(g, 200_010))
+    got, want = gpu_k(a, b, 24), oracle_k(a, b, 24)
+    assert np.array_equal(got, want) and (want[:6] != 0xFFFFFFFF).all() and want[6] == 0xFFFFFFFF
+
+
+def test_big_batch_tiny_strings():
+    """3M pairs of 0..12-byte strings (many waves, ragged, lots of empties)."""
+    g = Dg.rng(3)
+    n = 3_000_000
+    la = g.integers(0, 13, size=n); lb = g.integers(0, 13, size=n)
+    blob_a = g.integers(97, 101, size=int(la.sum()) + 16, dtype=np.uint8)
+    blob_b = g.integers(97, 101, size=int(lb.sum()) + 16, dtype=np.uint8)
+    off_a = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64); off_b = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+    import torch
+    from triple_accel_amd import batch as B
+    sa = B.Strings(torch.from_numpy(blob_a).cuda(), torch.from_numpy(off_a.astype(np.int64)).cuda(), max_len=12)
+    sb = B.Strings(torch.from_numpy(blob_b).cuda(), torch.from_numpy(off_b.astype(np.int64)).cuda(), max_len=12)
+    got = B.levenshtein_k_batch(sa, sb, 5, (1, 1, 0, 1)).cpu().numpy().view(np.uint32)
+    want = O.levenshtein_k_batch((blob_a, off_a), (blob_b, off_b), 5, (1, 1, 0, 1))
+    assert np.array_equal(got, want)
