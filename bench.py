@@ -47,11 +47,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    local = local % torch.cuda.device_count()          # (lets a 1-GPU box dry-run the multi-rank control flow)
     torch.cuda.set_device(local)
     dist = None
+    backend = os.environ.get("TA_BENCH_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; "gloo" only for dry runs
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     wl = args.workload
     seed = 0x7A00 + int(wl[3:]) + 1000 * rank
@@ -158,7 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:
