@@ -134,3 +134,26 @@ def test_big_k_takes_the_unpacked_kernel():
     for k in (40000, 70000):
         want = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, False)
         assert prod_search(needle, hay, k, O.ALL, costs) == want
+
+
+def test_hamming_search_alignment_and_edges():
+    """Every haystack alignment (interior pointers), needle lengths around the 4-byte word size, offsets at both ends."""
+    import torch
+    from triple_accel_amd import batch as B
+    g = Dg.rng(91)
+    base = Dg.rand_str(g, 5000)
+    big = torch.zeros(5000 + 64, dtype=torch.uint8, device="cuda")
+    for shift in range(0, 8):
+        big.zero_()
+        big[shift:shift + 5000] = torch.frombuffer(bytearray(base), dtype=torch.uint8).cuda()
+        view = big[shift:]
+        for n in (1, 2, 3, 4, 5, 7, 8, 9, 31, 33):
+            needle = base[100:100 + n]
+            for hl in (5000, 4999, 4997):
+                want = O.hamming_search_naive_with_opts(needle, base[:hl], n // 3, O.ALL)
+                got = [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, (view, hl), n // 3)]
+                assert got == want, (shift, n, hl)
+    # needle as long as the haystack, and matches at offset 0 and at the last offset
+    hay = b"abcdefghij"
+    assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(hay, B.haystack_tensor(hay), 0)] == [(0, 10, 0)]
+    assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(b"ab", B.haystack_tensor(b"abxxab"), 0)] == [(0, 2, 0), (4, 6, 0)]

@@ -86,31 +86,59 @@ hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hip
     return hipGetLastError();
 }
 
-// hamming_search: one lane per haystack offset, needle (kernarg) compared 4 bytes at a time.
-// Replaces hamming_search_simd_core_* (src/hamming.rs:481-552); contract: mismatches(offset) <= k.
-__global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// hamming_search: one lane per aligned group of 4 consecutive haystack offsets.  The lane loads the aligned dwords
+// covering its 4 windows once (coalesced), re-aligns them per offset with v_alignbyte, and counts non-zero bytes of
+// window ^ needle with the SWAR test + v_bcnt accumulate.  Replaces hamming_search_simd_core_*
+// (src/hamming.rs:481-552); contract: mismatches(offset) <= k for every offset 0..=h-n.
+__global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uint32_t delta) {
+    const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // aligned dword index of the group's first byte
     const uint32_t n = P.needle_len;
-    if (i + n > P.hay_len) return;
-    const uint8_t *h = P.hay + i;
-    uint32_t cnt = 0;
-    uint32_t j = 0;
-    typedef uint32_t u32u __attribute__((aligned(1)));
-    for (; j + 4 <= n; j += 4) {
-        uint32_t x = *(const u32u *)(h + j) ^ *(const u32u *)(P.needle_dev + j);
-        cnt += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+    const uint64_t h = P.hay_len;
+    const uint64_t last = h - n;                                            // last valid offset
+    const uint64_t byte0 = grp * 4;                                         // in the aligned-down address space
+    if (byte0 > last + delta) return;
+    const uint32_t *hw = (const uint32_t *)(P.hay - delta) + grp;
+    const uint32_t nwords = (n + 3) >> 2;
+    const uint32_t tail_mask = (n & 3) ? (0xFFFFFFFFu >> (8 * (4 - (n & 3)))) : 0xFFFFFFFFu;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t lo = hw[0];
+    for (uint32_t w = 0; w < nwords; w++) {
+        const uint32_t hi = hw[w + 1];
+        uint32_t nd;                                                        // needle word w (wave-uniform)
+        {
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            nd = *(const u32u *)(P.needle_dev + 4 * w);                     // needle_dev carries 16 bytes of slack
+        }
+        const uint32_t m = (w + 1 == nwords) ? tail_mask : 0xFFFFFFFFu;
+        auto nz = [&](uint32_t win) -> uint32_t {
+            uint32_t x = (win ^ nd) & m;
+            return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+        };
+        c0 += __builtin_popcount(nz(lo));
+        c1 += __builtin_popcount(nz(__builtin_amdgcn_alignbyte(hi, lo, 1)));
+        c2 += __builtin_popcount(nz(__builtin_amdgcn_alignbyte(hi, lo, 2)));
+        c3 += __builtin_popcount(nz(__builtin_amdgcn_alignbyte(hi, lo, 3)));
+        lo = hi;
     }
-    for (; j < n; j++) cnt += (h[j] != P.needle_dev[j]);
-    if (cnt <= P.k) {
-        unsigned long long idx = atomicAdd(P.count, 1ull);
-        if (idx < P.cap) P.hits[idx] = ta_match{P.base + i, P.base + i + n, cnt, 0u};
+    const uint32_t cnt[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint64_t b = byte0 + r;
+        if (b < delta) continue;
+        const uint64_t pos = b - delta;
+        if (pos > last) continue;
+        if (cnt[r] <= P.k) {
+            unsigned long long idx = atomicAdd(P.count, 1ull);
+            if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt[r], 0u};
+        }
     }
 }
 
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s) {
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
-    const uint64_t positions = P.hay_len - P.needle_len + 1;
-    hipLaunchKernelGGL(hamming_search_kernel, dim3((uint32_t)((positions + 255) / 256)), dim3(256), 0, s, P);
+    const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 3u);
+    const uint64_t groups = (P.hay_len - P.needle_len + delta) / 4 + 1;
+    hipLaunchKernelGGL(hamming_search_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, P, delta);
     return hipGetLastError();
 }
 
