@@ -29,7 +29,7 @@ extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const 
                             uint32_t n, uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, int has_t, uint32_t tc,
                             uint64_t max_len, int force_D, int force_L, int force_affine, uint32_t *out,
                             uint32_t *plan_out /* D, L, PW, u, o */) {
-    LevPlan pl = lev_make_plan(k, gc, sg, max_len, force_D, force_L);
+    LevPlan pl = lev_make_plan(k, mc, gc, sg, max_len, force_D, force_L);
     if (!pl.ok) return 1;
     LevParams P;
     P.a = StrView{a_blob, a_off, 0, 0};

@@ -123,3 +123,38 @@ def test_emu_transposition_forms_agree():
             want = oracle(a, b, k, costs)
             assert E.lev_band(a, b, k, costs)[0] == want, (costs, k)
             assert E.lev_band(a, b, k, costs, force_trans_select=True)[0] == want, (costs, k)
+
+
+def _edge_pairs(seed, n, base_len, u):
+    """Pairs whose optimal alignment hugs the edge of the narrow band: a block deleted near the start and
+    re-inserted near the end (and the mirror image), on top of a length difference, so the path first strays
+    t diagonals to one side and only returns at the very end."""
+    g = Dg.rng(seed)
+    a, b = [], []
+    for i in range(n):
+        x = bytearray(Dg.rand_str(g, base_len))
+        delta = int(g.integers(0, u + 1))
+        t = int(g.integers(0, (u - delta) // 2 + 2))           # sometimes one more than the band allows -> None
+        y = bytearray(x)
+        blk = bytes(Dg.rand_str(g, t))
+        y = y[t:] if i & 1 else bytearray(blk) + y              # stray t diagonals right at the start ...
+        y = y + bytearray(blk) if i & 1 else y[:len(y) - t]     # ... and come back at the very end
+        y = y + bytearray(Dg.rand_str(g, delta))                # plus the length difference
+        pair = (bytes(x), bytes(y))
+        if i & 2:
+            pair = pair[::-1]
+        a.append(pair[0]); b.append(pair[1])
+    return a, b
+
+
+@pytest.mark.parametrize("costs", [(1, 1, 0, None), (9, 1, 0, None), (3, 2, 0, 2), (2, 1, 3, None), (255, 1, 0, None)])
+def test_emu_narrow_band_edges(costs):
+    """The kernel's band is [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|)/2 -- about half of the
+    reference's [-unit_k, unit_k] (lev_plan.h).  Alignments built to run along its edges must still come out
+    exactly as the scalar path reports them, for every k around the true distance."""
+    for u in (6, 13, 32):
+        a, b = _edge_pairs(0xED6E + u, 60, 70, u)
+        k_unit = costs[1] * u + costs[2]
+        for k in (k_unit - 1, k_unit, k_unit + costs[1], 2 * k_unit + 1, 0xFFFFFFFF):
+            got, plan = E.lev_band(a, b, max(k, 0), costs)
+            assert got == oracle(a, b, max(k, 0), costs), (u, k, costs, plan)

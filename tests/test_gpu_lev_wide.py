@@ -62,12 +62,12 @@ def test_unforced_dispatch_to_wide():
     """levenshtein() / rdamerau() on strings too long for the register band pick the wide kernel by themselves."""
     import triple_accel_amd as T
     g = Dg.rng(3)
-    x = Dg.rand_str(g, 3000)
+    x = Dg.rand_str(g, 6000)                     # unit_k = 6000 -> 6002 diagonal slots > 64 lanes x 66
     y = Dg.mutate(g, x, 100, True)
     assert T.levenshtein(x, y) == O.levenshtein(x, y)
     assert T.last_launch_info()["kernel"] == 2
     assert T.rdamerau(x, y) == O.rdamerau(x, y)
-    z = Dg.rand_str(g, 2800)
+    z = Dg.rand_str(g, 5600)
     assert T.levenshtein(x, z) == O.levenshtein(x, z)
     assert T.levenshtein_exp(x, z) == O.levenshtein_exp(x, z)
 

@@ -15,26 +15,36 @@ def plan_for(k, max_len, costs=(1, 1, 0, None), force_D=0, force_L=0):
     return pl
 
 
+def batch_unit_k(k, costs, max_len):
+    """lev_plan.h lev_batch_unit_k: the dispatcher's max_k clamp (src/levenshtein.rs:734-757) taken over every pair
+    with both lengths <= max_len, then unit_k = (K - sg) / gc, capped by the 2 max_len diagonals a matrix has."""
+    mc, gc, sg, _ = costs
+    K = min(k, 2 * max_len * gc + 2 * sg, max_len * max(mc, gc) + sg)
+    return min(max(0, K - sg) // gc, 2 * max_len)
+
+
 def test_plan_invariants():
     for max_len in (1, 5, 64, 256, 1000):
         for k in (0, 1, 8, 31, 32, 33, 100, 254, 255, 1000, 0xFFFFFFFF):
             for costs in [(1, 1, 0, None), (2, 3, 1, None), (1, 255, 0, None), (5, 1, 4, 1)]:
                 pl = plan_for(k, max_len, costs)
-                mc, gc, sg, tc = costs
-                u = min(max(0, min(k, 0xFFFFFFFF) - sg) // gc, max_len)
+                u = batch_unit_k(k, costs, max_len)
                 if pl is None:
-                    assert (u | 1) + u + 1 > 64 * 66
+                    assert u + 2 > 64 * 66
                     continue
-                assert pl["u"] == u and pl["o"] == (u | 1)
-                need = pl["o"] + pl["u"] + 1
-                assert pl["D"] % 2 == 0 and pl["D"] * pl["L"] >= need            # every band diagonal has a register
+                assert pl["u"] == u and pl["o"] == ((u >> 1) | 1)
+                # every pair's band fits: the widest one holds u + 1 diagonals plus one slot of parity padding
+                assert pl["D"] % 2 == 0 and pl["D"] * pl["L"] >= u + 2
                 assert 1 <= pl["L"] <= 64 and pl["PW"] == 64 // pl["L"] and pl["PW"] * pl["L"] <= 64
+                # the batch bound never falls below a pair's own unit_k (ta_levenshtein_select) for |delta| <= u
+                for la, lb in ((max_len, max_len), (max_len, max_len // 2), (1, max_len)):
+                    assert min(O.levenshtein_select(la, lb, k, costs)[1], 2 * max_len) <= max(u, 0) or abs(la - lb) > u
 
 
-def test_plan_matches_reference_band_on_baseline_configs():
-    # cfg2: unit_k = 32 -> 66 diagonals; cfg4: unit_k = 8 -> 18 diagonals
+def test_plan_band_is_half_of_the_reference_band_on_baseline_configs():
+    # cfg2: unit_k = 32: reference band 65 diagonals, ours 33 (+1 parity slot); cfg4: unit_k = 8: 17 vs 9 (+1)
     assert O.levenshtein_select(256, 256, 32)[1] == 32
     pl = plan_for(32, 256)
-    assert pl["u"] == 32 and pl["o"] == 33 and pl["D"] * pl["L"] >= 66
+    assert pl["u"] == 32 and pl["o"] == 17 and pl["D"] * pl["L"] >= 34 and pl["D"] * pl["L"] < 66
     pl = plan_for(8, 128, (1, 1, 0, 1))
-    assert pl["u"] == 8 and pl["o"] == 9 and pl["D"] * pl["L"] >= 18
+    assert pl["u"] == 8 and pl["o"] == 5 and pl["D"] * pl["L"] >= 10 and pl["D"] * pl["L"] < 18

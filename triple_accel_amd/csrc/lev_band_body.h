@@ -194,7 +194,7 @@ struct LevBand {
     // Stream chunk kc (iterations [kc*CH, kc*CH+CH)) of every pair's two strings into the LDS ring.  The 8 pieces
     // (2 strings x 4 x 16 B) of a pair are fetched by the pair's own L lanes, so no pointer ever crosses lanes.
     static TA_HD inline void load_chunk(uint8_t *lds, const LevParams &P, uint32_t kc, U32 grp, U32 g, Bool active,
-                                  Ptr aptr, U32 alen, Ptr bptr, U32 blen, uint32_t ea, uint32_t eb) {
+                                  Ptr aptr, U32 alen, Ptr bptr, U32 blen, U32 ea, U32 eb) {
         constexpr uint32_t PIECES = 2u * (LEV_CH / 16);
         for (uint32_t base = 0; base < PIECES; base += P.L) {
             U32 pc = g + base;                   // piece index within the pair: [0,4) = a, [4,8) = b
@@ -202,7 +202,7 @@ struct LevBand {
             Bool isb = pc >= (uint32_t)(LEV_CH / 16);
             U32 piece = pc & 3u;
             U32 len = W::sel(isb, blen, alen);
-            U32 e = W::sel(isb, W::splat(eb), W::splat(ea));
+            U32 e = W::sel(isb, eb, ea);
             U32 y0 = piece * 16u + kc * LEV_CH;  // ring position (absolute)
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
@@ -229,20 +229,23 @@ struct LevBand {
         W::load_str(P.a, pair, valid, aptr, alen);
         W::load_str(P.b, pair, valid, bptr, blen);
 
-        // answer cell (alen, blen): step s_ans, diagonal p_ans = o + blen - alen
+        // the pair's band (lev_plan.h): diagonals [min(0,delta) - t, max(0,delta) + t], slot p = d + o, o odd
         const U32 s_ans = alen + blen;
         const U32 diff = W::sel(blen >= alen, blen - alen, alen - blen);
         const Bool inband = diff <= P.u;                       // else None (:426-428, :860-862)
-        const U32 p_ans = W::sel(inband, (blen + P.o) - alen, W::splat(0));
+        const U32 tband = W::sel(inband, (W::splat(P.u) - diff) >> 1, W::splat(0));
+        const U32 o = W::sel(inband, (tband + W::sel(blen >= alen, W::splat(0), diff)) | 1u, W::splat(1));
+        // answer cell (alen, blen): step s_ans, slot p_ans = o + blen - alen
+        const U32 p_ans = W::sel(inband, (blen + o) - alen, W::splat(0));
         const U32 g_ans = W::udiv(p_ans, (uint32_t)D);
         const U32 q_ans = p_ans - g_ans * (uint32_t)D;
 
         const uint32_t Tw = P.Tw;                              // warm-up iterations: windows fill up (>= L*Dh)
-        const uint32_t h = (P.o + 1) >> 1;
+        const U32 h = (o + 1u) >> 1;                           // <= (u + 2) / 2 <= L * Dh <= Tw
         // iteration t' = tau + Tw feeds a[t' - ca] into lane 0 and b[t' - cb] into lane L-1
-        const uint32_t ca = Tw - h, cb = Tw - L * Dh + h;
-        const uint32_t da = (16u - (ca & 15u)) & 15u, db = (16u - (cb & 15u)) & 15u;
-        const uint32_t ea = ca + da, eb = cb + db;             // multiples of 16: pieces never straddle index 0
+        const U32 ca = W::splat(Tw) - h, cb = W::splat(Tw - L * Dh) + h;
+        const U32 da = (W::splat(16u) - (ca & 15u)) & 15u, db = (W::splat(16u) - (cb & 15u)) & 15u;
+        const U32 ea = ca + da, eb = cb + db;                  // multiples of 16: pieces never straddle index 0
         const uint32_t iters = Tw + W::wave_max((s_ans + 1u) >> 1);
         const U32 t_cap = W::sel(s_ans == 0u, W::splat(0xFFFFFFFFu), ((s_ans - 1u) >> 1) + Tw);
 
@@ -256,11 +259,11 @@ struct LevBand {
 #pragma unroll
         for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(0); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(0); st.BWp[w] = W::splat(0); }
         {   // seed dp(0,0) = 0 on diagonal p = o  (:450-452 row 0 then grows through the a_gap chain)
-            const uint32_t gs = P.o / D, qs = P.o % D;
+            const U32 gs = W::udiv(o, (uint32_t)D), qs = o - gs * (uint32_t)D;
             const Bool seed_lane = (g == gs);
 #pragma unroll
             for (int q = 1; q < D; q += 2) {
-                Bool hit = seed_lane & (W::splat(qs) == (uint32_t)q);
+                Bool hit = seed_lane & (qs == (uint32_t)q);
                 st.reg[q] = W::sel(hit, W::splat(0), st.reg[q]);
                 st.HA[q] = W::sel(hit, W::splat(AFFINE ? P.sg + P.gc : 2u * P.gc), st.HA[q]);
                 if (AFFINE) st.HB[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HB[q]);
@@ -271,7 +274,8 @@ struct LevBand {
         const U32 a_slot = (grp * 2u) * LEV_SLOT, b_slot = (grp * 2u + 1u) * LEV_SLOT;
 
         // iterations before min(ca, cb) would only shift zeros into zero windows: start there
-        const uint32_t tp0 = ca < cb ? ca : cb, kc0 = tp0 / LEV_CH;
+        const uint32_t hfar = W::wave_max(W::sel(active, W::sel(h + h >= L * Dh, h, W::splat(L * Dh) - h), W::splat(0)));
+        const uint32_t tp0 = Tw - hfar, kc0 = tp0 / LEV_CH;
         load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         W::lds_wave_sync();
@@ -286,15 +290,15 @@ struct LevBand {
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
             // warm-up part: only the char windows move
             for (; tp < t_hi && tp < Tw; tp++) {
-                U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));
-                U32 b_in = W::lds_u8(lds, b_slot + ((tp + db) & (LEV_RING - 1)));
+                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & (LEV_RING - 1)));
+                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & (LEV_RING - 1)));
                 advance_b(st, b_in, is_gl);
                 advance_a(st, a_in, is_g0);
             }
             // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase)
             for (; tp < t_hi; tp++) {
-                U32 a_in = W::lds_u8(lds, a_slot + ((tp + da) & (LEV_RING - 1)));
-                U32 b_in = W::lds_u8(lds, b_slot + ((tp + db) & (LEV_RING - 1)));
+                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & (LEV_RING - 1)));
+                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & (LEV_RING - 1)));
                 phase<0>(st, P, is_g0, is_gl, tp - Tw, lane);
                 advance_b(st, b_in, is_gl);
                 phase<1>(st, P, is_g0, is_gl, tp - Tw, lane);

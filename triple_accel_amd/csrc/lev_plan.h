@@ -10,7 +10,7 @@ static const int LEV_D_SET[] = {2, 4, 6, 8, 10, 12, 16, 18, 20, 22, 24, 28, 32, 
 static const int LEV_D_COUNT = (int)(sizeof(LEV_D_SET) / sizeof(LEV_D_SET[0]));
 
 struct LevPlan {
-    uint32_t u, o, need;     // band half width, diagonal index of d=0, diagonals needed (o+u+1)
+    uint32_t u, o, need;     // unit_k of the batch, diagonal index of d=0 for an equal-length pair, diagonal slots (u+2)
     int D;                   // diagonals per lane
     uint32_t L, PW;          // lanes per pair, pairs per wave
     uint32_t lds_per_wave;
@@ -20,15 +20,39 @@ struct LevPlan {
 
 static inline uint32_t lev_sat_sub(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }
 
-// u: the farthest any alignment of cost <= k strays from the main diagonal (src/levenshtein.rs:760-763);
-// max_len clamps it exactly like the dispatcher does.  force_D > 0 pins D (tuning / tests).
-static inline LevPlan lev_make_plan(uint32_t k, uint32_t gc, uint32_t sg, uint64_t max_len, int force_D, int force_L) {
+// The band.  An alignment of cost <= K that strays t diagonals outside [min(0,delta), max(0,delta)]
+// (delta = b_len - a_len) pays for at least 2t + |delta| gap characters and one gap opening, so
+//     2t + |delta| <= (K - sg) / gc = unit_k                     (unit_k as in src/levenshtein.rs:426, :760-763)
+// and the diagonals d = j - i in [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2, hold every such
+// alignment: at most unit_k + 1 diagonals, half of the reference's [-unit_k, unit_k] (:434-438, :866).  Results are
+// unchanged -- inside either band every cell on an optimal alignment of cost <= K is exact, and a banded value is
+// never below the true one, so "d <= k ? Some(d) : None" (:539-541) comes out the same.
+// A pair's diagonal index is p = d + o_pair with o_pair odd (dp(0,0) must sit on an odd slot):
+static inline uint32_t lev_pair_offset(uint32_t u, uint64_t a_len, uint64_t b_len) {
+    const uint64_t diff = a_len > b_len ? a_len - b_len : b_len - a_len;
+    const uint64_t t = diff <= u ? (u - diff) >> 1 : 0;
+    return (uint32_t)(t + (a_len > b_len ? a_len - b_len : 0)) | 1u;
+}
+
+// unit_k of a batch whose strings are at most max_len long: K = min(k, the largest distance any such pair can have)
+// -- the dispatcher's max_k clamp (:734-757) taken over the batch -- then (K - sg) / gc, and never more than the
+// 2 max_len diagonals a matrix has.
+static inline uint32_t lev_batch_unit_k(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, uint64_t max_len) {
+    const uint64_t all_gaps = 2 * max_len * gc + 2ull * sg;                       // delete a, insert b
+    const uint64_t subs = max_len * (mc > gc ? mc : gc) + sg;                     // substitute, then one gap run
+    uint64_t K = all_gaps < subs ? all_gaps : subs;
+    if (K > k) K = k;
+    uint64_t u = (K > sg ? K - sg : 0) / gc;
+    if (u > 2 * max_len) u = 2 * max_len;
+    return (uint32_t)(u > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : u);
+}
+
+// force_D > 0 pins D (tuning / tests).
+static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, uint64_t max_len, int force_D, int force_L) {
     LevPlan p;
-    uint64_t u64 = lev_sat_sub(k, sg) / gc;
-    if (u64 > max_len) u64 = max_len;
-    p.u = (uint32_t)u64;
-    p.o = p.u | 1u;
-    p.need = p.o + p.u + 1u;
+    p.u = lev_batch_unit_k(k, mc, gc, sg, max_len);
+    p.o = (p.u >> 1) | 1u;
+    p.need = p.u + 2u;
     p.ok = false;
     p.D = 0; p.L = 0; p.PW = 0; p.lds_per_wave = 0;
     double best = 1e30;

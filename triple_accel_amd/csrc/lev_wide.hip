@@ -11,7 +11,7 @@
 // column (dp, and A of the column to come) in VGPRs.  At step s lane t computes column j = jlo + s - t of
 // its rows top to bottom, so the R-cell dependency chain runs inside a lane and the only cross-lane
 // traffic per step is the bottom row handed to lane t+1 (DPP wave_shr:1) plus the column's b byte.
-// Only the columns a stripe's rows can reach inside the band, [i_first - u, i_last + u], are visited.
+// Only the columns a stripe's rows can reach inside the pair's band (lev_plan.h) are visited.
 // Strings longer than one stripe are processed stripe by stripe; the stripe's last row goes to a per-wave
 // HBM scratch line and comes back as the next stripe's top boundary (64 columns per coalesced load,
 // handed to lane 0 with v_readlane).  Waves are persistent: grid = resident waves, pairs strided.
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
             if (t == 0) P.out[pair] = d <= P.k ? d : 0xFFFFFFFFu;
             continue;
         }
+        const uint32_t tband = (u - diff) >> 1;
+        const uint32_t below = tband + (n > m ? diff : 0u), above = tband + (m > n ? diff : 0u);
         uint32_t ans = WINF;
         uint32_t plo = 1, phi = 0;                       // previous stripe's column range (empty for stripe 0)
         const uint32_t stripes = (n + WROWS - 1) / WROWS;
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
         for (uint32_t q = 0; q < stripes; q++) {
             const uint32_t i0 = q * WROWS;               // the stripe's rows are i0+1 .. i0+WROWS
             const uint32_t i_last = (i0 + WROWS < n) ? i0 + WROWS : n;
-            const uint32_t jlo = (i0 + 1 > u) ? i0 + 1 - u : 1;
-            const uint32_t jhi = ((uint64_t)i_last + u < m) ? i_last + u : m;
+            // the pair's band (lev_plan.h): row i visits columns [i - below, i + above]
+            const uint32_t jlo = (i0 + 1 > below) ? i0 + 1 - below : 1;
+            const uint32_t jhi = ((uint64_t)i_last + above < m) ? i_last + above : m;
             const uint32_t Cn = jhi - jlo + 1;           // >= 1 because |n - m| <= u
             const uint32_t *rd = line_base + (uint64_t)((q + 1) & 1) * 3 * S.line;   // written by stripe q-1
             uint32_t *wr = line_base + (uint64_t)(q & 1) * 3 * S.line;

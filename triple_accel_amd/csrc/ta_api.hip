@@ -86,7 +86,7 @@ static int side_max_len(const ta_strings *s, uint32_t n, hipStream_t st, uint64_
 static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, const uint32_t *subset, uint32_t k,
                     const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st) {
     const uint32_t gc = c->gap_cost, sg = c->start_gap_cost;
-    LevPlan pl = lev_make_plan(k, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"));
+    LevPlan pl = lev_make_plan(k, c->mismatch_cost, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"));
     LevParams P;
     P.a = view_of(a); P.b = view_of(b);
     P.subset = subset; P.trace = nullptr; P.out = out_dev; P.n = n_work; P.k = k;
@@ -266,14 +266,13 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         flip ^= 1;
         n_work = left;
         k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
-        // Once the next band would cover more than half of the matrix, another bounded pass costs about as much as
-        // the exact answer: finish the unresolved pairs with k = u32::MAX (same return values -- levenshtein_exp
-        // returns the distance, whatever k schedule finds it; on random 4 KiB pairs this skips the k = 1920 and
-        // 3840 passes, 1.7 of the reference loop's 3.6 matrix-equivalents of work).
+        // Once the next bounded pass (about nn * unit_k cells) would cost more than a quarter of the matrix, it is
+        // cheaper in expectation to finish the unresolved pairs with k = u32::MAX right away (same return values --
+        // levenshtein_exp returns the distance, whatever k schedule finds it; on random 4 KiB pairs this skips the
+        // k = 1920 and 3840 passes of the reference loop).
         const double nn = (double)(max_len ? max_len : 1);
-        double u = (double)(lev_sat_sub(k, costs->start_gap_cost) / costs->gap_cost);
-        if (u > nn) u = nn;
-        if ((2.0 * nn * u - u * u) > 0.5 * nn * nn && !env_int("TA_EXP_FAITHFUL")) k = 0xFFFFFFFFu;
+        double u = (double)lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
+        if (u > 0.25 * nn && !env_int("TA_EXP_FAITHFUL")) k = 0xFFFFFFFFu;
     }
     return TA_OK;
 }
@@ -358,9 +357,9 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     ta_lev_select sel;
     ta_levenshtein_select(n, m, k, costs, &sel);
     const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
-    LevPlan pl = lev_make_plan(sel.max_k, gc, sg, m, 16, 0);
-    if (!pl.ok) pl = lev_make_plan(sel.max_k, gc, sg, m, 66, 0);
-    if (!pl.ok) { set_last_error_msg("traceback band wider than 4224 diagonals is not on the GPU path yet"); return TA_ERR_UNSUPPORTED; }
+    LevPlan pl = lev_make_plan(sel.max_k, costs->mismatch_cost, gc, sg, m, 16, 0);
+    if (!pl.ok) pl = lev_make_plan(sel.max_k, costs->mismatch_cost, gc, sg, m, 66, 0);
+    if (!pl.ok) { set_last_error_msg("traceback band wider than 4222 diagonals is not on the GPU path yet"); return TA_ERR_UNSUPPORTED; }
     ta_strings sa, sb;
     uint32_t *od;
     int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
@@ -385,9 +384,10 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     std::vector<uint32_t> tr(trace_words);
     TA_HIP(hipMemcpy(tr.data(), ts.dev, trace_words * 4, hipMemcpyDeviceToHost));
     std::vector<ta_edit> res;
+    const uint32_t o_pair = lev_pair_offset(pl.u, n, m);
     size_t i = n, j = m;
     while (i > 0 || j > 0) {                                                    // :561-603
-        const uint32_t s = (uint32_t)(i + j), p = (uint32_t)(j + pl.o - i);
+        const uint32_t s = (uint32_t)(i + j), p = (uint32_t)(j + o_pair - i);
         const uint32_t g = p / (uint32_t)pl.D, q = p % (uint32_t)pl.D, par = q & 1u, c = q >> 1, tau = (s - 1) >> 1;
         const uint32_t word = tr[(((size_t)tau * 2 + par) * 64 + g) * tw + ((2 * c) >> 5)];
         const uint32_t code = (word >> ((2 * c) & 31)) & 3u;
