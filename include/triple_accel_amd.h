@@ -40,7 +40,7 @@ typedef enum {
     TA_ERR_BAD_COSTS = 3,    /* EditCosts::new / check_search    src/levenshtein.rs:44-52,67-71 */
     TA_ERR_HIP = 4,          /* HIP runtime failure / no device (no CPU fallback) */
     TA_ERR_ARG = 5,          /* null pointer, size over the documented limit */
-    TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. traceback of a band wider than 4224 diagonals) */
+    TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. traceback of a band wider than 4222 diagonals) */
     TA_ERR_CAPACITY = 7      /* caller-provided match buffer too small; *n_out holds the need */
 } ta_status;
 
@@ -103,7 +103,7 @@ int ta_levenshtein_select(size_t a_len, size_t b_len, uint32_t k, const ta_edit_
 /* What the last distance batch launched on this thread used (for tests / debug logging;
  * the analogue of the reference's `debug` feature println, src/levenshtein.rs:840-847). */
 typedef struct {
-    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup */
+    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup, 3 = bit-parallel band (unit costs) */
     uint32_t diags_per_lane;  /* D */
     uint32_t lanes_per_pair;  /* L */
     uint32_t pairs_per_wave;
@@ -127,7 +127,7 @@ int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, u
 int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                                     uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out);
 /* levenshtein_simd_k_with_opts(a, b, k, true, costs): distance + run-length traceback (library-owned, ta_free).
- * 2-bit argmin codes come from the band-wavefront kernel; the walk is host code.  Bands wider than 4224 diagonals
+ * 2-bit argmin codes come from the band-wavefront kernel; the walk is host code.  Bands wider than 4222 diagonals
  * (unit_k > ~2100) return TA_ERR_UNSUPPORTED. */
 int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k,
                          const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits);

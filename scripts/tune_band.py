@@ -22,7 +22,10 @@ cells = O.band_cells(L, L, k, costs)
 want = O.levenshtein_k_batch(O.csr_from_fixed(a[:2000]), O.csr_from_fixed(b[:2000]), k, costs)
 layouts = [tuple(map(int, x.split(","))) for x in sys.argv[2:]] or [(0, 0)]
 for D, Lp in layouts:
-    os.environ["TA_FORCE_D"] = str(D); os.environ["TA_FORCE_L"] = str(Lp)
+    if D or Lp:
+        os.environ["TA_FORCE_D"] = str(D); os.environ["TA_FORCE_L"] = str(Lp)
+    else:
+        os.environ.pop("TA_FORCE_D", None); os.environ.pop("TA_FORCE_L", None)
     try:
         B.levenshtein_k_batch(sa, sb, k, costs, out=out)
     except Exception as e:
@@ -36,5 +39,5 @@ for D, Lp in layouts:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     info = T.last_launch_info()
-    print("D=%d L=%d PW=%d  %.3f ms  %.0f GCUPS  parity=%s" % (info["diags_per_lane"], info["lanes_per_pair"],
+    print("kernel=%d D=%d L=%d PW=%d  %.3f ms  %.0f GCUPS  parity=%s" % (info["kernel"], info["diags_per_lane"], info["lanes_per_pair"],
           info["pairs_per_wave"], ms, cells * n / ms / 1e6, ok), flush=True)

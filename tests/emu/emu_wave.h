@@ -28,6 +28,7 @@ struct VP {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
 TA_EMU_BIN(+) TA_EMU_BIN(-) TA_EMU_BIN(*) TA_EMU_BIN(^) TA_EMU_BIN(|) TA_EMU_BIN(&)
 #undef TA_EMU_BIN
+static inline V32 operator~(const V32 &a) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = ~a.v[i]; return r; }
 static inline V32 operator>>(const V32 &a, int s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >> s; return r; }
 static inline V32 operator<<(const V32 &a, int s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] << s; return r; }
 #define TA_EMU_CMP(op)                                                                    \
@@ -46,6 +47,7 @@ struct EmuWave {
 
     static U32 lane() { V32 r; for (int i = 0; i < 64; i++) r.v[i] = i; return r; }
     static U32 splat(uint32_t x) { return V32(x); }
+    static Bool bfalse() { VB r; for (int i = 0; i < 64; i++) r.v[i] = false; return r; }
     static U32 sel(const Bool &c, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
     static U32 umin(const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
     static U32 umin3(const U32 &a, const U32 &b, const U32 &c) { return umin(umin(a, b), c); }
@@ -72,6 +74,28 @@ struct EmuWave {
     static U32 dot4_byte(const U32 &x, int n, uint32_t m, const U32 &acc) {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + ((x.v[i] >> (8 * n)) & 0xffu) * (m & 0xffu); return r;
     }
+    static U32 dot4(const U32 &a, const U32 &b, const U32 &acc) {
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            uint32_t t = acc.v[i];
+            for (int k = 0; k < 4; k++) t += ((a.v[i] >> (8 * k)) & 0xffu) * ((b.v[i] >> (8 * k)) & 0xffu);
+            r.v[i] = t;
+        }
+        return r;
+    }
+    static U32 splat_byte(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] & 0xffu) * 0x01010101u; return r; }
+    static void addc(const U32 &a, const U32 &b, const Bool &cin, U32 &sum, Bool &cout) {
+        for (int i = 0; i < 64; i++) {
+            uint64_t t = (uint64_t)a.v[i] + b.v[i] + (cin.v[i] ? 1u : 0u);
+            sum.v[i] = (uint32_t)t; cout.v[i] = (t >> 32) != 0;
+        }
+    }
+    static U32 bcnt(const U32 &x, const U32 &acc) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + (uint32_t)__builtin_popcount(x.v[i]); return r; }
+    template <int N> static U32 alignbit(const U32 &hi, const U32 &lo) {
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> N); return r;
+    }
+    static U32 shlv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] << (s.v[i] & 31); return r; }
+    static U32 shrv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] >> (s.v[i] & 31); return r; }
     static U32 byte_of(const U32 &x, int n) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] >> (8 * n)) & 0xffu; return r; }
     static U32 bfi(uint32_t mask, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask); return r; }
     static U32 from_lower(const U32 &x, const U32 &fill) { V32 r; r.v[0] = fill.v[0]; for (int i = 1; i < 64; i++) r.v[i] = x.v[i - 1]; return r; }

@@ -19,6 +19,9 @@ def lib():
         L.emu_lev_band.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_lev_bits.restype = C.c_int
+        L.emu_lev_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -37,8 +40,10 @@ def pack(strings):
     return blob, off
 
 
-def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False):
-    """-> (list of dist|None, plan dict)"""
+def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False,
+             chunk=0):
+    """-> (list of dist|None, plan dict); chunk = bytes per streamed LDS chunk (0: the planner's choice)"""
+    lib().emu_lev_set_chunk(int(chunk))
     n = len(a_list)
     ab, ao = pack(a_list)
     bb, bo = pack(b_list)
@@ -53,6 +58,24 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
         raise RuntimeError("emu_lev_band rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(D=int(plan[0]), L=int(plan[1]), PW=int(plan[2]), u=int(plan[3]), o=int(plan[4]))
+
+
+def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0):
+    """Bit-parallel band kernel body (unit costs).  -> (list of dist|None, plan dict)"""
+    lib().emu_lev_set_chunk(int(chunk))
+    n = len(a_list)
+    ab, ao = pack(a_list)
+    bb, bo = pack(b_list)
+    out = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    plan = np.zeros(3, dtype=np.uint32)
+    max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
+    rc = lib().emu_lev_bits(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, int(bool(trans)),
+                            max_len, force_NA, out.ctypes.data, plan.ctypes.data)
+    lib().emu_lev_set_chunk(0)
+    if rc:
+        raise RuntimeError("emu_lev_bits rc=%d" % rc)
+    res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
+    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
 
 
 def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False, tile=64, halo=None, packed=False):

@@ -158,3 +158,13 @@ def test_emu_narrow_band_edges(costs):
         for k in (k_unit - 1, k_unit, k_unit + costs[1], 2 * k_unit + 1, 0xFFFFFFFF):
             got, plan = E.lev_band(a, b, max(k, 0), costs)
             assert got == oracle(a, b, max(k, 0), costs), (u, k, costs, plan)
+
+
+@pytest.mark.parametrize("chunk", [16, 32, 64])
+def test_emu_stream_chunk_lengths(chunk):
+    """The LDS ring works for every chunk length the planner may pick, on strings spanning many chunks."""
+    a, b = make_pairs(0xC4 + chunk, 64, 300, 20, True)
+    for costs, k in [((1, 1, 0, None), 25), ((1, 1, 0, 1), 40), ((2, 1, 2, None), 30)]:
+        for D, L in [(0, 0), (4, 0), (24, 2)]:
+            got, plan = E.lev_band(a, b, k, costs, force_D=D, force_L=L, chunk=chunk)
+            assert got == oracle(a, b, k, costs), (chunk, costs, k, plan)

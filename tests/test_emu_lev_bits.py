@@ -1,0 +1,96 @@
+"""Kernel-logic check without a GPU: the bit-parallel band kernel body (lev_bits_body.h, unit-cost families) run as
+a 64-lane host emulation must equal the oracle's scalar banded path bit for bit -- ragged lengths, every window
+width, both cost families, strings spanning many LDS chunks, null bytes."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+from test_emu_lev_band import make_pairs, _edge_pairs
+
+LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+
+
+def oracle(a, b, k, trans):
+    costs = RDAM if trans else LEV
+    return [O.levenshtein_simd_k_with_opts(x, y, k, False, costs)[0] for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bits_small(trans):
+    a, b = make_pairs(11, 200, 40, 6, trans)
+    for k in (0, 1, 2, 3, 7, 12, 30, 61, 0xFFFFFFFF):
+        got, plan = E.lev_bits(a, b, k, trans)
+        assert got == oracle(a, b, k, trans), (k, trans, plan)
+
+
+@pytest.mark.parametrize("force_NA", [1, 2, 3, 5, 8, 9, 11, 16])
+def test_bits_every_window_width(force_NA):
+    """The same small band inside every window width (1 or 2 dwords per bit-vector, partial top dwords)."""
+    for trans in (False, True):
+        k = max(0, min(4 * force_NA - 1 - (2 if trans else 0), 9))
+        a, b = make_pairs(100 + force_NA, 130, 70, max(1, k), trans)
+        got, plan = E.lev_bits(a, b, k, trans, force_NA=force_NA)
+        assert plan["NA"] == force_NA
+        assert got == oracle(a, b, k, trans), (k, trans, plan)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bits_band_edges(trans):
+    """Alignments that run along the edges of the narrow band, k just below / at / above the distance."""
+    for u in (6, 13, 32, 50):
+        a, b = _edge_pairs(0xB175 + u, 70, 80, u)
+        for k in (u - 1, u, u + 1, min(61, 2 * u)):
+            got, plan = E.lev_bits(a, b, k, trans)
+            assert got == oracle(a, b, k, trans), (u, k, trans, plan)
+
+
+def test_bits_cfg2_cfg4_shapes():
+    """BASELINE cfg2 (256 B, k = 32, Levenshtein) and cfg4 (128 B, k = 8, restricted Damerau) geometry."""
+    ar, br = Dg.pairs_random(0x7A02, 40, 256)
+    am, bm = Dg.pairs_mutated_fixed(0x7A12, 90, 256, 32)
+    a = [x.tobytes() for x in ar] + [x.tobytes() for x in am]
+    b = [x.tobytes() for x in br] + [x.tobytes() for x in bm]
+    got, plan = E.lev_bits(a, b, 32, False)
+    assert plan["NA"] == 9 and got == oracle(a, b, 32, False)
+    assert sum(x is not None for x in got) >= 60
+    ar, br = Dg.pairs_random(0x7A04, 40, 128)
+    am, bm = Dg.pairs_mutated_fixed(0x7A14, 90, 128, 8, swaps=True)
+    a = [x.tobytes() for x in ar] + [x.tobytes() for x in am]
+    b = [x.tobytes() for x in br] + [x.tobytes() for x in bm]
+    got, plan = E.lev_bits(a, b, 8, True)
+    assert plan["NA"] == 3 and got == oracle(a, b, 8, True)
+    assert sum(x is not None for x in got) >= 60
+
+
+@pytest.mark.parametrize("chunk", [16, 32, 64])
+def test_bits_long_strings_and_chunks(chunk):
+    a, b = make_pairs(0xC0 + chunk, 64, 700, 40, True)
+    for trans, k in [(False, 50), (True, 33), (False, 5)]:
+        got, plan = E.lev_bits(a, b, k, trans, chunk=chunk)
+        assert got == oracle(a, b, k, trans), (chunk, trans, k, plan)
+
+
+def test_bits_null_bytes_and_degenerate():
+    """Zero bytes are ordinary characters for Levenshtein (tests/basic_tests.rs:503-537); empty strings; 1-byte strings."""
+    g = Dg.rng(77)
+    a = [b"", b"", b"\0", b"\0\0\0", b"abc", b"\0a\0b", bytes(40), bytes(40), b"x", b"ab", b"ba"]
+    b = [b"", b"\0\0", b"\0", b"\0", b"", b"a\0b\0", bytes(37), bytes([0] * 20 + [1] + [0] * 19), b"y", b"ba", b"ab"]
+    for _ in range(60):
+        x = bytes(g.integers(0, 2, size=int(g.integers(0, 30))).astype(np.uint8))
+        y = bytes(g.integers(0, 2, size=int(g.integers(0, 30))).astype(np.uint8))
+        a.append(x); b.append(y)
+    for trans in (False, True):
+        for k in (0, 1, 2, 5, 9, 40):
+            got, plan = E.lev_bits(a, b, k, trans)
+            assert got == oracle(a, b, k, trans), (k, trans, plan)
+
+
+def test_bits_rejects_what_it_cannot_hold():
+    with pytest.raises(RuntimeError):
+        E.lev_bits([b"a" * 300], [b"b" * 300], 64, False)      # 65 diagonals > 64-bit window
+    with pytest.raises(RuntimeError):
+        E.lev_bits([b"a" * 300], [b"b" * 300], 62, True)       # 63 + 2 > 64
+    got, _ = E.lev_bits([b"a" * 300], [b"b" * 300], 63, False)
+    assert got == [None]

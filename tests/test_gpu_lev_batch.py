@@ -68,7 +68,7 @@ def test_cfg2_shape_100k():
     a = np.concatenate([ar, am]); b = np.concatenate([br, bm])
     out = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 32).cpu().numpy().view(np.uint32)
     info = T.last_launch_info()
-    assert info["kernel"] == 1 and info["cell_bits"] == 8
+    assert info["kernel"] == 3 and info["cell_bits"] == 8      # unit costs, 33 diagonals: the bit-parallel band kernel
     want = O.levenshtein_k_batch(O.csr_from_fixed(a), O.csr_from_fixed(b), 32)
     assert np.array_equal(out, want)
     assert (want[: n // 2] == 0xFFFFFFFF).all() and (want[n // 2:] != 0xFFFFFFFF).mean() > 0.2

@@ -1,0 +1,97 @@
+"""-m gpu: the bit-parallel band kernel (lev_bits_body.h: unit-cost families, through the C ABI) against the CPU
+oracle bit for bit, and against the DP band kernel at BASELINE sizes (two independent HIP implementations of the
+same contract must agree on every pair)."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import oracle_lib as O
+from test_gpu_lev_batch import gpu_k, oracle_k, ragged_pairs
+
+pytestmark = pytest.mark.gpu
+
+LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+
+
+def kernel_id():
+    import triple_accel_amd as T
+    return T.last_launch_info()["kernel"]
+
+
+@pytest.mark.parametrize("costs", [LEV, RDAM])
+def test_bits_ragged_vs_oracle(costs):
+    a, b = ragged_pairs(21, 6000, 80, 10, costs[3] is not None)
+    for k in (0, 1, 2, 3, 7, 12, 30, 47, 61):
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert kernel_id() == 3
+        assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_bits_every_window_width(monkeypatch):
+    a, b = ragged_pairs(22, 3000, 90, 9, True)
+    for na in range(1, 17):
+        monkeypatch.setenv("TA_FORCE_NA", str(na))
+        for costs in (LEV, RDAM):
+            k = max(0, min(4 * na - 1 - (2 if costs[3] else 0), 9))
+            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+            assert kernel_id() == 3
+            assert np.array_equal(got, want), (na, k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_bits_chunk_lengths_and_long_strings(monkeypatch):
+    g = Dg.rng(5)
+    a, b = [], []
+    for n in (1, 31, 32, 33, 63, 64, 65, 200, 513, 1500, 4000):
+        x = Dg.rand_str(g, n)
+        a += [x, x, x, x[: n // 2]]
+        b += [Dg.mutate(g, x, 25, True), x, Dg.rand_str(g, n + 3), x]
+    for ch in (16, 32, 64):
+        monkeypatch.setenv("TA_FORCE_CH", str(ch))
+        for k, costs in [(30, LEV), (40, RDAM), (61, LEV), (3, RDAM)]:
+            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+            assert kernel_id() == 3
+            assert np.array_equal(got, want), (ch, k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_unit_costs_beyond_the_window_use_the_dp_kernel():
+    """unit_k > 63 (61 with transpositions) does not fit the 64-bit window: the planner falls back to the DP band."""
+    a, b = ragged_pairs(23, 2000, 200, 30, True)
+    for k, costs in [(64, LEV), (62, RDAM), (150, LEV)]:
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert kernel_id() == 1
+        assert np.array_equal(got, want), (k, costs)
+
+
+def test_dp_kernel_still_covers_unit_costs(monkeypatch):
+    """TA_NO_BITS=1 routes the unit-cost families through the general DP band kernel (planner's own layout)."""
+    monkeypatch.setenv("TA_NO_BITS", "1")
+    a, b = ragged_pairs(24, 5000, 80, 10, True)
+    for k in (0, 3, 12, 32, 61):
+        for costs in (LEV, RDAM):
+            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+            assert kernel_id() == 1
+            assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
+
+
+@pytest.mark.parametrize("wl", ["cfg2", "cfg4"])
+def test_full_size_bits_equals_dp(wl, monkeypatch):
+    """BASELINE cfg2 / cfg4 at full size (1M pairs): the bit-parallel kernel and the DP band kernel agree on every
+    pair (half random, half mutated so that both None and Some(d) are exercised), plus a sampled oracle check."""
+    import torch
+    from triple_accel_amd import batch as B
+    n, L, k, costs = {"cfg2": (1_000_000, 256, 32, LEV), "cfg4": (1_000_000, 128, 8, RDAM)}[wl]
+    ar, br = Dg.pairs_random(0x7B00 + L, n // 2, L)
+    am, bm = Dg.pairs_mutated_fixed(0x7B10 + L, n // 2, L, k, swaps=costs[3] is not None)
+    a, b = np.concatenate([ar, am]), np.concatenate([br, bm])
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    bits = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    assert kernel_id() == 3
+    monkeypatch.setenv("TA_NO_BITS", "1")
+    dp = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    assert kernel_id() == 1
+    assert np.array_equal(bits, dp), np.flatnonzero(bits != dp)[:10]
+    assert (bits[: n // 2] == 0xFFFFFFFF).all() and (bits[n // 2:] != 0xFFFFFFFF).mean() > 0.2
+    idx = np.concatenate([np.arange(0, 2000), np.arange(n - 4000, n)])
+    want = O.levenshtein_k_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx]), k, costs)
+    assert np.array_equal(bits[idx], want)
+    torch.cuda.synchronize()

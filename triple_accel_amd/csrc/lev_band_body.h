@@ -27,9 +27,9 @@
 namespace ta {
 
 constexpr uint32_t LEV_INF = 0x3FFFFFFFu;   // "unreachable"; real costs stay far below (n+m < 2^22)
-constexpr int LEV_CH = 64;                  // iterations (= bytes per string) per streamed chunk
-constexpr int LEV_RING = 2 * LEV_CH;        // ring bytes per (pair, string) slot in LDS
-constexpr int LEV_SLOT = LEV_RING + 4;      // slot stride: odd number of dwords -> the per-pair byte reads hit distinct banks
+// Streamed chunk = P.ch iterations (= bytes per string; 16, 32 or 64, lev_plan.h), ring = 2 chunks per (pair, string)
+// slot in LDS, slot stride = ring + 4: an odd number of dwords, so the per-pair byte reads hit distinct banks.
+constexpr uint32_t lev_slot_bytes(uint32_t ch) { return 2u * ch + 4u; }
 
 struct LevParams {
     StrView a, b;
@@ -44,6 +44,7 @@ struct LevParams {
     uint32_t PW;              // pairs per wave = 64 / L
     uint32_t lds_per_wave;    // bytes
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
+    uint32_t ch;              // bytes per string per streamed chunk
     uint32_t *trace;          // TRACE kernels: 2-bit argmin codes, word w of (iteration tau, phase, lane) at
                               // ((tau*2 + phase)*64 + lane)*LEV_TRACE_WORDS(D) + w, cell c in bits [2c, 2c+2)
 };
@@ -114,11 +115,23 @@ struct LevBand {
             U32 t = (X[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;      // bit 7 of each byte <- low 7 bits nonzero
             X[w] = W::opaque((t | X[w]) & 0x80808080u) >> 7;  // 1 per nonzero byte (opaque: keep the and fused with the or)
         }
+        // all substitution candidates first: a v_dot4 result needs 3 wait states before another VALU may read it,
+        // so the mins below must not directly follow their own dot4
+        U32 subv[Dh];
+#pragma unroll
+        for (int c = 0; c < Dh; c++) subv[c] = W::dot4_byte(X[(c + 1) >> 2], (c + 1) & 3, P.mc, st.reg[2 * c + PAR]);   // :471-475
+        U32 tqv[TRANS == 1 ? Dh : 1];
+        if (TRANS == 1) {
+            // PV holds dp(i-2,j-2) + tc.  A failed test adds 255, which lifts the candidate above nv:
+            // nv <= dp(i-1,j-1) + mc <= dp(i-2,j-2) + 2 mc <= dp(i-2,j-2) + tc + 255 (host guarantees the last step).
+#pragma unroll
+            for (int c = 0; c < Dh; c++) tqv[c] = W::dot4_byte(Z[(c + 1) >> 2], (c + 1) & 3, 255u, st.PV[2 * c + PAR]);   // :523-525 (<= : min)
+        }
 #pragma unroll
         for (int c = 0; c < Dh; c++) {
             const int q = 2 * c + PAR;
             const int byte = c + 1, w = byte >> 2;
-            U32 sub = W::dot4_byte(X[w], byte & 3, P.mc, st.reg[q]);              // :471-475
+            U32 sub = subv[c];
             const int ql = q > 0 ? q - 1 : 0, qr = q + 1 < D ? q + 1 : D - 1;
             U32 lft = (PAR == 0 && c == 0) ? xl : ((AFFINE || PAR == 0) ? st.HA[ql] : st.reg[ql]);          // a_gap  :476-483
             U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : (PAR == 0 ? st.HA[qr] : st.reg[qr]));   // b_gap :484-491
@@ -129,11 +142,8 @@ struct LevBand {
                 code = W::sel(rgt < m1, W::splat(2), W::sel(lft < sub, W::splat(1), W::splat(0)));
             }
             if (TRANS == 1) {
-                // PV holds dp(i-2,j-2) + tc.  A failed test adds 255, which lifts the candidate above nv:
-                // nv <= dp(i-1,j-1) + mc <= dp(i-2,j-2) + 2 mc <= dp(i-2,j-2) + tc + 255 (host guarantees the last step).
-                U32 tq = W::dot4_byte(Z[w], byte & 3, 255u, st.PV[q]);                // :523-525 (<= : min)
                 st.PV[q] = st.reg[q] + P.tc;
-                nv = W::umin(nv, tq);
+                nv = W::umin(nv, tqv[c]);
             } else if (TRANS == 2) {
                 U32 t = st.PV[q];
                 st.PV[q] = st.reg[q] + P.tc;
@@ -195,20 +205,20 @@ struct LevBand {
     // (2 strings x 4 x 16 B) of a pair are fetched by the pair's own L lanes, so no pointer ever crosses lanes.
     static TA_HD inline void load_chunk(uint8_t *lds, const LevParams &P, uint32_t kc, U32 grp, U32 g, Bool active,
                                   Ptr aptr, U32 alen, Ptr bptr, U32 blen, U32 ea, U32 eb) {
-        constexpr uint32_t PIECES = 2u * (LEV_CH / 16);
+        const uint32_t CH = P.ch, PPS = CH / 16u, PIECES = 2u * PPS;
         for (uint32_t base = 0; base < PIECES; base += P.L) {
-            U32 pc = g + base;                   // piece index within the pair: [0,4) = a, [4,8) = b
+            U32 pc = g + base;                   // piece index within the pair: [0,PPS) = a, [PPS,2 PPS) = b
             Bool pred = active & (pc < PIECES);
-            Bool isb = pc >= (uint32_t)(LEV_CH / 16);
-            U32 piece = pc & 3u;
+            Bool isb = pc >= PPS;
+            U32 piece = W::sel(isb, pc - PPS, pc);
             U32 len = W::sel(isb, blen, alen);
             U32 e = W::sel(isb, eb, ea);
-            U32 y0 = piece * 16u + kc * LEV_CH;  // ring position (absolute)
+            U32 y0 = piece * 16u + kc * CH;      // ring position (absolute)
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
             auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, bptr, aptr), idx0), ok);
             U32 slot = grp * 2u + W::sel(isb, W::splat(1), W::splat(0));
-            W::lds_store16(lds, slot * LEV_SLOT + (y0 & (LEV_RING - 1)), q, pred);
+            W::lds_store16(lds, slot * lev_slot_bytes(CH) + (y0 & (2u * CH - 1u)), q, pred);
         }
     }
 
@@ -271,34 +281,35 @@ struct LevBand {
         }
         U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
 
-        const U32 a_slot = (grp * 2u) * LEV_SLOT, b_slot = (grp * 2u + 1u) * LEV_SLOT;
+        const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
+        const U32 a_slot = (grp * 2u) * lev_slot_bytes(CH), b_slot = (grp * 2u + 1u) * lev_slot_bytes(CH);
 
         // iterations before min(ca, cb) would only shift zeros into zero windows: start there
         const uint32_t hfar = W::wave_max(W::sel(active, W::sel(h + h >= L * Dh, h, W::splat(L * Dh) - h), W::splat(0)));
-        const uint32_t tp0 = Tw - hfar, kc0 = tp0 / LEV_CH;
+        const uint32_t tp0 = Tw - hfar, kc0 = tp0 / CH;
         load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         W::lds_wave_sync();
 
-        for (uint32_t kc = kc0; kc * LEV_CH < iters; kc++) {
+        for (uint32_t kc = kc0; kc * CH < iters; kc++) {
             if (kc > kc0) {
                 load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
                 W::lds_wave_sync();
             }
-            const uint32_t t_lo = kc * LEV_CH;
-            const uint32_t t_hi = (t_lo + LEV_CH < iters) ? t_lo + LEV_CH : iters;
+            const uint32_t t_lo = kc * CH;
+            const uint32_t t_hi = (t_lo + CH < iters) ? t_lo + CH : iters;
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
             // warm-up part: only the char windows move
             for (; tp < t_hi && tp < Tw; tp++) {
-                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & (LEV_RING - 1)));
-                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & (LEV_RING - 1)));
+                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
+                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
                 advance_b(st, b_in, is_gl);
                 advance_a(st, a_in, is_g0);
             }
             // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase)
             for (; tp < t_hi; tp++) {
-                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & (LEV_RING - 1)));
-                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & (LEV_RING - 1)));
+                U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
+                U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
                 phase<0>(st, P, is_g0, is_gl, tp - Tw, lane);
                 advance_b(st, b_in, is_gl);
                 phase<1>(st, P, is_g0, is_gl, tp - Tw, lane);

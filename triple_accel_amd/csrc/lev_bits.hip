@@ -1,0 +1,43 @@
+// lev_bits.hip -- gfx950 instantiations of the bit-parallel band kernel (lev_bits_body.h).
+#include <hip/hip_runtime.h>
+
+#include "lev_bits_body.h"
+#include "lev_plan.h"
+
+namespace ta {
+
+constexpr int BITS_WAVES_PER_BLOCK = 4;
+
+template <int NA, bool TRANS>
+__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6;
+    LevBits<DevWave, NA, TRANS>::run(P, blockIdx.x * BITS_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+}
+
+template <int NA>
+static hipError_t launch_na(const LevParams &P, bool trans, uint32_t grid, size_t lds, hipStream_t s) {
+    dim3 g(grid), b(64 * BITS_WAVES_PER_BLOCK);
+    if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true>), g, b, lds, s, P);
+    else hipLaunchKernelGGL((lev_bits_kernel<NA, false>), g, b, lds, s, P);
+    return hipGetLastError();
+}
+
+hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out,
+                           uint32_t *lds_out) {
+    const uint32_t waves = (P.n + 63u) / 64u;
+    const uint32_t grid = (waves + BITS_WAVES_PER_BLOCK - 1) / BITS_WAVES_PER_BLOCK;
+    const size_t lds = (size_t)pl.lds_per_wave * BITS_WAVES_PER_BLOCK;
+    if (grid_out) *grid_out = grid;
+    if (lds_out) *lds_out = (uint32_t)lds;
+    if (grid == 0) return hipSuccess;
+    switch (pl.NA) {
+#define TA_CASE(n) case n: return launch_na<n>(P, trans, grid, lds, s);
+        TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)
+        TA_CASE(9) TA_CASE(10) TA_CASE(11) TA_CASE(12) TA_CASE(13) TA_CASE(14) TA_CASE(15) TA_CASE(16)
+#undef TA_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ta

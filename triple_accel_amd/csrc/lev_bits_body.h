@@ -1,0 +1,196 @@
+// lev_bits_body.h -- bit-parallel banded Levenshtein / restricted-Damerau for the two unit-cost families
+// (LEVENSHTEIN_COSTS and RDAMERAU_COSTS, src/levenshtein.rs:79-91): what levenshtein(), rdamerau(),
+// levenshtein_simd_k() and the levenshtein_exp loop run with (:1397-1526).
+//
+// Same result contract as lev_band_body.h -- d if d <= k else None (src/levenshtein.rs:539-541) -- but the
+// cells of one column of the pair's band (lev_plan.h) are ONE bit each: the vertical differences of the DP
+// matrix are in {-1, 0, +1} for unit costs, so a column is two bit-vectors (VP: +1, VN: -1) and a column step is
+// ~10 bitwise ops per 32 cells (Myers 1999; Hyyro 2003, "A bit-vector algorithm for computing Levenshtein and
+// Damerau edit distances", whose diagonal-band form is used here: the window slides one row down per column,
+// so a DIAGONAL is a fixed bit position and the distance is read off the answer cell's diagonal:
+//     d = |delta| + sum over columns (1 - D0[bit of that diagonal]),
+// D0 = "the cell equals its diagonal predecessor").  What dominates is no longer the recurrence but building
+// the match vector: 4 byte compares per SWAR group, then v_dot4_u32_u8 with power-of-two weights squeezes the
+// four flag bytes into a nibble.
+//
+// One pair per lane (64 pairs per wavefront); the window is 4*NA bits wide (NA = packed dwords of `a` bytes
+// under it).  Rows outside [1, a_len] need no masking: above row 0 the virtual values D[r][j] = j + |r| satisfy
+// the recurrence with or without spurious matches, and rows below a_len never feed the rows above them.
+// Strings are streamed HBM -> LDS exactly as in lev_band_body.h (same ring, same loader).
+#pragma once
+#include "lev_band_body.h"
+
+namespace ta {
+
+template <class W, int NA, bool TRANS>
+struct LevBits {
+    static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
+    static constexpr int NW = (NA + 7) / 8;            // dwords per bit-vector
+    static constexpr int WB = 4 * NA;                  // window bits (diagonals)
+    using U32 = typename W::U32;
+    using Bool = typename W::Bool;
+    using Ptr = typename W::Ptr;
+    using Loader = LevBand<W, 2, false, 0>;
+
+    static constexpr uint32_t wmask(int q) { return (q == NW - 1 && (WB & 31)) ? ((1u << (WB & 31)) - 1u) : 0xFFFFFFFFu; }
+
+    struct State {
+        U32 VP[NW], VN[NW];     // vertical +1 / -1 differences of the previous column, at the current window's rows
+        U32 AW[NA];             // byte i = a[row(i) - 1], row(i) = j - d_hi + i: window bit i <-> byte i
+        U32 PMp[NW], D0p[NW];   // TRANS: previous column's match vector and D0
+    };
+
+    // the window moves one row down: byte i <- byte i+1, the next byte of `a` enters on top
+    static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in) {
+#pragma unroll
+        for (int k = 0; k < NA - 1; k++) st.AW[k] = W::template alignbyte<1>(st.AW[k + 1], st.AW[k]);
+        st.AW[NA - 1] = W::template alignbyte<1>(a_in, st.AW[NA - 1]);
+    }
+
+    // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
+    template <bool CAP>
+    static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
+        const U32 Bs = W::splat_byte(b_in);
+        U32 PM[NW], D0[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            U32 ne = W::splat(0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int k0 = 8 * q + 2 * p;
+                if (k0 >= NA) break;
+                U32 acc = W::splat(0);
+#pragma unroll
+                for (int h = 0; h < 2 && k0 + h < NA; h++) {
+                    const U32 x = st.AW[k0 + h] ^ Bs;
+                    const U32 t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;                 // bit 7 of each byte <- low 7 bits nonzero
+                    const U32 f = W::opaque((t | x) & 0x80808080u);               // 0x80 per mismatching byte
+                    acc = W::dot4(f, W::splat(h ? 0x80402010u : 0x08040201u), acc);   // 128 * (8 mismatch bits)
+                }
+                ne = p == 0 ? (acc >> 7) : (ne | (acc << (8 * p - 7)));
+            }
+            PM[q] = ~ne & wmask(q);
+        }
+        // D0 = (((PM & VP) + VP) ^ VP) | PM | VN      (Hyyro 2003, eq. for the diagonal zero-difference vector)
+        Bool carry = W::bfalse();
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            U32 s;
+            W::addc(PM[q] & st.VP[q], st.VP[q], carry, s, carry);
+            D0[q] = ((s ^ st.VP[q]) | PM[q]) | st.VN[q];
+        }
+        if (TRANS) {
+            // a[i-1] == b[j-2] && a[i-2] == b[j-1] (src/levenshtein.rs:517-521) and the diagonal step before was +1:
+            // D0 |= ~D0_prev & (PM << 1) & (PM_prev >> 1)      (window indices: a diagonal keeps its bit)
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const U32 pml = q ? W::template alignbit<31>(PM[q], PM[q - 1]) : (PM[q] << 1);
+                const U32 pmr = (q + 1 < NW) ? W::template alignbit<1>(st.PMp[q + 1], st.PMp[q]) : (st.PMp[q] >> 1);
+                D0[q] = D0[q] | (~st.D0p[q] & pml & pmr);
+            }
+        }
+        if (WB & 31) D0[NW - 1] = D0[NW - 1] & wmask(NW - 1);
+        U32 z = W::splat(0);
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const U32 HP = st.VN[q] | ~(D0[q] | st.VP[q]);
+            const U32 HN = D0[q] & st.VP[q];
+            const U32 D0s = (q + 1 < NW) ? W::template alignbit<1>(D0[q + 1], D0[q]) : (D0[q] >> 1);   // next window's rows
+            st.VP[q] = HN | ~(D0s | HP);
+            st.VN[q] = D0s & HP;
+            z = z | (D0[q] & M[q]);
+            if (TRANS) { st.PMp[q] = PM[q]; st.D0p[q] = D0[q]; }
+        }
+        if (CAP) z = W::sel(live, z, W::splat(0));
+        cnt = W::bcnt(z, cnt);
+    }
+
+    static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
+        const U32 lane = W::lane();
+        const U32 grp = lane, g = W::splat(0);
+        const Bool active = (lane == lane);
+        const U32 slot_idx = lane + wave_index * 64u;
+        const Bool valid = slot_idx < P.n;
+        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, valid, 0u) : slot_idx;
+
+        Ptr aptr, bptr;
+        U32 alen, blen;
+        W::load_str(P.a, pair, valid, aptr, alen);     // rows
+        W::load_str(P.b, pair, valid, bptr, blen);     // columns
+
+        // the pair's band (lev_plan.h): diagonals d = j - i in [-nlo, d_hi]; window bit i <-> diagonal d_hi - i
+        const U32 diff = W::sel(blen >= alen, blen - alen, alen - blen);
+        const Bool inband = diff <= P.u;                       // else None (:426-428, :860-862)
+        const U32 tband = W::sel(inband, (W::splat(P.u) - diff) >> 1, W::splat(0));
+        const U32 nlo = W::sel(inband, tband + W::sel(blen >= alen, W::splat(0), diff) + (TRANS ? 1u : 0u), W::splat(0));
+        const U32 dhi = W::splat((uint32_t)WB - 1u) - nlo;
+        const U32 idx_ans = W::sel(inband, (dhi + alen) - blen, W::splat(0));   // row a_len at column b_len
+
+        State st;
+        U32 M[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const uint32_t lo = 32u * (uint32_t)q;
+            // column 0, D[r][0] = |r|: rows r = 1 - d_hi + i >= 1 step up (+1), rows <= 0 step down (-1)
+            const U32 below = W::sel(dhi >= lo + 32u, W::splat(0xFFFFFFFFu),
+                                     W::sel(dhi <= lo, W::splat(0), W::shlv(W::splat(1), dhi - lo) - 1u));
+            st.VN[q] = below & wmask(q);
+            st.VP[q] = ~below & wmask(q);
+            st.PMp[q] = W::splat(0);
+            st.D0p[q] = W::splat(wmask(q));
+            M[q] = W::sel((idx_ans >> 5) == (uint32_t)q, W::shlv(W::splat(1), idx_ans & 31u), W::splat(0));
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) st.AW[k] = W::splat(0);
+        U32 cnt = W::splat(0);
+
+        // iteration tp inserts a[tp - ca] into the window and, from tp = T0 on, runs column tp - T0 + 1 with b[tp - T0]
+        const uint32_t T0 = P.Tw;
+        const U32 ca = W::splat(T0) - nlo, cb = W::splat(T0);
+        const U32 da = (W::splat(16u) - (ca & 15u)) & 15u, db = (W::splat(16u) - (cb & 15u)) & 15u;
+        const U32 ea = ca + da, eb = cb + db;
+        const uint32_t tp0 = T0 - W::wave_max(W::sel(valid, nlo, W::splat(0)));
+        const uint32_t iters = T0 + W::wave_max(blen);
+        const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
+
+        const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
+        const U32 a_slot = (grp * 2u) * lev_slot_bytes(CH), b_slot = (grp * 2u + 1u) * lev_slot_bytes(CH);
+        const uint32_t kc0 = tp0 / CH;
+        Loader::load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        Loader::load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        W::lds_wave_sync();
+
+        for (uint32_t kc = kc0; kc * CH < iters; kc++) {
+            if (kc > kc0) {
+                Loader::load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+                W::lds_wave_sync();
+            }
+            const uint32_t t_lo = kc * CH;
+            const uint32_t t_hi = (t_lo + CH < iters) ? t_lo + CH : iters;
+            uint32_t tp = t_lo > tp0 ? t_lo : tp0;
+            for (; tp < t_hi && tp < T0; tp++)                 // warm-up: rows 1..nlo slide in
+                advance_a(st, W::lds_u8(lds, a_slot + ((da + tp) & RMASK)));
+            if (!W::any(t_stop < t_hi)) {                      // every pair still has columns up to the chunk's end
+                for (; tp < t_hi; tp++) {
+                    const U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
+                    const U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
+                    advance_a(st, a_in);
+                    column<false>(st, b_in, M, cnt, active);
+                }
+            } else {
+                for (; tp < t_hi; tp++) {
+                    const U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
+                    const U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
+                    advance_a(st, a_in);
+                    column<true>(st, b_in, M, cnt, t_stop > tp);
+                }
+            }
+        }
+
+        const U32 d = (diff + blen) - cnt;                     // |delta| + columns - zero-difference steps
+        const Bool some = inband & (d <= P.k);                 // :539-541, :1166-1168
+        W::store_u32(P.out, pair, W::sel(some, d, W::splat(0xFFFFFFFFu)), valid);
+    }
+};
+
+}  // namespace ta

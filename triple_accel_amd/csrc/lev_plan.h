@@ -15,6 +15,7 @@ struct LevPlan {
     uint32_t L, PW;          // lanes per pair, pairs per wave
     uint32_t lds_per_wave;
     uint32_t Tw;             // warm-up iterations
+    uint32_t ch;             // bytes per string per streamed chunk (LDS ring = 2 chunks)
     bool ok;                 // false: band too wide for one wavefront (needs the wide-band kernel)
 };
 
@@ -48,7 +49,8 @@ static inline uint32_t lev_batch_unit_k(uint32_t k, uint32_t mc, uint32_t gc, ui
 }
 
 // force_D > 0 pins D (tuning / tests).
-static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, uint64_t max_len, int force_D, int force_L) {
+static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, uint64_t max_len, int force_D, int force_L,
+                                    int force_ch = 0) {
     LevPlan p;
     p.u = lev_batch_unit_k(k, mc, gc, sg, max_len);
     p.o = (p.u >> 1) | 1u;
@@ -69,7 +71,10 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32
         if (cost < best) { best = cost; p.D = D; p.L = L; p.PW = PW; p.ok = true; }
     }
     if (p.ok) {
-        p.lds_per_wave = (2u * p.PW * 132u + 15u) & ~15u;   // LEV_SLOT bytes per (pair, string)
+        // LDS ring: 2 chunks per (pair, string).  64-byte chunks when a wave holds <= 32 pairs; 32-byte ones at 64
+        // pairs per wave, so that a wave's rings stay under ~8.5 KB and 4 waves per SIMD fit next to each other.
+        p.ch = (force_ch == 16 || force_ch == 32 || force_ch == 64) ? (uint32_t)force_ch : (p.PW > 32 ? 32u : 64u);
+        p.lds_per_wave = (2u * p.PW * (2u * p.ch + 4u) + 15u) & ~15u;
         // The ring chunk of iteration block kc holds a[64 kc - ea ..) and b[64 kc - eb ..), ea = (Tw - h) rounded up to
         // 16, eb likewise.  Pad the warm-up so that both are multiples of 64: every 64-byte chunk then maps onto ONE
         // 64-byte line of a line-aligned string instead of straddling two (which costs a second HBM fetch when the line
@@ -80,6 +85,34 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32
         for (uint32_t w = 0; w < 64; w++)
             if (lined(base + w - h) && lined(w + h)) { p.Tw = base + w; break; }
     }
+    return p;
+}
+
+// ---- bit-parallel band kernel (lev_bits_body.h): unit costs only, one pair per lane, window of 4*NA diagonals
+static const int LEV_BITS_MAX_NA = 16;
+
+struct LevBitsPlan {
+    bool ok;                 // false: costs are not a unit-cost family, or the band is wider than the window
+    uint32_t u;              // unit_k of the batch
+    int NA;                  // packed dwords of `a` under the window (window = 4*NA bits)
+    uint32_t Tw, ch, lds_per_wave;
+};
+
+static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc,
+                                             uint64_t max_len, int force_NA = 0, int force_ch = 0) {
+    LevBitsPlan p;
+    p.ok = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1);   // LEVENSHTEIN_COSTS / RDAMERAU_COSTS (src/levenshtein.rs:79-91)
+    p.u = lev_batch_unit_k(k, mc, gc, sg, max_len);
+    const uint64_t w = (uint64_t)p.u + 1u + (has_t ? 2u : 0u);     // the transposition test looks one row past each band edge
+    uint64_t na = (w + 3) / 4;
+    if (force_NA > 0 && (uint64_t)force_NA >= na) na = (uint64_t)force_NA;
+    if (na > (uint64_t)LEV_BITS_MAX_NA) { p.ok = false; na = LEV_BITS_MAX_NA; }
+    p.NA = (int)na;
+    p.ch = (force_ch == 16 || force_ch == 32 || force_ch == 64) ? (uint32_t)force_ch : 32u;
+    p.lds_per_wave = (2u * 64u * (2u * p.ch + 4u) + 15u) & ~15u;
+    // columns start at iteration Tw >= the deepest band (rows that must slide in first); a multiple of 64 keeps the
+    // chunks of `b` on 64-byte lines
+    p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;
     return p;
 }
 

@@ -86,7 +86,7 @@ static int side_max_len(const ta_strings *s, uint32_t n, hipStream_t st, uint64_
 static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, const uint32_t *subset, uint32_t k,
                     const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st) {
     const uint32_t gc = c->gap_cost, sg = c->start_gap_cost;
-    LevPlan pl = lev_make_plan(k, c->mismatch_cost, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"));
+    LevPlan pl = lev_make_plan(k, c->mismatch_cost, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"), env_int("TA_FORCE_CH"));
     LevParams P;
     P.a = view_of(a); P.b = view_of(b);
     P.subset = subset; P.trace = nullptr; P.out = out_dev; P.n = n_work; P.k = k;
@@ -98,8 +98,19 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     ta_lev_select sel;
     ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
     li.cell_bits = sel.cell_bits;
-    if (pl.ok && !env_int("TA_FORCE_WIDE")) {
-        P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw;
+    // unit-cost families (levenshtein(), rdamerau(), levenshtein_simd_k(), the exp loop): bit-parallel columns
+    const LevBitsPlan bp = lev_bits_make_plan(k, c->mismatch_cost, gc, sg, trans, c->has_transpose ? c->transpose_cost : 0, max_len,
+                                              env_int("TA_FORCE_NA"), env_int("TA_FORCE_CH"));
+    const bool dp_forced = env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L") || env_int("TA_FORCE_AFFINE") ||
+                           env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
+    if (bp.ok && !dp_forced) {
+        P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
+        uint32_t grid = 0, lds = 0;
+        TA_HIP(lev_bits_launch(P, bp, trans, st, &grid, &lds));
+        li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
+        li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
+    } else if (pl.ok && !env_int("TA_FORCE_WIDE")) {
+        P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
         uint32_t grid = 0, lds = 0;
         const int tmode = !trans ? 0 : ((2u * P.mc <= 255u + P.tc && !env_int("TA_FORCE_TRANS_SELECT")) ? 1 : 2);
         TA_HIP(lev_band_launch(P, pl, affine, tmode, st, &grid, &lds));
@@ -373,7 +384,7 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     P.a = view_of(&sa); P.b = view_of(&sb);
     P.subset = nullptr; P.out = od; P.n = 1; P.k = k;
     P.mc = costs->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = costs->has_transpose ? costs->transpose_cost : 0;
-    P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw;
+    P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
     P.trace = (uint32_t *)ts.dev;
     TA_HIP(lev_band_trace_launch(P, pl, sg > 0, costs->has_transpose != 0, 0));
     uint32_t d = 0;

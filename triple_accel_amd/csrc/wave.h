@@ -36,6 +36,7 @@ struct DevWave {
         return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     }
     static __device__ __forceinline__ U32 splat(uint32_t x) { return x; }
+    static __device__ __forceinline__ Bool bfalse() { return false; }
     static __device__ __forceinline__ U32 sel(Bool c, U32 a, U32 b) { return c ? a : b; }
     static __device__ __forceinline__ U32 umin(U32 a, U32 b) { return a < b ? a : b; }
     static __device__ __forceinline__ U32 umin3(U32 a, U32 b, U32 c) { return umin(umin(a, b), c); }
@@ -60,6 +61,23 @@ struct DevWave {
     static __device__ __forceinline__ U32 dot4_byte(U32 x, int n, uint32_t m, U32 acc) {
         return __builtin_amdgcn_udot4(x, m << (8 * n), acc, false);
     }
+    // acc + sum of the four byte products of a and b -> v_dot4_u32_u8
+    static __device__ __forceinline__ U32 dot4(U32 a, U32 b, U32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+    // the low byte of x in all four bytes -> v_perm_b32
+    static __device__ __forceinline__ U32 splat_byte(U32 x) { return __builtin_amdgcn_perm(x, x, 0x04040404u); }
+    // sum = a + b + cin, cout = carry out -> v_add_co_u32 / v_addc_co_u32
+    static __device__ __forceinline__ void addc(U32 a, U32 b, Bool cin, U32 &sum, Bool &cout) {
+        unsigned int co;
+        sum = __builtin_addc(a, b, cin ? 1u : 0u, &co);
+        cout = co != 0u;
+    }
+    // acc + popcount(x) -> v_bcnt_u32_b32
+    static __device__ __forceinline__ U32 bcnt(U32 x, U32 acc) { return (U32)__builtin_popcount(x) + acc; }
+    // ({hi,lo} >> N)[31:0], N in 1..31 -> v_alignbit_b32
+    template <int N> static __device__ __forceinline__ U32 alignbit(U32 hi, U32 lo) { return __builtin_amdgcn_alignbit(hi, lo, N); }
+    // per-lane shift amounts (< 32)
+    static __device__ __forceinline__ U32 shlv(U32 x, U32 s) { return x << s; }
+    static __device__ __forceinline__ U32 shrv(U32 x, U32 s) { return x >> s; }
     // byte N of x, zero-extended (folds into the consumer as an SDWA byte select)
     static __device__ __forceinline__ U32 byte_of(U32 x, int n) { return (x >> (8 * n)) & 0xffu; }
     // (a & mask) | (b & ~mask) -> v_bfi_b32
