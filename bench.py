@@ -59,6 +59,7 @@ def main():
             dist.init_process_group(backend)
 
     wl = args.workload
+    evaluated_unit = None
     seed = 0x7A00 + int(wl[3:]) + 1000 * rank
     cores = O.max_threads()
     LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
@@ -100,6 +101,10 @@ def main():
                     "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)"}[wl]
             unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select), arithmetic in 32-bit VGPR lanes
             cpu_sample = min(n, 20000 * max(1, cores // 2))
+            # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
+            #  -- about half of the credited reference band; reported for transparency, never credited
+            uk = min((min(k, L * max(costs[0], costs[1])) - costs[2]) // costs[1], 2 * L)
+            evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
         units = n
 
         def parity():
@@ -197,13 +202,15 @@ def main():
         cpu = {"value": cells_unit * done / dt / 1e9, "unit": "GCUPS", "cores": used, "kind": "port",
                "sample": "%s, oracle/ta_oracle.c (restated scalar path), %.1f s" % (what, dt)}
 
+    if info.get("kernel") == 3:
+        dtype = "u32 bit-vectors, 1 bit per band cell (reference width class u%d)" % info.get("cell_bits", 8)
     line = {
         "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
         "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "unit": unit_name,
-                   "credited_cells_per_unit": cells_unit, "parallelism": "independent units sharded x%d, no collective" % world},
+                   "credited_cells_per_unit": cells_unit, "evaluated_band_cells_per_unit": evaluated_unit, "parallelism": "independent units sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "device_ms_per_pass": dev_s * 1e3, "algorithmic_bytes_per_pass": bytes_unit * units,

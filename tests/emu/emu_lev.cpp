@@ -82,9 +82,31 @@ extern "C" int emu_lev_bits(const uint8_t *a_blob, const uint64_t *a_off, const 
     switch (pl.NA) {
 #define CASE(d) case d: run_bits<d>(P, has_t != 0, waves); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
-        CASE(13) CASE(14) CASE(15) CASE(16)
+        CASE(13) CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(26) CASE(28) CASE(30) CASE(32)
 #undef CASE
         default: return 2;
     }
+    return 0;
+}
+
+// ---- row-blocked bit-parallel full-column kernel (lev_widebits_body.h)
+#include "lev_widebits_body.h"
+
+extern "C" int emu_lev_widebits(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                                uint32_t n, uint32_t k, int has_t, uint64_t max_len, int nwl, uint32_t nwaves, uint32_t *out) {
+    LevParams P;
+    P.a = StrView{a_blob, a_off, 0, 0};
+    P.b = StrView{b_blob, b_off, 0, 0};
+    P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
+    P.u = lev_batch_unit_k(k, 1, 1, 0, max_len);
+    P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+    if (max_len > 64u * 32u * (uint32_t)nwl && false) return 1;
+    uint8_t *lds = (uint8_t *)calloc(33 * 64 * 2 * 4 + 64, 1);
+    for (uint32_t w = 0; w < nwaves; w++) {
+        if (nwl == 1) { if (has_t) LevWideBits<EmuWave, 1, true>::run(P, w, nwaves, lds); else LevWideBits<EmuWave, 1, false>::run(P, w, nwaves, lds); }
+        else { if (has_t) LevWideBits<EmuWave, 2, true>::run(P, w, nwaves, lds); else LevWideBits<EmuWave, 2, false>::run(P, w, nwaves, lds); }
+    }
+    free(lds);
     return 0;
 }

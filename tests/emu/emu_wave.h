@@ -141,10 +141,23 @@ struct EmuWave {
         }
         return q;
     }
+    static U32 qword(const Q128V &q, int i) {
+        V32 r;
+        for (int l = 0; l < 64; l++) r.v[l] = i == 0 ? q.v[l].x : i == 1 ? q.v[l].y : i == 2 ? q.v[l].z : q.v[l].w;
+        return r;
+    }
     static void lds_store16(uint8_t *lds, const U32 &off, const Q128V &q, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &q.v[i], 16);
     }
     static U32 lds_u8(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = lds[off.v[i]]; return r; }
+    static U32 lds_read32(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], lds + off.v[i], 4); return r; }
+    static void lds_write32(uint8_t *lds, const U32 &off, const U32 &v) { for (int i = 0; i < 64; i++) memcpy(lds + off.v[i], &v.v[i], 4); }
+    static void lds_or32(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) {
+        for (int i = 0; i < 64; i++) if (pred.v[i]) { uint32_t t; memcpy(&t, lds + off.v[i], 4); t |= v.v[i]; memcpy(lds + off.v[i], &t, 4); }
+    }
+    static uint32_t readlane(const U32 &x, uint32_t l) { return x.v[l & 63]; }
+    static U32 gload_u8(const Ptr &p, const Bool &pred) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = pred.v[i] ? *p.v[i] : 0u; return r; }
+    static uint32_t wave_sum(const U32 &x) { uint32_t t = 0; for (int i = 0; i < 64; i++) t += x.v[i]; return t; }
     static void lds_wave_sync() {}
 };
 

@@ -22,6 +22,9 @@ def lib():
         L.emu_lev_bits.restype = C.c_int
         L.emu_lev_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                    C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_lev_widebits.restype = C.c_int
+        L.emu_lev_widebits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                       C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -76,6 +79,20 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0):
         raise RuntimeError("emu_lev_bits rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
+
+
+def lev_widebits(a_list, b_list, k, trans=False, nwl=2, nwaves=3):
+    """Row-blocked bit-parallel kernel body (unit costs, shorter string <= 64 * 32 * nwl bytes).  -> list of dist|None"""
+    n = len(a_list)
+    ab, ao = pack(a_list)
+    bb, bo = pack(b_list)
+    out = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
+    rc = lib().emu_lev_widebits(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, int(bool(trans)),
+                                max_len, nwl, nwaves, out.ctypes.data)
+    if rc:
+        raise RuntimeError("emu_lev_widebits rc=%d" % rc)
+    return [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
 
 
 def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False, tile=64, halo=None, packed=False):

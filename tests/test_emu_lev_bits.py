@@ -20,12 +20,12 @@ def oracle(a, b, k, trans):
 @pytest.mark.parametrize("trans", [False, True])
 def test_bits_small(trans):
     a, b = make_pairs(11, 200, 40, 6, trans)
-    for k in (0, 1, 2, 3, 7, 12, 30, 61, 0xFFFFFFFF):
+    for k in (0, 1, 2, 3, 7, 12, 30, 61, 64, 100, 0xFFFFFFFF):
         got, plan = E.lev_bits(a, b, k, trans)
         assert got == oracle(a, b, k, trans), (k, trans, plan)
 
 
-@pytest.mark.parametrize("force_NA", [1, 2, 3, 5, 8, 9, 11, 16])
+@pytest.mark.parametrize("force_NA", [1, 2, 3, 5, 8, 9, 11, 16, 18, 24, 26, 32])
 def test_bits_every_window_width(force_NA):
     """The same small band inside every window width (1 or 2 dwords per bit-vector, partial top dwords)."""
     for trans in (False, True):
@@ -39,9 +39,9 @@ def test_bits_every_window_width(force_NA):
 @pytest.mark.parametrize("trans", [False, True])
 def test_bits_band_edges(trans):
     """Alignments that run along the edges of the narrow band, k just below / at / above the distance."""
-    for u in (6, 13, 32, 50):
-        a, b = _edge_pairs(0xB175 + u, 70, 80, u)
-        for k in (u - 1, u, u + 1, min(61, 2 * u)):
+    for u in (6, 13, 32, 50, 90):
+        a, b = _edge_pairs(0xB175 + u, 70, 150, u)
+        for k in (u - 1, u, u + 1, min(125, 2 * u)):
             got, plan = E.lev_bits(a, b, k, trans)
             assert got == oracle(a, b, k, trans), (u, k, trans, plan)
 
@@ -89,8 +89,8 @@ def test_bits_null_bytes_and_degenerate():
 
 def test_bits_rejects_what_it_cannot_hold():
     with pytest.raises(RuntimeError):
-        E.lev_bits([b"a" * 300], [b"b" * 300], 64, False)      # 65 diagonals > 64-bit window
+        E.lev_bits([b"a" * 300], [b"b" * 300], 128, False)     # 129 diagonals > 128-bit window
     with pytest.raises(RuntimeError):
-        E.lev_bits([b"a" * 300], [b"b" * 300], 62, True)       # 63 + 2 > 64
-    got, _ = E.lev_bits([b"a" * 300], [b"b" * 300], 63, False)
+        E.lev_bits([b"a" * 300], [b"b" * 300], 126, True)      # 127 + 2 > 128
+    got, _ = E.lev_bits([b"a" * 300], [b"b" * 300], 127, False)
     assert got == [None]

@@ -1,0 +1,79 @@
+"""Kernel-logic check without a GPU: the row-blocked bit-parallel kernel body (lev_widebits_body.h: one pair per
+wavefront, 32/64 rows per lane, nibble tables in LDS, skewed lanes) as a 64-lane host emulation against the oracle."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+
+
+def oracle(a, b, k, trans):
+    costs = RDAM if trans else LEV
+    return [O.levenshtein_simd_k_with_opts(x, y, k, False, costs)[0] for x, y in zip(a, b)]
+
+
+def pairs(seed, count, maxlen, small_alphabet=False):
+    g = Dg.rng(seed)
+    a, b = [], []
+    for i in range(count):
+        la = int(g.integers(0, maxlen + 1))
+        if small_alphabet:
+            x = bytes(g.integers(97, 100, size=la).astype(np.uint8))
+        else:
+            x = Dg.rand_str(g, la)
+        t = i % 4
+        if t == 0:
+            lb = int(g.integers(0, maxlen + 1))
+            y = bytes(g.integers(97, 100, size=lb).astype(np.uint8)) if small_alphabet else Dg.rand_str(g, lb)
+        elif t == 1:
+            y = x
+        else:
+            y = Dg.mutate(g, x, int(g.integers(0, 30)), True)
+        a.append(x); b.append(y)
+    return a, b
+
+
+@pytest.mark.parametrize("nwl", [1, 2])
+@pytest.mark.parametrize("trans", [False, True])
+def test_widebits_ragged(nwl, trans):
+    a, b = pairs(5 + nwl, 60, 300)
+    for k in (0, 3, 25, 100, 0xFFFFFFFF):
+        got = E.lev_widebits(a, b, k, trans, nwl=nwl)
+        assert got == oracle(a, b, k, trans), (k, trans, nwl)
+
+
+@pytest.mark.parametrize("nwl", [1, 2])
+def test_widebits_small_alphabet_transpositions(nwl):
+    """Three-letter alphabet: matches and transpositions everywhere, incl. across lane (row-block) boundaries."""
+    a, b = pairs(50 + nwl, 50, 200, small_alphabet=True)
+    for trans in (False, True):
+        got = E.lev_widebits(a, b, 0xFFFFFFFF, trans, nwl=nwl)
+        assert got == oracle(a, b, 0xFFFFFFFF, trans), (trans, nwl)
+
+
+def test_widebits_many_lanes_and_chunks():
+    """Rows spread over all 64 lanes (2000+ bytes) and columns over many 64-byte chunks; null bytes; swapped roles."""
+    g = Dg.rng(9)
+    x = Dg.rand_str(g, 2048)
+    y = Dg.mutate(g, x, 150, True)
+    z = bytes(2000)
+    w = bytes([0] * 700 + [7] + [0] * 1299)
+    a = [x, y, x, z, w, x[:33], b"", x]
+    b = [y, x, Dg.rand_str(g, 1900), w, z, x[:2000], x[:100], x]
+    for trans in (False, True):
+        got = E.lev_widebits(a, b, 0xFFFFFFFF, trans, nwl=1, nwaves=2)
+        assert got == oracle(a, b, 0xFFFFFFFF, trans), trans
+    got = E.lev_widebits(a, b, 140, False, nwl=2, nwaves=1)
+    assert got == oracle(a, b, 140, False)
+
+
+def test_widebits_4k_pair():
+    """BASELINE cfg3 geometry: one 4 KiB pair, 64 rows per lane."""
+    g = Dg.rng(0x7A03)
+    x, y = Dg.rand_str(g, 4096), Dg.rand_str(g, 4096)
+    ym = Dg.mutate(g, x, 500, False)
+    got = E.lev_widebits([x, x], [y, ym], 0xFFFFFFFF, False, nwl=2, nwaves=1)
+    assert got == [O.levenshtein(x, y), O.levenshtein(x, ym)]

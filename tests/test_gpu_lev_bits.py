@@ -21,7 +21,7 @@ def kernel_id():
 @pytest.mark.parametrize("costs", [LEV, RDAM])
 def test_bits_ragged_vs_oracle(costs):
     a, b = ragged_pairs(21, 6000, 80, 10, costs[3] is not None)
-    for k in (0, 1, 2, 3, 7, 12, 30, 47, 61):
+    for k in (0, 1, 2, 3, 7, 12, 30, 47, 61, 64, 100, 125):
         got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
         assert kernel_id() == 3
         assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
@@ -29,7 +29,7 @@ def test_bits_ragged_vs_oracle(costs):
 
 def test_bits_every_window_width(monkeypatch):
     a, b = ragged_pairs(22, 3000, 90, 9, True)
-    for na in range(1, 17):
+    for na in list(range(1, 17)) + list(range(18, 33, 2)):
         monkeypatch.setenv("TA_FORCE_NA", str(na))
         for costs in (LEV, RDAM):
             k = max(0, min(4 * na - 1 - (2 if costs[3] else 0), 9))
@@ -54,9 +54,9 @@ def test_bits_chunk_lengths_and_long_strings(monkeypatch):
 
 
 def test_unit_costs_beyond_the_window_use_the_dp_kernel():
-    """unit_k > 63 (61 with transpositions) does not fit the 64-bit window: the planner falls back to the DP band."""
-    a, b = ragged_pairs(23, 2000, 200, 30, True)
-    for k, costs in [(64, LEV), (62, RDAM), (150, LEV)]:
+    """unit_k > 127 (125 with transpositions) does not fit the 128-bit window: the planner falls back to the DP band."""
+    a, b = ragged_pairs(23, 2000, 400, 30, True)
+    for k, costs in [(128, LEV), (126, RDAM), (250, LEV)]:
         got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
         assert kernel_id() == 1
         assert np.array_equal(got, want), (k, costs)
@@ -66,7 +66,7 @@ def test_dp_kernel_still_covers_unit_costs(monkeypatch):
     """TA_NO_BITS=1 routes the unit-cost families through the general DP band kernel (planner's own layout)."""
     monkeypatch.setenv("TA_NO_BITS", "1")
     a, b = ragged_pairs(24, 5000, 80, 10, True)
-    for k in (0, 3, 12, 32, 61):
+    for k in (0, 3, 12, 32, 61, 100):
         for costs in (LEV, RDAM):
             got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
             assert kernel_id() == 1
@@ -95,3 +95,71 @@ def test_full_size_bits_equals_dp(wl, monkeypatch):
     want = O.levenshtein_k_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx]), k, costs)
     assert np.array_equal(bits[idx], want)
     torch.cuda.synchronize()
+
+
+def long_pairs(seed, lens, kmut):
+    g = Dg.rng(seed)
+    a, b = [], []
+    for n in lens:
+        x = Dg.rand_str(g, n)
+        a += [x, x, x, x[: n // 3], x]
+        b += [Dg.mutate(g, x, kmut, True), Dg.rand_str(g, max(0, n - 17)), x, x, Dg.mutate(g, x, 3 * kmut, True)]
+    return a, b
+
+
+@pytest.mark.parametrize("rows", [32, 64])
+def test_widebits_forced_vs_oracle(rows, monkeypatch):
+    """The row-blocked bit-parallel kernel on everything it may be given: short to 2 KiB / 4 KiB strings, both cost
+    families, bounded and unbounded k."""
+    monkeypatch.setenv("TA_FORCE_WIDEBITS", str(rows))
+    top = 2048 if rows == 32 else 4096
+    a, b = long_pairs(31 + rows, (1, 5, 31, 32, 33, 64, 65, 200, 777, top // 2 + 1, top - 200), 40)   # mutations may add up to 120 bytes
+    a += [Dg.rand_str(Dg.rng(1), top)]; b += [Dg.rand_str(Dg.rng(2), top)]
+    a += [b"", b"", b"\0" * 100]; b += [b"", b"abc", b"\0" * 90 + b"\1"]
+    for k, costs in [(0xFFFFFFFF, LEV), (0xFFFFFFFF, RDAM), (150, LEV), (130, RDAM), (1000, LEV)]:
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert kernel_id() == 4
+        assert np.array_equal(got, want), (rows, k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_widebits_small_alphabet(monkeypatch):
+    monkeypatch.setenv("TA_FORCE_WIDEBITS", "32")
+    g = Dg.rng(8)
+    a = [bytes(g.integers(97, 100, size=int(g.integers(0, 900))).astype(np.uint8)) for _ in range(300)]
+    b = [bytes(g.integers(97, 100, size=int(g.integers(0, 900))).astype(np.uint8)) for _ in range(300)]
+    for costs in (LEV, RDAM):
+        got, want = gpu_k(a, b, 0xFFFFFFFF, costs), oracle_k(a, b, 0xFFFFFFFF, costs)
+        assert kernel_id() == 4
+        assert np.array_equal(got, want), (costs, np.flatnonzero(got != want)[:10])
+
+
+def test_long_unit_cost_pairs_pick_widebits_by_themselves():
+    import triple_accel_amd as T
+    g = Dg.rng(3)
+    x = Dg.rand_str(g, 3000)
+    y = Dg.mutate(g, x, 100, True)
+    assert T.levenshtein(x, y) == O.levenshtein(x, y)
+    assert kernel_id() == 4
+    assert T.rdamerau(x, y) == O.rdamerau(x, y)
+    assert kernel_id() == 4
+    z = Dg.rand_str(g, 2800)
+    assert T.levenshtein_exp(x, z) == O.levenshtein_exp(x, z)
+    assert T.rdamerau_exp(z, x) == O.rdamerau_exp(z, x)
+
+
+def test_widebits_equals_dp_on_cfg3_shape(monkeypatch):
+    """BASELINE cfg3 geometry (4 KiB pairs): levenshtein_exp through the bit-parallel kernels == through the DP kernels
+    == oracle on a sample (the DP path is the slow one: keep the batch small)."""
+    from triple_accel_amd import batch as B
+    n = 192
+    ar, br = Dg.pairs_random(0x7B03, n // 2, 4096)
+    am, bm = Dg.pairs_mutated_fixed(0x7B13, n // 2, 4096, 300)
+    a, b = np.concatenate([ar, am]), np.concatenate([br, bm])
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    bits = B.levenshtein_exp_batch(sa, sb).cpu().numpy().view(np.uint32)
+    monkeypatch.setenv("TA_NO_BITS", "1")
+    dp = B.levenshtein_exp_batch(sa, sb).cpu().numpy().view(np.uint32)
+    assert np.array_equal(bits, dp)
+    idx = np.r_[0:8, n - 8:n]
+    want = O.levenshtein_exp_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx]))
+    assert np.array_equal(bits[idx], want)

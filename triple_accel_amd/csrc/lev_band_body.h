@@ -28,7 +28,8 @@ namespace ta {
 
 constexpr uint32_t LEV_INF = 0x3FFFFFFFu;   // "unreachable"; real costs stay far below (n+m < 2^22)
 // Streamed chunk = P.ch iterations (= bytes per string; 16, 32 or 64, lev_plan.h), ring = 2 chunks per (pair, string)
-// slot in LDS, slot stride = ring + 4: an odd number of dwords, so the per-pair byte reads hit distinct banks.
+// slot in LDS, slot stride = ring + 4: an odd number of dwords, so the per-pair byte reads hit distinct banks
+// (slot order: the PW rings of `a`, then the PW rings of `b`).
 constexpr uint32_t lev_slot_bytes(uint32_t ch) { return 2u * ch + 4u; }
 
 struct LevParams {
@@ -217,7 +218,7 @@ struct LevBand {
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
             auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, bptr, aptr), idx0), ok);
-            U32 slot = grp * 2u + W::sel(isb, W::splat(1), W::splat(0));
+            U32 slot = grp + W::sel(isb, W::splat(P.PW), W::splat(0));   // all `a` rings, then all `b` rings
             W::lds_store16(lds, slot * lev_slot_bytes(CH) + (y0 & (2u * CH - 1u)), q, pred);
         }
     }
@@ -282,7 +283,7 @@ struct LevBand {
         U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
 
         const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
-        const U32 a_slot = (grp * 2u) * lev_slot_bytes(CH), b_slot = (grp * 2u + 1u) * lev_slot_bytes(CH);
+        const U32 a_slot = grp * lev_slot_bytes(CH), b_slot = (grp + P.PW) * lev_slot_bytes(CH);
 
         // iterations before min(ca, cb) would only shift zeros into zero windows: start there
         const uint32_t hfar = W::wave_max(W::sel(active, W::sel(h + h >= L * Dh, h, W::splat(L * Dh) - h), W::splat(0)));

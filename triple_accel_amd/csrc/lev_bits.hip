@@ -35,6 +35,7 @@ hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans
 #define TA_CASE(n) case n: return launch_na<n>(P, trans, grid, lds, s);
         TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)
         TA_CASE(9) TA_CASE(10) TA_CASE(11) TA_CASE(12) TA_CASE(13) TA_CASE(14) TA_CASE(15) TA_CASE(16)
+        TA_CASE(18) TA_CASE(20) TA_CASE(22) TA_CASE(24) TA_CASE(26) TA_CASE(28) TA_CASE(30) TA_CASE(32)
 #undef TA_CASE
         default: return hipErrorInvalidValue;
     }

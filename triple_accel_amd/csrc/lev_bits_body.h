@@ -154,7 +154,7 @@ struct LevBits {
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
         const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
-        const U32 a_slot = (grp * 2u) * lev_slot_bytes(CH), b_slot = (grp * 2u + 1u) * lev_slot_bytes(CH);
+        const U32 a_slot = grp * lev_slot_bytes(CH), b_slot = (grp + 64u) * lev_slot_bytes(CH);
         const uint32_t kc0 = tp0 / CH;
         Loader::load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
         Loader::load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
@@ -168,19 +168,29 @@ struct LevBits {
             const uint32_t t_lo = kc * CH;
             const uint32_t t_hi = (t_lo + CH < iters) ? t_lo + CH : iters;
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
-            for (; tp < t_hi && tp < T0; tp++)                 // warm-up: rows 1..nlo slide in
-                advance_a(st, W::lds_u8(lds, a_slot + ((da + tp) & RMASK)));
-            if (!W::any(t_stop < t_hi)) {                      // every pair still has columns up to the chunk's end
+            // the two ring bytes of iteration tp + 1 are fetched while iteration tp computes (the ring always holds the
+            // next chunk already), so no column waits on LDS latency
+            U32 a_nx = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
+            U32 b_nx = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
+            for (; tp < t_hi && tp < T0; tp++) {               // warm-up: rows 1..nlo slide in
+                const U32 a_in = a_nx;
+                a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
+                b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
+                advance_a(st, a_in);
+            }
+            if (!W::any(valid & (t_stop < t_hi))) {            // every pair still has columns up to the chunk's end
                 for (; tp < t_hi; tp++) {
-                    const U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
-                    const U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
+                    const U32 a_in = a_nx, b_in = b_nx;
+                    a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
+                    b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
                     advance_a(st, a_in);
                     column<false>(st, b_in, M, cnt, active);
                 }
             } else {
                 for (; tp < t_hi; tp++) {
-                    const U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
-                    const U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
+                    const U32 a_in = a_nx, b_in = b_nx;
+                    a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
+                    b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
                     advance_a(st, a_in);
                     column<true>(st, b_in, M, cnt, t_stop > tp);
                 }

@@ -89,7 +89,7 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32
 }
 
 // ---- bit-parallel band kernel (lev_bits_body.h): unit costs only, one pair per lane, window of 4*NA diagonals
-static const int LEV_BITS_MAX_NA = 16;
+static const int LEV_BITS_MAX_NA = 32;      // kernels exist for NA = 1..16 and the even NA up to 32
 
 struct LevBitsPlan {
     bool ok;                 // false: costs are not a unit-cost family, or the band is wider than the window
@@ -106,6 +106,7 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     const uint64_t w = (uint64_t)p.u + 1u + (has_t ? 2u : 0u);     // the transposition test looks one row past each band edge
     uint64_t na = (w + 3) / 4;
     if (force_NA > 0 && (uint64_t)force_NA >= na) na = (uint64_t)force_NA;
+    if (na > 16) na += na & 1;
     if (na > (uint64_t)LEV_BITS_MAX_NA) { p.ok = false; na = LEV_BITS_MAX_NA; }
     p.NA = (int)na;
     p.ch = (force_ch == 16 || force_ch == 32 || force_ch == 64) ? (uint32_t)force_ch : 32u;
@@ -114,6 +115,41 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     // chunks of `b` on 64-byte lines
     p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;
     return p;
+}
+
+// ---- which kernel runs a k-bounded pass, and roughly what it costs (wave-instructions per pair; only ratios matter)
+enum LevKernel { LEV_K_BAND = 1, LEV_K_WIDE = 2, LEV_K_BITS = 3, LEV_K_WIDEBITS = 4 };
+
+struct LevChoice {
+    int kernel;              // LevKernel
+    int rows_per_lane;       // LEV_K_WIDEBITS: 32 or 64
+    double cost;
+};
+
+static inline LevChoice lev_choose(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len,
+                                   bool dp_only) {
+    const double n = (double)(max_len ? max_len : 1);
+    const LevBitsPlan bp = lev_bits_make_plan(k, mc, gc, sg, has_t, tc, max_len);
+    const LevPlan pl = lev_make_plan(k, mc, gc, sg, max_len, 0, 0);
+    const bool unit = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1);
+    LevChoice c;
+    if (bp.ok && !dp_only) {                                   // one pair per lane, ~6 instructions per window dword + 25
+        c.kernel = LEV_K_BITS; c.rows_per_lane = 0;
+        c.cost = n * (6.0 * bp.NA + 25.0 + (has_t ? 8.0 : 0.0)) / 64.0;
+        return c;
+    }
+    // DP band: (4.5 D + 25) instructions per iteration, shared by the PW pairs of a wave; wide DP kernel: ~6 per cell
+    const double band = pl.ok ? n * (4.5 * pl.D + 25.0 + (has_t ? 1.5 * pl.D : 0.0)) / pl.PW : 1e300;
+    const double uu = pl.u < n ? (double)pl.u : n;
+    const double wide = (2.0 * n * uu - uu * uu) * 6.0 / 64.0 + n * 40.0;
+    c.kernel = band <= wide ? LEV_K_BAND : LEV_K_WIDE; c.rows_per_lane = 0;
+    c.cost = band <= wide ? band : wide;
+    if (unit && !dp_only && max_len <= 4096) {                 // one pair per wave, one column of all rows per ~40 instructions
+        const int rpl = max_len > 2048 ? 64 : 32;
+        const double wb = (n + n / rpl) * (rpl == 64 ? 40.0 : 30.0) + (has_t ? n * 10.0 : 0.0) + 600.0;
+        if (wb < c.cost) { c.kernel = LEV_K_WIDEBITS; c.rows_per_lane = rpl; c.cost = wb; }
+    }
+    return c;
 }
 
 }  // namespace ta

@@ -1,0 +1,197 @@
+// lev_widebits_body.h -- bit-parallel FULL-COLUMN Levenshtein / restricted-Damerau for long unit-cost pairs:
+// levenshtein(), rdamerau() and the last rounds of levenshtein_exp (src/levenshtein.rs:1397-1526) on strings of
+// a few hundred bytes to 4 KiB, where the band is (nearly) the whole matrix.
+//
+// One pair per wavefront.  The shorter string is laid along the rows; lane t owns RB = 32*NWL consecutive rows as
+// NWL-dword bit-vectors of vertical differences (Pv: +1, Mv: -1; Myers 1999, in Hyyro's D0 form as in
+// lev_bits_body.h).  The lanes run skewed -- at step s lane t computes column s - t + 1 -- so the only cross-lane
+// traffic per step is what the block below needs from the block above for the same column, produced one step
+// earlier: the top bits of the horizontal difference vectors (and of Hyyro's transposition term) plus the column's
+// character, four DPP wave_shr:1 moves.
+//
+// The rows of a lane never change during a pair, so the match vector of a column is a table lookup instead of 64
+// byte compares: per lane two 16-entry tables in LDS, indexed by the high and the low nibble of the column's
+// character (Eq = Hi[c >> 4] & Lo[c & 15]), built once per pair with 2 ds_or_b32 per row.  A 17th Hi row stays
+// zero: character code 256 = "no character", used for the virtual columns a lane sees before its first real one.
+// Those virtual columns need no predication: with D[i][j] = i + |j| for j <= 0 the state Pv = ~0, Mv = 0 is a fixed
+// point of the step when the block above reports a horizontal difference of -1 and nothing matches.
+//
+// Result: d = m + sum over lanes of (popcount(Pv) - popcount(Mv)) over rows <= n at column m;  out = d <= k ? d : None.
+#pragma once
+#include "lev_band_body.h"
+
+namespace ta {
+
+template <class W, int NWL, bool TRANS>
+struct LevWideBits {
+    static_assert(NWL == 1 || NWL == 2, "32 or 64 rows per lane");
+    static constexpr uint32_t RB = 32u * NWL;                    // rows per lane
+    static constexpr uint32_t LO_BASE = 17u * 64u * NWL * 4u;    // byte offset of the low-nibble tables
+    static constexpr uint32_t LDS_BYTES = 33u * 64u * NWL * 4u;
+    using U32 = typename W::U32;
+    using Bool = typename W::Bool;
+    using Ptr = typename W::Ptr;
+
+    struct State {
+        U32 Pv[NWL], Mv[NWL], D0p[NWL], Eqp[NWL];
+        U32 sP, sM, sX, sc;      // what the lane below reads next step: top dwords of Ph, Mh, X, and the character
+    };
+
+    static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&Eq)[NWL]) {
+        const U32 hi = (c >> 4) * (64u * NWL * 4u) + lane_off;
+        const U32 lo = (c & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE;
+#pragma unroll
+        for (int q = 0; q < NWL; q++) Eq[q] = W::lds_read32(lds, hi + 4u * q) & W::lds_read32(lds, lo + 4u * q);
+    }
+
+    // one column for every lane; rP/rM/rX = top dwords handed down by the lane above (row 0 boundary for lane 0)
+    static TA_HD inline __attribute__((always_inline)) void step(State &st, const U32 (&Eq)[NWL], U32 c, U32 rP, U32 rM, U32 rX) {
+        U32 D0[NWL], X[NWL], Ph[NWL], Mh[NWL];
+        const U32 hN = rM >> 31;                                  // the row above stepped -1 along this column pair
+        Bool carry = W::bfalse();
+#pragma unroll
+        for (int q = 0; q < NWL; q++) {
+            const U32 e = q == 0 ? (Eq[0] | hN) : Eq[q];
+            U32 s;
+            W::addc(e & st.Pv[q], st.Pv[q], carry, s, carry);
+            D0[q] = ((s ^ st.Pv[q]) | e) | st.Mv[q];
+        }
+        if (TRANS) {
+            // D0 |= ((~D0_prev & Eq) << 1) & Eq_prev  (Hyyro 2003; src/levenshtein.rs:517-525), the shift crossing lanes
+#pragma unroll
+            for (int q = 0; q < NWL; q++) X[q] = ~st.D0p[q] & Eq[q];
+#pragma unroll
+            for (int q = 0; q < NWL; q++)
+                D0[q] = D0[q] | (W::template alignbit<31>(X[q], q ? X[q - 1] : rX) & st.Eqp[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NWL; q++) {
+            Ph[q] = st.Mv[q] | ~(D0[q] | st.Pv[q]);
+            Mh[q] = D0[q] & st.Pv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NWL; q++) {
+            const U32 Phs = W::template alignbit<31>(Ph[q], q ? Ph[q - 1] : rP);
+            const U32 Mhs = W::template alignbit<31>(Mh[q], q ? Mh[q - 1] : rM);
+            st.Pv[q] = Mhs | ~(D0[q] | Phs);
+            st.Mv[q] = Phs & D0[q];
+            if (TRANS) { st.D0p[q] = D0[q]; st.Eqp[q] = Eq[q]; }
+        }
+        st.sP = Ph[NWL - 1]; st.sM = Mh[NWL - 1]; st.sc = c;
+        if (TRANS) st.sX = X[NWL - 1];
+    }
+
+    // Step s of the skewed sweep.  TAIL: lane 0 has passed the last column; lanes t <= s - m hold column m and freeze.
+    template <bool TAIL>
+    static TA_HD inline __attribute__((always_inline)) void iter(State &st, const uint8_t *lds, U32 lane, U32 lane_off, Ptr bp,
+                                                                uint32_t m, uint32_t s, U32 &cb, U32 &c, U32 (&Eq)[NWL]) {
+        // next step's character and match vector first: the LDS lookups overlap this step's arithmetic
+        if (!TAIL && ((s + 1u) & 63u) == 0u) cb = W::gload_u8(W::ptr_add(bp, lane + (s + 1u)), (lane + (s + 1u)) < m);
+        const uint32_t b_next = (!TAIL && s + 1u < m) ? W::readlane(cb, (s + 1u) & 63u) : 256u;
+        const U32 c_next = W::from_lower(c, W::splat(b_next));
+        U32 Eq_next[NWL];
+        lookup(lds, c_next, lane_off, Eq_next);
+        const U32 rP = W::from_lower(st.sP, W::splat(0x80000000u));   // row 0: D[0][j] - D[0][j-1] = +1
+        const U32 rM = W::from_lower(st.sM, W::splat(0));
+        const U32 rX = TRANS ? W::from_lower(st.sX, W::splat(0)) : W::splat(0);
+        if (!TAIL) {
+            step(st, Eq, c, rP, rM, rX);
+        } else {
+            State nx = st;
+            step(nx, Eq, c, rP, rM, rX);
+            const Bool done = lane <= (s - m);
+#pragma unroll
+            for (int q = 0; q < NWL; q++) {
+                st.Pv[q] = W::sel(done, st.Pv[q], nx.Pv[q]); st.Mv[q] = W::sel(done, st.Mv[q], nx.Mv[q]);
+                st.D0p[q] = nx.D0p[q]; st.Eqp[q] = nx.Eqp[q];
+            }
+            st.sP = nx.sP; st.sM = nx.sM; st.sX = nx.sX; st.sc = nx.sc;
+        }
+        c = c_next;
+#pragma unroll
+        for (int q = 0; q < NWL; q++) Eq[q] = Eq_next[q];
+    }
+
+    // wave `wave_slot` of `nwaves` resident waves walks the pairs slot, slot + nwaves, ...
+    static TA_HD inline void run(const LevParams &P, uint32_t wave_slot, uint32_t nwaves, uint8_t *lds) {
+        const U32 lane = W::lane();
+        const U32 lane_off = lane * (NWL * 4u);
+        const Bool all = (lane == lane);
+        for (uint32_t slot = wave_slot; slot < P.n; slot += nwaves) {
+            const U32 pair = P.subset ? W::load_u32(P.subset, W::splat(slot), all, 0u) : W::splat(slot);
+            Ptr xp, yp;
+            U32 xl, yl;
+            W::load_str(P.a, pair, all, xp, xl);
+            W::load_str(P.b, pair, all, yp, yl);
+            const uint32_t alen = W::readlane(xl, 0), blen = W::readlane(yl, 0);
+            const bool swap = alen > blen;                       // rows <- the shorter string (distance is symmetric)
+            const uint32_t n = swap ? blen : alen, m = swap ? alen : blen;
+            const Ptr ap = swap ? yp : xp, bp = swap ? xp : yp;
+            const Bool lane0 = (lane == 0u);
+            uint32_t res;
+            if (m - n > P.u) {
+                res = 0xFFFFFFFFu;                               // :426-428, :860-862
+            } else if (n == 0) {
+                res = m <= P.k ? m : 0xFFFFFFFFu;                // one gap run (or two empty strings)
+            } else {
+                // ---- per-lane nibble tables of this lane's rows [lane*RB, lane*RB + RB)
+#pragma unroll 1
+                for (uint32_t e = 0; e < 33u; e++) {
+#pragma unroll
+                    for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * (64u * NWL * 4u) + 4u * q, W::splat(0));
+                }
+                W::lds_wave_sync();
+                const U32 row0 = lane * RB;
+#pragma unroll 1
+                for (uint32_t r0 = 0; r0 < RB; r0 += 16) {
+                    const U32 i0 = row0 + r0;
+                    auto piece = W::gload16(W::ptr_add(ap, i0), i0 < n);   // blobs carry 16 bytes of slack (TA_BLOB_SLACK)
+                    const U32 w4[4] = {W::qword(piece, 0), W::qword(piece, 1), W::qword(piece, 2), W::qword(piece, 3)};
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const U32 ch = W::byte_of(w4[r >> 2], r & 3);
+                        const Bool ok = (i0 + (uint32_t)r) < n;
+                        const uint32_t bit = 1u << ((r0 + r) & 31u), qo = 4u * ((r0 + r) >> 5);
+                        W::lds_or32(lds, (ch >> 4) * (64u * NWL * 4u) + lane_off + qo, W::splat(bit), ok);
+                        W::lds_or32(lds, (ch & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE + qo, W::splat(bit), ok);
+                    }
+                }
+                W::lds_wave_sync();
+
+                State st;
+#pragma unroll
+                for (int q = 0; q < NWL; q++) {
+                    st.Pv[q] = W::splat(0xFFFFFFFFu); st.Mv[q] = W::splat(0);
+                    st.D0p[q] = W::splat(0xFFFFFFFFu); st.Eqp[q] = W::splat(0);
+                }
+                st.sP = W::splat(0); st.sM = W::splat(0x80000000u); st.sX = W::splat(0); st.sc = W::splat(256);
+                const uint32_t t_last = (n - 1u) / RB;           // lane holding row n
+                const uint32_t steps = m + t_last;
+
+                U32 cb = W::gload_u8(W::ptr_add(bp, lane), lane < m);
+                U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
+                U32 Eq[NWL];
+                lookup(lds, c, lane_off, Eq);
+                uint32_t s = 0;
+                for (; s < m; s++) iter<false>(st, lds, lane, lane_off, bp, m, s, cb, c, Eq);
+                for (; s < steps; s++) iter<true>(st, lds, lane, lane_off, bp, m, s, cb, c, Eq);   // <= 63 draining steps
+                // D[n][m] = D[0][m] + vertical differences of column m over rows 1..n
+                U32 contrib = W::splat(0);
+#pragma unroll
+                for (int q = 0; q < NWL; q++) {
+                    const uint32_t lo = 32u * (uint32_t)q;
+                    const U32 first = row0 + lo;                 // 0-based index of this dword's first row
+                    const U32 cnt = W::sel(first >= n, W::splat(0), W::sel(first + 32u <= n, W::splat(32), W::splat(n) - first));
+                    const U32 msk = W::sel(cnt >= 32u, W::splat(0xFFFFFFFFu), W::shlv(W::splat(1), cnt) - 1u);
+                    contrib = W::bcnt(st.Pv[q] & msk, contrib);
+                    contrib = contrib - W::bcnt(st.Mv[q] & msk, W::splat(0));
+                }
+                const uint32_t d = m + W::wave_sum(contrib);
+                res = d <= P.k ? d : 0xFFFFFFFFu;                 // :539-541
+            }
+            W::store_u32(P.out, pair, W::splat(res), lane0);
+        }
+    }
+};
+
+}  // namespace ta

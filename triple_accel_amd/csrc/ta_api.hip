@@ -98,16 +98,28 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     ta_lev_select sel;
     ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
     li.cell_bits = sel.cell_bits;
-    // unit-cost families (levenshtein(), rdamerau(), levenshtein_simd_k(), the exp loop): bit-parallel columns
-    const LevBitsPlan bp = lev_bits_make_plan(k, c->mismatch_cost, gc, sg, trans, c->has_transpose ? c->transpose_cost : 0, max_len,
-                                              env_int("TA_FORCE_NA"), env_int("TA_FORCE_CH"));
+    // unit-cost families (levenshtein(), rdamerau(), levenshtein_simd_k(), the exp loop) have bit-parallel kernels
+    const uint32_t tcost = c->has_transpose ? c->transpose_cost : 0;
+    const LevBitsPlan bp = lev_bits_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, env_int("TA_FORCE_NA"), env_int("TA_FORCE_CH"));
     const bool dp_forced = env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L") || env_int("TA_FORCE_AFFINE") ||
                            env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
-    if (bp.ok && !dp_forced) {
+    LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced);
+    const bool unit = c->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || tcost == 1);
+    if (env_int("TA_FORCE_WIDEBITS") && unit && max_len <= 4096 && !dp_forced) {
+        ch.kernel = LEV_K_WIDEBITS;
+        ch.rows_per_lane = env_int("TA_FORCE_WIDEBITS") == 32 && max_len <= 2048 ? 32 : (env_int("TA_FORCE_WIDEBITS") == 64 || max_len > 2048 ? 64 : 32);
+    }
+    if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits_launch(P, bp, trans, st, &grid, &lds));
         li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
+        li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
+    } else if (ch.kernel == LEV_K_WIDEBITS) {
+        P.u = bp.u; P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+        uint32_t grid = 0, lds = 0;
+        TA_HIP(lev_widebits_launch(P, ch.rows_per_lane, trans, st, &grid, &lds));
+        li.kernel = 4; li.diags_per_lane = (uint32_t)ch.rows_per_lane; li.lanes_per_pair = 64; li.pairs_per_wave = 1;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else if (pl.ok && !env_int("TA_FORCE_WIDE")) {
         P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
@@ -277,13 +289,14 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         flip ^= 1;
         n_work = left;
         k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
-        // Once the next bounded pass (about nn * unit_k cells) would cost more than a quarter of the matrix, it is
-        // cheaper in expectation to finish the unresolved pairs with k = u32::MAX right away (same return values --
-        // levenshtein_exp returns the distance, whatever k schedule finds it; on random 4 KiB pairs this skips the
-        // k = 1920 and 3840 passes of the reference loop).
-        const double nn = (double)(max_len ? max_len : 1);
-        double u = (double)lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
-        if (u > 0.25 * nn && !env_int("TA_EXP_FAITHFUL")) k = 0xFFFFFFFFu;
+        // Once the next bounded pass would cost more than a quarter of the unbounded one (kernel cost model, lev_plan.h),
+        // it is cheaper in expectation to finish the unresolved pairs with k = u32::MAX right away (same return values
+        // -- levenshtein_exp returns the distance, whatever k schedule finds it).
+        const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
+        const bool dpo = env_int("TA_NO_BITS") != 0;
+        const double c_next = lev_choose(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo).cost;
+        const double c_full = lev_choose(0xFFFFFFFFu, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo).cost;
+        if (c_next > 0.25 * c_full && !env_int("TA_EXP_FAITHFUL")) k = 0xFFFFFFFFu;
     }
     return TA_OK;
 }

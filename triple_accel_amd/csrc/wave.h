@@ -144,6 +144,7 @@ struct DevWave {
         }
         return q;
     }
+    static __device__ __forceinline__ U32 qword(const Q128 &q, int i) { return i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w; }
     static __device__ __forceinline__ void lds_store16(uint8_t *lds, U32 off, Q128 q, Bool pred) {
         if (pred) {   // 4-byte aligned only (slot stride is an odd number of dwords)
             uint32_t *d = (uint32_t *)(lds + off);
@@ -151,6 +152,19 @@ struct DevWave {
         }
     }
     static __device__ __forceinline__ U32 lds_u8(const uint8_t *lds, U32 off) { return lds[off]; }
+    // lane-private dwords in LDS (4-byte aligned offsets)
+    static __device__ __forceinline__ U32 lds_read32(const uint8_t *lds, U32 off) { return *(const uint32_t *)(lds + off); }
+    static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
+    static __device__ __forceinline__ void lds_or32(uint8_t *lds, U32 off, U32 v, Bool pred) {   // ds_or_b32, no return
+        if (pred) (void)__hip_atomic_fetch_or((uint32_t *)(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    // value of x in lane l (l wave-uniform) -> v_readlane_b32
+    static __device__ __forceinline__ uint32_t readlane(U32 x, uint32_t l) { return __builtin_amdgcn_readlane(x, l); }
+    static __device__ __forceinline__ U32 gload_u8(Ptr p, Bool pred) { return pred ? (U32)*p : 0u; }
+    static __device__ __forceinline__ uint32_t wave_sum(U32 x) {
+        for (int m = 32; m >= 1; m >>= 1) x += shfl(x, lane() ^ (uint32_t)m);
+        return __builtin_amdgcn_readfirstlane(x);
+    }
     // this wave's LDS writes become visible to its own later LDS reads (same-wave DS ops are
     // ordered in hardware; this only stops the compiler from moving them)
     static __device__ __forceinline__ void lds_wave_sync() {
