@@ -8,7 +8,8 @@ timeout 900 python bench.py --workload cfg2 --dist mutated --no-cpu > $O/bench_c
 timeout 900 python bench.py --workload cfg4 --steps 20 --warmup 3 > $O/bench_cfg4.json 2>/dev/null
 timeout 900 python bench.py --workload cfg1 --steps 50 --warmup 5 > $O/bench_cfg1.json 2>/dev/null
 timeout 1500 python bench.py --workload cfg5 --steps 5 --warmup 2 > $O/bench_cfg5.json 2>/dev/null
-timeout 1500 python bench.py --workload cfg3 --steps 2 --warmup 1 > $O/bench_cfg3.json 2>/dev/null
+timeout 1500 python bench.py --workload cfg3 --steps 3 --warmup 1 > $O/bench_cfg3.json 2>/dev/null
+cd /tmp; rocprofv3 --kernel-trace --stats -d $O/kt3 -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py --workload cfg3 --steps 3 --warmup 1 --no-cpu > $O/kt3.log 2>&1; cp $O/kt3/kt_kernel_stats.csv $O/bench_cfg3_kernel_stats.csv; rm -rf $O/kt3; cd $GRAFT_REPO_ROOT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu > $O/kt.log 2>&1
 cp $O/kt/kt_kernel_stats.csv $O/bench_cfg2_kernel_stats.csv
@@ -23,7 +24,7 @@ for d in glob.glob(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/final/pmc_*"):
     rows=list(csv.DictReader(open(d+"/p_counter_collection.csv")))
     agg=collections.defaultdict(list)
     for r in rows:
-        if 'lev_band' in r['Kernel_Name'] and int(r['Grid_Size'])>100000: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'lev_bits' in r['Kernel_Name'] and int(r['Grid_Size'])>100000: agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items(): out[k]={"mean_per_launch":sum(v)/len(v),"launches":len(v)}
 json.dump(out,open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/final/bench_cfg2_pmc.json","w"),indent=1)
 print(json.dumps(out)[:900])

@@ -12,12 +12,12 @@ template <int NA, bool TRANS>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, NA, TRANS>::run(P, blockIdx.x * BITS_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+    LevBits<DevWave, NA, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
 template <int NA>
-static hipError_t launch_na(const LevParams &P, bool trans, uint32_t grid, size_t lds, hipStream_t s) {
-    dim3 g(grid), b(64 * BITS_WAVES_PER_BLOCK);
+static hipError_t launch_na(const LevParams &P, bool trans, uint32_t grid, uint32_t wpb, size_t lds, hipStream_t s) {
+    dim3 g(grid), b(64 * wpb);
     if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true>), g, b, lds, s, P);
     else hipLaunchKernelGGL((lev_bits_kernel<NA, false>), g, b, lds, s, P);
     return hipGetLastError();
@@ -26,13 +26,16 @@ static hipError_t launch_na(const LevParams &P, bool trans, uint32_t grid, size_
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out,
                            uint32_t *lds_out) {
     const uint32_t waves = (P.n + 63u) / 64u;
-    const uint32_t grid = (waves + BITS_WAVES_PER_BLOCK - 1) / BITS_WAVES_PER_BLOCK;
-    const size_t lds = (size_t)pl.lds_per_wave * BITS_WAVES_PER_BLOCK;
+    // 4 waves per block while four rings fit a quarter of the CU's LDS; else one wave per block so that the CU packs
+    // as many waves as the LDS holds
+    const uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
+    const uint32_t grid = (waves + wpb - 1) / wpb;
+    const size_t lds = (size_t)pl.lds_per_wave * wpb;
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
     switch (pl.NA) {
-#define TA_CASE(n) case n: return launch_na<n>(P, trans, grid, lds, s);
+#define TA_CASE(n) case n: return launch_na<n>(P, trans, grid, wpb, lds, s);
         TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)
         TA_CASE(9) TA_CASE(10) TA_CASE(11) TA_CASE(12) TA_CASE(13) TA_CASE(14) TA_CASE(15) TA_CASE(16)
         TA_CASE(18) TA_CASE(20) TA_CASE(22) TA_CASE(24) TA_CASE(26) TA_CASE(28) TA_CASE(30) TA_CASE(32)

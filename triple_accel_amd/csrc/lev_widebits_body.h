@@ -35,13 +35,16 @@ struct LevWideBits {
     struct State {
         U32 Pv[NWL], Mv[NWL], D0p[NWL], Eqp[NWL];
         U32 sP, sM, sX, sc;      // what the lane below reads next step: top dwords of Ph, Mh, X, and the character
+        U32 rP, rM, rX;          // ... as received; lane 0 never receives and keeps the row-0 boundary it was given once
     };
 
-    static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&Eq)[NWL]) {
+    // the two table rows of character c, NOT yet combined: the AND happens one step later, so the LDS reads of step
+    // s + 1 stay in flight during the arithmetic of step s
+    static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&T)[2 * NWL]) {
         const U32 hi = (c >> 4) * (64u * NWL * 4u) + lane_off;
         const U32 lo = (c & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE;
 #pragma unroll
-        for (int q = 0; q < NWL; q++) Eq[q] = W::lds_read32(lds, hi + 4u * q) & W::lds_read32(lds, lo + 4u * q);
+        for (int q = 0; q < NWL; q++) { T[q] = W::lds_read32(lds, hi + 4u * q); T[NWL + q] = W::lds_read32(lds, lo + 4u * q); }
     }
 
     // one column for every lane; rP/rM/rX = top dwords handed down by the lane above (row 0 boundary for lane 0)
@@ -84,16 +87,19 @@ struct LevWideBits {
     // Step s of the skewed sweep.  TAIL: lane 0 has passed the last column; lanes t <= s - m hold column m and freeze.
     template <bool TAIL>
     static TA_HD inline __attribute__((always_inline)) void iter(State &st, const uint8_t *lds, U32 lane, U32 lane_off, Ptr bp,
-                                                                uint32_t m, uint32_t s, U32 &cb, U32 &c, U32 (&Eq)[NWL]) {
+                                                                uint32_t m, uint32_t s, U32 &cb, U32 &c, U32 (&T)[2 * NWL]) {
+        U32 Eq[NWL];
+#pragma unroll
+        for (int q = 0; q < NWL; q++) Eq[q] = T[q] & T[NWL + q];
         // next step's character and match vector first: the LDS lookups overlap this step's arithmetic
         if (!TAIL && ((s + 1u) & 63u) == 0u) cb = W::gload_u8(W::ptr_add(bp, lane + (s + 1u)), (lane + (s + 1u)) < m);
         const uint32_t b_next = (!TAIL && s + 1u < m) ? W::readlane(cb, (s + 1u) & 63u) : 256u;
         const U32 c_next = W::from_lower(c, W::splat(b_next));
-        U32 Eq_next[NWL];
-        lookup(lds, c_next, lane_off, Eq_next);
-        const U32 rP = W::from_lower(st.sP, W::splat(0x80000000u));   // row 0: D[0][j] - D[0][j-1] = +1
-        const U32 rM = W::from_lower(st.sM, W::splat(0));
-        const U32 rX = TRANS ? W::from_lower(st.sX, W::splat(0)) : W::splat(0);
+        lookup(lds, c_next, lane_off, T);
+        st.rP = W::from_lower(st.sP, st.rP);      // lane 0 keeps 0x80000000: D[0][j] - D[0][j-1] = +1
+        st.rM = W::from_lower(st.sM, st.rM);      // lane 0 keeps 0
+        if (TRANS) st.rX = W::from_lower(st.sX, st.rX);
+        const U32 rP = st.rP, rM = st.rM, rX = st.rX;
         if (!TAIL) {
             step(st, Eq, c, rP, rM, rX);
         } else {
@@ -108,8 +114,6 @@ struct LevWideBits {
             st.sP = nx.sP; st.sM = nx.sM; st.sX = nx.sX; st.sc = nx.sc;
         }
         c = c_next;
-#pragma unroll
-        for (int q = 0; q < NWL; q++) Eq[q] = Eq_next[q];
     }
 
     // wave `wave_slot` of `nwaves` resident waves walks the pairs slot, slot + nwaves, ...
@@ -165,16 +169,17 @@ struct LevWideBits {
                     st.D0p[q] = W::splat(0xFFFFFFFFu); st.Eqp[q] = W::splat(0);
                 }
                 st.sP = W::splat(0); st.sM = W::splat(0x80000000u); st.sX = W::splat(0); st.sc = W::splat(256);
+                st.rP = W::splat(0x80000000u); st.rM = W::splat(0); st.rX = W::splat(0);
                 const uint32_t t_last = (n - 1u) / RB;           // lane holding row n
                 const uint32_t steps = m + t_last;
 
                 U32 cb = W::gload_u8(W::ptr_add(bp, lane), lane < m);
                 U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
-                U32 Eq[NWL];
-                lookup(lds, c, lane_off, Eq);
+                U32 T[2 * NWL];
+                lookup(lds, c, lane_off, T);
                 uint32_t s = 0;
-                for (; s < m; s++) iter<false>(st, lds, lane, lane_off, bp, m, s, cb, c, Eq);
-                for (; s < steps; s++) iter<true>(st, lds, lane, lane_off, bp, m, s, cb, c, Eq);   // <= 63 draining steps
+                for (; s < m; s++) iter<false>(st, lds, lane, lane_off, bp, m, s, cb, c, T);
+                for (; s < steps; s++) iter<true>(st, lds, lane, lane_off, bp, m, s, cb, c, T);   // <= 63 draining steps
                 // D[n][m] = D[0][m] + vertical differences of column m over rows 1..n
                 U32 contrib = W::splat(0);
 #pragma unroll
