@@ -67,3 +67,24 @@ extern "C" int emu_lev_search(const uint8_t *needle, uint32_t n, const uint8_t *
     for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];
     return 0;
 }
+
+// ---- bit-parallel candidate filter (lev_filter_body.h): flagged 64-column blocks of a tiled scan
+#include "lev_filter_body.h"
+
+extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, int has_t,
+                              uint64_t tile, uint64_t halo, uint64_t *blocks_out, uint64_t cap, uint64_t *count) {
+    if (n == 0 || n > 32 || tile == 0 || tile % FILTER_BLOCK) return 1;
+    uint32_t peq[256];
+    for (uint32_t c = 0; c < 256; c++) peq[c] = lev_filter_peq(needle, n, c);
+    std::vector<uint64_t> blocks;
+    for (uint64_t eb = 0; eb < h; eb += tile) {
+        const uint64_t ee = eb + tile < h ? eb + tile : h, cb = eb > halo ? eb - halo : 0;
+        auto pq = [&](uint32_t c) { return peq[c]; };
+        auto mk = [&](uint64_t b) { blocks.push_back(b); };
+        if (has_t) lev_filter_tile<true>(hay, pq, n, k, cb, eb, ee, mk);
+        else lev_filter_tile<false>(hay, pq, n, k, cb, eb, ee, mk);
+    }
+    *count = blocks.size();
+    for (uint64_t i = 0; i < blocks.size() && i < cap; i++) blocks_out[i] = blocks[i];
+    return 0;
+}

@@ -25,6 +25,9 @@ def lib():
         L.emu_lev_widebits.restype = C.c_int
         L.emu_lev_widebits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                        C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
+        L.emu_lev_filter.restype = C.c_int
+        L.emu_lev_filter.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
+                                     C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -119,3 +122,20 @@ def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False,
     for i in range(cnt.value):
         res.append((int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))))
     return res
+
+
+def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None):
+    """64-column blocks the bit-parallel filter flags (sorted list of block indices)."""
+    n = len(needle)
+    if halo is None:
+        halo = n + k + 2
+    hay = np.zeros(len(haystack) + 16, dtype=np.uint8)
+    hay[:len(haystack)] = np.frombuffer(haystack, dtype=np.uint8)
+    cap = len(haystack) // 64 + 2
+    out = np.zeros(cap, dtype=np.uint64)
+    cnt = C.c_uint64()
+    rc = lib().emu_lev_filter(needle, n, hay.ctypes.data, len(haystack), k, int(bool(trans)), tile, halo, out.ctypes.data, cap,
+                              C.byref(cnt))
+    if rc:
+        raise RuntimeError("emu_lev_filter rc=%d" % rc)
+    return sorted(int(x) for x in out[:cnt.value])

@@ -1,0 +1,40 @@
+"""not-gpu: the bit-parallel candidate filter (lev_filter_body.h) flags EXACTLY the 64-column blocks that hold an
+end position of cost <= k in the oracle's All-mode output -- so running the exact kernel on the flagged blocks only
+loses nothing."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+
+
+def oracle_blocks(needle, hay, k, costs):
+    hits = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, False)
+    return sorted({(end - 1) // 64 for (_, end, _) in hits if end > 0})
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_filter_blocks_equal_oracle_blocks(trans):
+    g = Dg.rng(41)
+    costs = RDAM if trans else LEV
+    for n in (1, 2, 5, 16, 31, 32):
+        needle = Dg.rand_str(g, n)
+        hay = Dg.planted_haystack(100 + n, needle, 6000, 300 + 7 * n, max(1, n // 3))
+        for k in sorted({0, 1, n // 4, n // 2, max(0, n - 1)}):
+            for tile in (64, 256, 1024):
+                got = E.lev_filter_blocks(needle, hay, k, trans, tile=tile)
+                assert got == oracle_blocks(needle, hay, k, costs), (n, k, tile, trans)
+
+
+def test_filter_small_alphabet_and_nulls():
+    g = Dg.rng(42)
+    for trans in (False, True):
+        costs = RDAM if trans else LEV
+        for n in (3, 8, 20, 32):
+            needle = bytes(g.integers(0, 3, size=n).astype(np.uint8))
+            hay = bytes(g.integers(0, 3, size=3000).astype(np.uint8))
+            for k in (0, 1, n // 3):
+                assert E.lev_filter_blocks(needle, hay, k, trans, tile=128) == oracle_blocks(needle, hay, k, costs), (n, k, trans)

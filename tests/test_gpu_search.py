@@ -157,3 +157,42 @@ def test_hamming_search_alignment_and_edges():
     hay = b"abcdefghij"
     assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(hay, B.haystack_tensor(hay), 0)] == [(0, 10, 0)]
     assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(b"ab", B.haystack_tensor(b"abxxab"), 0)] == [(0, 2, 0), (4, 6, 0)]
+
+
+def test_filter_path_equals_exact_kernel_on_a_large_shard(monkeypatch):
+    """Unit-cost searches with a short needle go through the bit-parallel candidate filter + the exact kernel on the
+    flagged blocks.  On a 64 MiB shard the hits must equal the exact kernel's over everything (TA_SEARCH_NOFILTER=1),
+    for both cost families, odd needle lengths, k = 0 .. n-1, odd shard lengths and a shifted base."""
+    import torch
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0xF117)
+    hay_np = Dg.random_bytes(g, (64 << 20) + 37)
+    needles = {n: Dg.random_bytes(g, n).tobytes() for n in (5, 17, 32)}
+    for n, needle in needles.items():
+        for pos in range(5000 + 100 * n, hay_np.size - 100, 1 << 19):        # a mutated copy every 512 KiB
+            mm = np.frombuffer(Dg.mutate(g, needle, max(1, n // 3), True), dtype=np.uint8)
+            hay_np[pos:pos + mm.size] = mm
+    hay = B.haystack_tensor(hay_np)
+    for n, needle in needles.items():
+        for k, costs in [(n // 2, (1, 1, 0, None)), (n // 3, (1, 1, 0, 1)), (0, (1, 1, 0, None)), (n - 1, (1, 1, 0, 1))]:
+            if k == n - 1 and n > 5:
+                continue                                                       # dense: covered below on a small shard
+            monkeypatch.delenv("TA_SEARCH_NOFILTER", raising=False)
+            got = B.levenshtein_search_dev(needle, hay, k, costs, base=1000, emit_from=1000 + 77)
+            monkeypatch.setenv("TA_SEARCH_NOFILTER", "1")
+            want = B.levenshtein_search_dev(needle, hay, k, costs, base=1000, emit_from=1000 + 77)
+            assert np.array_equal(got, want), (n, k, costs, len(got), len(want))
+            assert len(want) > 0 or k < n // 2                                  # the planted copies carry up to n/3 edits
+    torch.cuda.synchronize()
+
+
+def test_filter_falls_back_when_matches_are_dense():
+    """k close to the needle length: nearly every block is flagged, the host takes the exact kernel over everything."""
+    g = Dg.rng(77)
+    needle = g.integers(97, 100, size=6, dtype=np.uint8).tobytes()
+    hay = g.integers(97, 100, size=50000, dtype=np.uint8).tobytes()
+    for k in (2, 4, 5):
+        for costs in [(1, 1, 0, None), (1, 1, 0, 1)]:
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (k, costs, st)

@@ -1,6 +1,7 @@
 // lev_search.hip -- gfx950 kernels for levenshtein_search / hamming_search over a haystack shard in HBM.
 #include <hip/hip_runtime.h>
 
+#include "lev_filter_body.h"
 #include "lev_search_body.h"
 #include "ta_internal.h"
 
@@ -84,6 +85,109 @@ hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hip
     if (n <= 32) return launch_n<32>(P, trans, false, grid, s);
     hipLaunchKernelGGL(lev_search_mem_kernel, dim3(grid), dim3(256), 0, s, P, tiles);
     return hipGetLastError();
+}
+
+// ---- candidate filter + exact kernel on the flagged blocks (unit-cost families, needle <= 32 bytes)
+
+// One lane scans P.tile end positions (a multiple of 64) after P.halo bytes of left context and appends the index of
+// every 64-column block that holds a cost <= k to `list` (lev_filter_body.h).  The 256-entry match table of the
+// needle lives in LDS; the haystack is read 16 bytes per lane per load.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
+    __shared__ uint32_t peq[256];
+    peq[threadIdx.x] = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
+    __syncthreads();
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t emit_begin = tile * P.tile;
+    if (emit_begin >= P.hay_len) return;
+    uint64_t emit_end = emit_begin + P.tile;
+    if (emit_end > P.hay_len) emit_end = P.hay_len;
+    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+    const uint32_t k = P.k;
+    const uint8_t *hay = P.hay;
+    FilterState st;
+    lev_filter_reset(st, P.needle_len);
+    for (uint64_t i = col_begin; i < emit_begin; i++) lev_filter_step<TRANS>(st, peq[hay[i]]);   // left context
+    auto flag = [&](uint64_t col) {
+        const unsigned int idx = atomicAdd(list_count, 1u);
+        if (idx < list_cap) list[idx] = (uint32_t)(col / FILTER_BLOCK);
+    };
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    uint64_t i = emit_begin;
+    const uint64_t full_end = emit_begin + ((emit_end - emit_begin) & ~(uint64_t)(FILTER_BLOCK - 1));
+    u32x4u nxt = (i < full_end) ? *(const u32x4u *)(hay + i) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                        // whole 64-column blocks, 4 x 16 bytes
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32x4u cur = nxt;
+            if (i + 16u * (q + 1) < emit_end) nxt = *(const u32x4u *)(hay + i + 16u * (q + 1));   // blobs carry 16 bytes of slack
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t c = (cur[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                any |= lev_filter_step<TRANS>(st, peq[c]) <= k;
+            }
+        }
+        if (any) flag(i);
+        i += FILTER_BLOCK;
+    }
+    if (i < emit_end) {                                           // the shard's last, partial block
+        bool any = false;
+        for (uint64_t j = i; j < emit_end; j++) any |= lev_filter_step<TRANS>(st, peq[hay[j]]) <= k;
+        if (any) flag(i);
+    }
+}
+
+hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, uint32_t list_cap, unsigned int *list_count,
+                             hipStream_t s) {
+    if (P.hay_len == 0) return hipSuccess;
+    const uint64_t tiles = (P.hay_len + P.tile - 1) / P.tile;
+    const uint32_t grid = (uint32_t)((tiles + 255) / 256);
+    if (trans) hipLaunchKernelGGL(lev_filter_kernel<true>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+    else hipLaunchKernelGGL(lev_filter_kernel<false>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+    return hipGetLastError();
+}
+
+// the exact (cost, length) kernel on the flagged 64-column blocks only
+template <int N, bool TRANS>
+__global__ __launch_bounds__(64) void lev_search_list_kernel(SearchParams P, const uint32_t *list, uint32_t n_list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_list) return;
+    const uint64_t emit_begin = (uint64_t)list[t] * FILTER_BLOCK;
+    uint64_t emit_end = emit_begin + FILTER_BLOCK;
+    if (emit_end > P.hay_len) emit_end = P.hay_len;
+    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+    SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, P.anchored};
+    ta_match *hits = P.hits;
+    unsigned long long *count = P.count;
+    const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
+    lev_search_tile_packed<N, TRANS>(P.hay, P.needle, P.needle_len, C, col_begin, emit_begin, emit_end,
+                                     [=](uint64_t end, uint32_t len, uint32_t cost) {
+                                         const uint64_t gend = base + end;
+                                         if (gend <= emit_from) return;
+                                         unsigned long long idx = atomicAdd(count, 1ull);
+                                         if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
+                                     });
+}
+
+template <int N>
+static hipError_t launch_list_n(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s) {
+    const uint32_t grid = (n_list + 63) / 64;
+    if (trans) hipLaunchKernelGGL((lev_search_list_kernel<N, true>), dim3(grid), dim3(64), 0, s, P, list, n_list);
+    else hipLaunchKernelGGL((lev_search_list_kernel<N, false>), dim3(grid), dim3(64), 0, s, P, list, n_list);
+    return hipGetLastError();
+}
+
+hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s) {
+    if (n_list == 0) return hipSuccess;
+    switch (P.needle_len) {
+#define TA_N(x) case x: return launch_list_n<x>(P, trans, list, n_list, s);
+        TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)
+        TA_N(13) TA_N(14) TA_N(15) TA_N(16) TA_N(17) TA_N(18) TA_N(19) TA_N(20) TA_N(21) TA_N(22) TA_N(23) TA_N(24)
+        TA_N(25) TA_N(26) TA_N(27) TA_N(28) TA_N(29) TA_N(30) TA_N(31) TA_N(32)
+#undef TA_N
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // hamming_search: one lane per aligned group of 4 consecutive haystack offsets.  The lane loads the aligned dwords

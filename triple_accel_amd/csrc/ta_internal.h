@@ -69,6 +69,9 @@ struct SearchParams {
     unsigned long long *count;   // device
 };
 hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hipStream_t s);
+hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, uint32_t list_cap, unsigned int *list_count,
+                             hipStream_t s);
+hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
 
 }  // namespace ta

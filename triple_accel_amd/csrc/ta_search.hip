@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "lev_filter_body.h"
 #include "ta_internal.h"
 
 namespace ta {
@@ -105,7 +106,34 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     // packed cost/length kernel whenever every cost and length provably fits 16 bits
     bool packed = needle_len <= 32 && k <= 30000u && (uint64_t)P.tile + P.halo <= 60000u && !getenv("TA_SEARCH_UNPACKED");
     if (anchored) packed = needle_len <= 32 && k <= 30000u && h <= 60000u && !getenv("TA_SEARCH_UNPACKED");
-    TA_HIP(lev_search_launch(P, packed, costs->has_transpose != 0, st));
+    // Unit-cost families with a short needle: a bit-parallel scan (lev_filter_body.h) finds the 64-column blocks that hold
+    // a cost <= k, and only those go through the exact kernel.  With k >= needle_len every position matches: skip it.
+    const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 &&
+                      (!costs->has_transpose || costs->transpose_cost == 1);
+    bool filtered = false;
+    if (unit && !anchored && packed && needle_len <= 32 && k < needle_len && h >= 4096 && !getenv("TA_SEARCH_NOFILTER")) {
+        Scratch &ls = tls_scratch(5), &lc = tls_scratch(4);
+        uint64_t cap_list = h / FILTER_BLOCK + 2;
+        if (cap_list > (4u << 20)) cap_list = 4u << 20;
+        if ((rc = ls.ensure((size_t)cap_list * 4)) || (rc = lc.ensure(16))) return rc;
+        TA_HIP(hipMemsetAsync(lc.dev, 0, 4, st));
+        SearchParams F = P;
+        uint64_t ft = (h + 524287) / 524288;                          // ~2 sets of resident lanes, like pick_tile
+        if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
+        ft = (ft + FILTER_BLOCK - 1) / FILTER_BLOCK * FILTER_BLOCK;
+        if (const char *e = getenv("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
+        F.tile = (uint32_t)(ft > 0x7FFFFFC0ull ? 0x7FFFFFC0ull : ft);
+        TA_HIP(lev_filter_launch(F, costs->has_transpose != 0, (uint32_t *)ls.dev, (uint32_t)cap_list, (unsigned int *)lc.dev, st));
+        unsigned int n_list = 0;
+        TA_HIP(hipMemcpyAsync(&n_list, lc.dev, 4, hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+        // dense matches: the exact kernel over everything is cheaper than (64 + halo) columns per flagged block
+        if (n_list <= cap_list && (uint64_t)n_list * (FILTER_BLOCK + P.halo) < h / 2) {
+            TA_HIP(lev_search_list_launch(P, costs->has_transpose != 0, (const uint32_t *)ls.dev, n_list, st));
+            filtered = true;
+        }
+    }
+    if (!filtered) TA_HIP(lev_search_launch(P, packed, costs->has_transpose != 0, st));
     unsigned long long c = 0;
     TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
     TA_HIP(hipStreamSynchronize(st));
