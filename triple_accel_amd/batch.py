@@ -84,14 +84,15 @@ def hamming_batch(a: Strings, b: Strings, out=None):
 
 # ---------------------------------------------------------------- search on a haystack shard resident in HBM
 def _hits_to_numpy(hits_t, count):
+    """(start, end, k) rows sorted by end.  An end position is reported at most once per call, so `end` alone orders
+    the hits; the sort runs on the device and one copy brings the rows to the host."""
     import numpy as np
-    arr = hits_t[: count * 3].cpu().numpy().reshape(-1, 3)          # (start, end, k|pad) as int64 triples
-    out = np.empty((count, 3), dtype=np.int64)
-    out[:, 0] = arr[:, 0]
-    out[:, 1] = arr[:, 1]
-    out[:, 2] = arr[:, 2] & 0xFFFFFFFF
-    order = np.lexsort((out[:, 0], out[:, 1]))                  # by end (unique per hit), then start
-    return out[order]
+    if count == 0:
+        return np.empty((0, 3), dtype=np.int64)
+    v = hits_t[: count * 3].view(-1, 3)                                # (start, end, k|pad) as int64 triples
+    out = v[torch.argsort(v[:, 1])].cpu().numpy()
+    out[:, 2] &= 0xFFFFFFFF
+    return out
 
 
 _hit_bufs = {}

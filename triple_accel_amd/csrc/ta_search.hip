@@ -118,7 +118,7 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         if ((rc = ls.ensure((size_t)cap_list * 4)) || (rc = lc.ensure(16))) return rc;
         TA_HIP(hipMemsetAsync(lc.dev, 0, 4, st));
         SearchParams F = P;
-        uint64_t ft = (h + 524287) / 524288;                          // ~2 sets of resident lanes, like pick_tile
+        uint64_t ft = (h + 131071) / 131072;                          // one set of resident lanes (256 CUs x 8 waves x 64)
         if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
         ft = (ft + FILTER_BLOCK - 1) / FILTER_BLOCK * FILTER_BLOCK;
         if (const char *e = getenv("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
