@@ -133,6 +133,7 @@ struct EmuWave {
     static Ptr sel_ptr(const Bool &c, const Ptr &a, const Ptr &b) { VP r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 
     struct Q128V { Q128 v[64]; };
+    using Q = Q128V;
     static Q128V gload16(const Ptr &p, const Bool &pred) {
         Q128V q;
         for (int i = 0; i < 64; i++) {
@@ -141,6 +142,7 @@ struct EmuWave {
         }
         return q;
     }
+    static Q128V gload16_nt(const Ptr &p, const Bool &pred) { return gload16(p, pred); }
     static U32 qword(const Q128V &q, int i) {
         V32 r;
         for (int l = 0; l < 64; l++) r.v[l] = i == 0 ? q.v[l].x : i == 1 ? q.v[l].y : i == 2 ? q.v[l].z : q.v[l].w;

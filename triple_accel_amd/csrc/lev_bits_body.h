@@ -16,7 +16,7 @@
 // One pair per lane (64 pairs per wavefront); the window is 4*NA bits wide (NA = packed dwords of `a` bytes
 // under it).  Rows outside [1, a_len] need no masking: above row 0 the virtual values D[r][j] = j + |r| satisfy
 // the recurrence with or without spurious matches, and rows below a_len never feed the rows above them.
-// Strings are streamed HBM -> LDS exactly as in lev_band_body.h (same ring, same loader).
+// Strings are streamed HBM -> registers -> LDS, 64 bytes per string per refill (see run()).
 #pragma once
 #include "lev_band_body.h"
 
@@ -30,7 +30,8 @@ struct LevBits {
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
-    using Loader = LevBand<W, 2, false, 0>;
+    using Q = typename W::Q;
+    static constexpr uint32_t BITS_SLOT = 84;          // LDS bytes per (pair, string): 64 + 16 look-ahead, odd number of dwords
 
     static constexpr uint32_t wmask(int q) { return (q == NW - 1 && (WB & 31)) ? ((1u << (WB & 31)) - 1u) : 0xFFFFFFFFu; }
 
@@ -107,7 +108,7 @@ struct LevBits {
 
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
         const U32 lane = W::lane();
-        const U32 grp = lane, g = W::splat(0);
+        const U32 grp = lane;
         const Bool active = (lane == lane);
         const U32 slot_idx = lane + wave_index * 64u;
         const Bool valid = slot_idx < P.n;
@@ -153,47 +154,70 @@ struct LevBits {
         const uint32_t iters = T0 + W::wave_max(blen);
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
-        const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
-        const U32 a_slot = grp * lev_slot_bytes(CH), b_slot = (grp + 64u) * lev_slot_bytes(CH);
-        const uint32_t kc0 = tp0 / CH;
-        Loader::load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
-        Loader::load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        // ---- string streaming.  Per (pair, string) LDS holds ONE 64-byte chunk [0,64) plus the first 16 bytes of the next
+        // one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16) (the 16-byte pieces sit on
+        // the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk waits in
+        // registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is
+        // used up; whole 64-byte lines per fetch keep the HBM traffic at the algorithmic bytes.
+        const U32 a_slot = grp * BITS_SLOT, b_slot = (grp + 64u) * BITS_SLOT;
+        Q S[8];
+        auto fetch = [&](uint32_t kc) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t y0 = kc * 64u + 16u * (uint32_t)p;
+                const Bool oka = valid & (ea <= y0) & ((W::splat(y0) - ea) < alen);
+                const Bool okb = valid & (eb <= y0) & ((W::splat(y0) - eb) < blen);
+                S[p] = W::gload16(W::ptr_add(aptr, W::sel(oka, W::splat(y0) - ea, W::splat(0))), oka);
+                S[4 + p] = W::gload16(W::ptr_add(bptr, W::sel(okb, W::splat(y0) - eb, W::splat(0))), okb);
+            }
+        };
+        auto commit_main = [&]() {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                W::lds_store16(lds, a_slot + 16u * p, S[p], active);
+                W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
+            }
+        };
+        auto commit_look = [&]() {
+            W::lds_store16(lds, a_slot + 64u, S[0], active);
+            W::lds_store16(lds, b_slot + 64u, S[4], active);
+        };
+        const uint32_t kc0 = tp0 / 64u;
+        fetch(kc0);
+        commit_main();
+        fetch(kc0 + 1);
         W::lds_wave_sync();
 
-        for (uint32_t kc = kc0; kc * CH < iters; kc++) {
-            if (kc > kc0) {
-                Loader::load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
-                W::lds_wave_sync();
-            }
-            const uint32_t t_lo = kc * CH;
-            const uint32_t t_hi = (t_lo + CH < iters) ? t_lo + CH : iters;
+        for (uint32_t kc = kc0; kc * 64u < iters; kc++) {
+            const uint32_t t_lo = kc * 64u;
+            const uint32_t t_hi = (t_lo + 64u < iters) ? t_lo + 64u : iters;
+            const U32 ra = a_slot + da - t_lo, rb = b_slot + db - t_lo;   // LDS address = r + tp
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
-            // the two ring bytes of iteration tp + 1 are fetched while iteration tp computes (the ring always holds the
-            // next chunk already), so no column waits on LDS latency
-            U32 a_nx = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
-            U32 b_nx = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
-            for (; tp < t_hi && tp < T0; tp++) {               // warm-up: rows 1..nlo slide in
-                const U32 a_in = a_nx;
-                a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
-                b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
-                advance_a(st, a_in);
+            for (int part = 0; part < 2; part++) {
+                // the last 16 iterations of a chunk may read into the look-ahead bytes: commit them first (the fetch
+                // was issued at least 48 iterations ago)
+                const uint32_t p_hi = part == 0 ? (t_lo + 48u < t_hi ? t_lo + 48u : t_hi) : t_hi;
+                if (part == 1) { commit_look(); W::lds_wave_sync(); }
+                for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
+                    advance_a(st, W::lds_u8(lds, ra + tp));
+                if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the part's end
+                    for (; tp < p_hi; tp++) {
+                        const U32 a_in = W::lds_u8(lds, ra + tp), b_in = W::lds_u8(lds, rb + tp);
+                        advance_a(st, a_in);
+                        column<false>(st, b_in, M, cnt, active);
+                    }
+                } else {
+                    for (; tp < p_hi; tp++) {
+                        const U32 a_in = W::lds_u8(lds, ra + tp), b_in = W::lds_u8(lds, rb + tp);
+                        advance_a(st, a_in);
+                        column<true>(st, b_in, M, cnt, t_stop > tp);
+                    }
+                }
             }
-            if (!W::any(valid & (t_stop < t_hi))) {            // every pair still has columns up to the chunk's end
-                for (; tp < t_hi; tp++) {
-                    const U32 a_in = a_nx, b_in = b_nx;
-                    a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
-                    b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
-                    advance_a(st, a_in);
-                    column<false>(st, b_in, M, cnt, active);
-                }
-            } else {
-                for (; tp < t_hi; tp++) {
-                    const U32 a_in = a_nx, b_in = b_nx;
-                    a_nx = W::lds_u8(lds, a_slot + ((da + (tp + 1u)) & RMASK));
-                    b_nx = W::lds_u8(lds, b_slot + ((db + (tp + 1u)) & RMASK));
-                    advance_a(st, a_in);
-                    column<true>(st, b_in, M, cnt, t_stop > tp);
-                }
+            if (t_hi < iters) {                                 // next chunk: registers -> LDS, then fetch the one after
+                commit_main();
+                fetch(kc + 2);
+                W::lds_wave_sync();
             }
         }
 

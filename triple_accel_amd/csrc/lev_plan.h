@@ -109,8 +109,9 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     if (na > 16) na += na & 1;
     if (na > (uint64_t)LEV_BITS_MAX_NA) { p.ok = false; na = LEV_BITS_MAX_NA; }
     p.NA = (int)na;
-    p.ch = (force_ch == 16 || force_ch == 32 || force_ch == 64) ? (uint32_t)force_ch : 32u;
-    p.lds_per_wave = (2u * 64u * (2u * p.ch + 4u) + 15u) & ~15u;
+    (void)force_ch;
+    p.ch = 64u;                                                    // one 64-byte line per string per refill
+    p.lds_per_wave = 2u * 64u * 84u;                               // 64 + 16 look-ahead + 4 pad bytes per (pair, string)
     // columns start at iteration Tw >= the deepest band (rows that must slide in first); a multiple of 64 keeps the
     // chunks of `b` on 64-byte lines
     p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;

@@ -31,6 +31,7 @@ struct DevWave {
     using U32 = uint32_t;
     using Bool = bool;
     using Ptr = const uint8_t *;
+    using Q = Q128;
 
     static __device__ __forceinline__ U32 lane() {
         return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -141,6 +142,17 @@ struct DevWave {
             typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
             u32x4u v = *(const u32x4u *)p;
             q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+        }
+        return q;
+    }
+    // same, streamed: the line is consumed whole by this one load, do not keep it in L2 (nt)
+    static __device__ __forceinline__ Q128 gload16_nt(Ptr p, Bool pred) {
+        Q128 q = {0u, 0u, 0u, 0u};
+        if (pred) {
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            const u32u *w = (const u32u *)p;
+            q.x = __builtin_nontemporal_load(w); q.y = __builtin_nontemporal_load(w + 1);
+            q.z = __builtin_nontemporal_load(w + 2); q.w = __builtin_nontemporal_load(w + 3);
         }
         return q;
     }
