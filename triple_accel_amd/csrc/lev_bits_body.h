@@ -31,7 +31,8 @@ struct LevBits {
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
     using Q = typename W::Q;
-    static constexpr uint32_t BITS_SLOT = 84;          // LDS bytes per (pair, string): 64 + 16 look-ahead, odd number of dwords
+    static constexpr uint32_t BITS_SLOT_A = 84;        // LDS bytes per pair for `a`: 64 + 16 look-ahead + 4 (odd number of dwords)
+    static constexpr uint32_t BITS_SLOT_B = 68;        // ... for `b`: 64 + 4
 
     static constexpr uint32_t wmask(int q) { return (q == NW - 1 && (WB & 31)) ? ((1u << (WB & 31)) - 1u) : 0xFFFFFFFFu; }
 
@@ -148,7 +149,7 @@ struct LevBits {
         // iteration tp inserts a[tp - ca] into the window and, from tp = T0 on, runs column tp - T0 + 1 with b[tp - T0]
         const uint32_t T0 = P.Tw;
         const U32 ca = W::splat(T0) - nlo, cb = W::splat(T0);
-        const U32 da = (W::splat(16u) - (ca & 15u)) & 15u, db = (W::splat(16u) - (cb & 15u)) & 15u;
+        const U32 da = (W::splat(16u) - (ca & 15u)) & 15u, db = W::splat(0);   // T0 is a multiple of 64 (lev_plan.h)
         const U32 ea = ca + da, eb = cb + db;
         const uint32_t tp0 = T0 - W::wave_max(W::sel(valid, nlo, W::splat(0)));
         const uint32_t iters = T0 + W::wave_max(blen);
@@ -159,7 +160,8 @@ struct LevBits {
         // the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk waits in
         // registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is
         // used up; whole 64-byte lines per fetch keep the HBM traffic at the algorithmic bytes.
-        const U32 a_slot = grp * BITS_SLOT, b_slot = (grp + 64u) * BITS_SLOT;
+        // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
+        const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
         Q S[8];
         auto fetch = [&](uint32_t kc) {
 #pragma unroll
@@ -178,10 +180,7 @@ struct LevBits {
                 W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
             }
         };
-        auto commit_look = [&]() {
-            W::lds_store16(lds, a_slot + 64u, S[0], active);
-            W::lds_store16(lds, b_slot + 64u, S[4], active);
-        };
+        auto commit_look = [&]() { W::lds_store16(lds, a_slot + 64u, S[0], active); };
         const uint32_t kc0 = tp0 / 64u;
         fetch(kc0);
         commit_main();

@@ -111,7 +111,7 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     p.NA = (int)na;
     (void)force_ch;
     p.ch = 64u;                                                    // one 64-byte line per string per refill
-    p.lds_per_wave = 2u * 64u * 84u;                               // 64 + 16 look-ahead + 4 pad bytes per (pair, string)
+    p.lds_per_wave = 64u * (84u + 68u);                            // per pair: `a` 64 + 16 look-ahead + 4 pad, `b` 64 + 4 pad
     // columns start at iteration Tw >= the deepest band (rows that must slide in first); a multiple of 64 keeps the
     // chunks of `b` on 64-byte lines
     p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;
