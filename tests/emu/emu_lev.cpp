@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "emu_wave.h"
 #include "lev_band_body.h"
 #include "lev_plan.h"
@@ -101,7 +103,8 @@ extern "C" int emu_lev_widebits(const uint8_t *a_blob, const uint64_t *a_off, co
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = lev_batch_unit_k(k, 1, 1, 0, max_len);
     P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
-    if (max_len > 64u * 32u * (uint32_t)nwl && false) return 1;
+    std::vector<uint32_t> lines((size_t)nwaves * 6 * (max_len + 66));
+    P.bnd = lines.data(); P.bnd_line = max_len + 66;
     uint8_t *lds = (uint8_t *)calloc(33 * 64 * 2 * 4 + 64, 1);
     for (uint32_t w = 0; w < nwaves; w++) {
         if (nwl == 1) { if (has_t) LevWideBits<EmuWave, 1, true>::run(P, w, nwaves, lds); else LevWideBits<EmuWave, 1, false>::run(P, w, nwaves, lds); }

@@ -157,6 +157,7 @@ struct EmuWave {
     static void lds_or32(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) { uint32_t t; memcpy(&t, lds + off.v[i], 4); t |= v.v[i]; memcpy(lds + off.v[i], &t, 4); }
     }
+    static void mem_fence() {}
     static uint32_t readlane(const U32 &x, uint32_t l) { return x.v[l & 63]; }
     static U32 gload_u8(const Ptr &p, const Bool &pred) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = pred.v[i] ? *p.v[i] : 0u; return r; }
     static uint32_t wave_sum(const U32 &x) { uint32_t t = 0; for (int i = 0; i < 64; i++) t += x.v[i]; return t; }

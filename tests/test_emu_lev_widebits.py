@@ -77,3 +77,22 @@ def test_widebits_4k_pair():
     ym = Dg.mutate(g, x, 500, False)
     got = E.lev_widebits([x, x], [y, ym], 0xFFFFFFFF, False, nwl=2, nwaves=1)
     assert got == [O.levenshtein(x, y), O.levenshtein(x, ym)]
+
+
+def test_widebits_several_stripes_and_band_limited_columns():
+    """Both strings longer than one stripe (2048 rows at 32 rows per lane): boundary lines between stripes, the anchor
+    chain, and -- with a bounded k -- stripes that only visit the columns of their band."""
+    g = Dg.rng(0x57)
+    x = Dg.rand_str(g, 5000)
+    y = Dg.mutate(g, x, 120, True)
+    z = Dg.rand_str(g, 4500)
+    w = bytes(g.integers(97, 100, size=4300).astype(np.uint8))
+    v = bytes(g.integers(97, 100, size=4100).astype(np.uint8))
+    a = [x, y, x, w, x[:2049], x[:2048], x]
+    b = [y, x, z, v, y[:2100], y[:2048], x]
+    for trans in (False, True):
+        for k in (0xFFFFFFFF, 300, 130):
+            got = E.lev_widebits(a, b, k, trans, nwl=1, nwaves=2)
+            assert got == oracle(a, b, k, trans), (trans, k)
+    got = E.lev_widebits(a[:3], b[:3], 0xFFFFFFFF, True, nwl=2, nwaves=1)      # 4096-row stripes: 2 stripes
+    assert got == oracle(a[:3], b[:3], 0xFFFFFFFF, True)

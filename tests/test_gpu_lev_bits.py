@@ -133,6 +133,24 @@ def test_widebits_small_alphabet(monkeypatch):
         assert np.array_equal(got, want), (costs, np.flatnonzero(got != want)[:10])
 
 
+def test_widebits_several_stripes(monkeypatch):
+    """Strings longer than one stripe on both sides (boundary lines in HBM, anchor chain, band-limited columns), with the
+    stripe height forced to 2048 and 4096 rows; includes the lengths right at the stripe edges."""
+    g = Dg.rng(0x57)
+    a, b = [], []
+    for n in (2047, 2048, 2049, 4095, 4096, 4097, 6000, 9000, 12500):
+        x = Dg.rand_str(g, n)
+        a += [x, x, x]
+        b += [Dg.mutate(g, x, 150, True), Dg.rand_str(g, n - 100), x[: n - 300]]
+    a += [bytes(g.integers(97, 100, size=7000).astype(np.uint8))]; b += [bytes(g.integers(97, 100, size=6800).astype(np.uint8))]
+    for rows in (32, 64):
+        monkeypatch.setenv("TA_FORCE_WIDEBITS", str(rows))
+        for k, costs in [(0xFFFFFFFF, LEV), (0xFFFFFFFF, RDAM), (400, LEV), (170, RDAM)]:
+            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+            assert kernel_id() == 4
+            assert np.array_equal(got, want), (rows, k, costs, np.flatnonzero(got != want)[:10])
+
+
 def test_long_unit_cost_pairs_pick_widebits_by_themselves():
     import triple_accel_amd as T
     g = Dg.rng(3)
@@ -145,6 +163,9 @@ def test_long_unit_cost_pairs_pick_widebits_by_themselves():
     z = Dg.rand_str(g, 2800)
     assert T.levenshtein_exp(x, z) == O.levenshtein_exp(x, z)
     assert T.rdamerau_exp(z, x) == O.rdamerau_exp(z, x)
+    x2, y2 = Dg.rand_str(g, 20000), Dg.rand_str(g, 19000)                      # 5 stripes of 4096 rows
+    assert T.levenshtein(x2, y2) == O.levenshtein(x2, y2)
+    assert kernel_id() == 4
 
 
 def test_widebits_equals_dp_on_cfg3_shape(monkeypatch):

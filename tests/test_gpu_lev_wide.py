@@ -59,17 +59,21 @@ def test_multi_stripe_and_band_limited(monkeypatch):
 
 
 def test_unforced_dispatch_to_wide():
-    """levenshtein() / rdamerau() on strings too long for the register band pick the wide kernel by themselves."""
+    """A full-distance call with weighted / affine costs on strings too long for the register band picks the DP wide
+    kernel by itself (the unit-cost families take the bit-parallel kernels: tests/test_gpu_lev_bits.py)."""
     import triple_accel_amd as T
     g = Dg.rng(3)
-    x = Dg.rand_str(g, 6000)                     # unit_k = 6000 -> 6002 diagonal slots > 64 lanes x 66
+    x = Dg.rand_str(g, 6000)
     y = Dg.mutate(g, x, 100, True)
-    assert T.levenshtein(x, y) == O.levenshtein(x, y)
-    assert T.last_launch_info()["kernel"] == 2
-    assert T.rdamerau(x, y) == O.rdamerau(x, y)
     z = Dg.rand_str(g, 5600)
-    assert T.levenshtein(x, z) == O.levenshtein(x, z)
-    assert T.levenshtein_exp(x, z) == O.levenshtein_exp(x, z)
+    for costs in [(2, 1, 0, None), (1, 1, 1, None), (3, 2, 1, 3)]:
+        c = T.EditCosts(*costs)
+        for other in (y, z):
+            got = T.levenshtein_simd_k_with_opts(x, other, 0xFFFFFFFF, False, c)
+            assert T.last_launch_info()["kernel"] == 2
+            assert got[0] == O.levenshtein_simd_k_with_opts(x, other, 0xFFFFFFFF, False, costs)[0]
+    assert T.levenshtein_exp_with_opts(x, z, False, T.EditCosts(2, 1, 0, None))[0] == \
+        O.levenshtein_exp_with_opts(x, z, False, (2, 1, 0, None))[0]
 
 
 def test_cfg3_shape_exp_batch():

@@ -46,6 +46,8 @@ struct LevParams {
     uint32_t lds_per_wave;    // bytes
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
     uint32_t ch;              // bytes per string per streamed chunk
+    uint32_t *bnd = nullptr;  // lev_widebits: per wave 6 boundary lines of bnd_line u32 (strings spanning several stripes)
+    uint64_t bnd_line = 0;
     uint32_t *trace;          // TRACE kernels: 2-bit argmin codes, word w of (iteration tau, phase, lane) at
                               // ((tau*2 + phase)*64 + lane)*LEV_TRACE_WORDS(D) + w, cell c in bits [2c, 2c+2)
 };

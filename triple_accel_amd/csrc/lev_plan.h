@@ -145,9 +145,11 @@ static inline LevChoice lev_choose(uint32_t k, uint32_t mc, uint32_t gc, uint32_
     const double wide = (2.0 * n * uu - uu * uu) * 6.0 / 64.0 + n * 40.0;
     c.kernel = band <= wide ? LEV_K_BAND : LEV_K_WIDE; c.rows_per_lane = 0;
     c.cost = band <= wide ? band : wide;
-    if (unit && !dp_only && max_len <= 4096) {                 // one pair per wave, one column of all rows per ~40 instructions
+    if (unit && !dp_only) {                                    // one pair per wave, one column of a 2048/4096-row stripe per ~45 instructions
         const int rpl = max_len > 2048 ? 64 : 32;
-        const double wb = (n + n / rpl) * (rpl == 64 ? 40.0 : 30.0) + (has_t ? n * 10.0 : 0.0) + 600.0;
+        const double rows = 64.0 * rpl, stripes = (double)((max_len + (uint64_t)rows - 1) / (uint64_t)rows);
+        const double cols = (rows + pl.u < n ? rows + pl.u : n) + 64.0;          // columns a stripe visits inside the band
+        const double wb = stripes * cols * (rpl == 64 ? 45.0 : 35.0) + (has_t ? stripes * cols * 10.0 : 0.0) + 600.0 * stripes;
         if (wb < c.cost) { c.kernel = LEV_K_WIDEBITS; c.rows_per_lane = rpl; c.cost = wb; }
     }
     return c;

@@ -13,8 +13,9 @@ __global__ __launch_bounds__(64) void lev_widebits_kernel(LevParams P) {
 }
 
 // rows_per_lane: 32 or 64.  Persistent grid: one wavefront per block, as many blocks as fit next to each other.
-hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, bool trans, hipStream_t s, uint32_t *grid_out,
-                               uint32_t *lds_out) {
+hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t max_len, bool trans, hipStream_t s,
+                               uint32_t *grid_out, uint32_t *lds_out) {
+    LevParams P = P0;
     const int nwl = rows_per_lane / 32;
     const uint32_t lds = 33u * 64u * (uint32_t)nwl * 4u;
     int dev = 0, cus = 256;
@@ -23,7 +24,17 @@ hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, bool trans
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t per_cu = nwl == 2 ? 8u : 16u;            // 160 KB of LDS per CU / table bytes, rounded to whole waves per SIMD
     const uint32_t resident = (uint32_t)cus * per_cu;
-    const uint32_t grid = P.n < resident ? P.n : resident;
+    uint32_t grid = P.n < resident ? P.n : resident;
+    P.bnd = nullptr; P.bnd_line = 0;
+    if (max_len > 64ull * (uint64_t)rows_per_lane) {
+        // pairs may span several stripes: 6 boundary lines (2 x {HP, HN, transposition term}) of one u32 per column per wave
+        P.bnd_line = max_len + 66;
+        const uint64_t per_wave = 6ull * P.bnd_line * sizeof(uint32_t), budget = 8ull << 30;
+        if ((uint64_t)grid * per_wave > budget) grid = (uint32_t)(budget / per_wave ? budget / per_wave : 1);
+        Scratch &sc = tls_scratch(6);
+        if (sc.ensure((size_t)grid * per_wave) != TA_OK) return hipErrorOutOfMemory;
+        P.bnd = (uint32_t *)sc.dev;
+    }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = lds;
     if (grid == 0) return hipSuccess;

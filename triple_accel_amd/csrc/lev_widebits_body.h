@@ -84,28 +84,55 @@ struct LevWideBits {
         if (TRANS) st.sX = X[NWL - 1];
     }
 
-    // Step s of the skewed sweep.  TAIL: lane 0 has passed the last column; lanes t <= s - m hold column m and freeze.
-    template <bool TAIL>
+    // Per-stripe sweep parameters (wave-uniform).
+    struct Sweep {
+        uint32_t jlo, Cn, m;         // first column, number of columns, length of `b`
+        const uint32_t *inP, *inM, *inX;   // top boundary written by the stripe above (nullptr: row 0 of the matrix)
+        uint32_t plo, phi;           // columns the stripe above covered
+        uint32_t *outP, *outM, *outX;      // this stripe's bottom boundary (nullptr: last stripe)
+    };
+
+    // Step s of the skewed sweep: lane t computes column jlo + s - t.  TAIL (last stripe only): lanes t <= s - Cn hold
+    // the last column and freeze.  BND: the stripe's top boundary comes from the stripe above instead of row 0.
+    template <bool TAIL, bool BND>
     static TA_HD inline __attribute__((always_inline)) void iter(State &st, const uint8_t *lds, U32 lane, U32 lane_off, Ptr bp,
-                                                                uint32_t m, uint32_t s, U32 &cb, U32 &c, U32 (&T)[2 * NWL]) {
+                                                                const Sweep &Z, uint32_t s, U32 &cb, U32 (&hb)[3], U32 &c,
+                                                                U32 (&T)[2 * NWL]) {
         U32 Eq[NWL];
 #pragma unroll
         for (int q = 0; q < NWL; q++) Eq[q] = T[q] & T[NWL + q];
         // next step's character and match vector first: the LDS lookups overlap this step's arithmetic
-        if (!TAIL && ((s + 1u) & 63u) == 0u) cb = W::gload_u8(W::ptr_add(bp, lane + (s + 1u)), (lane + (s + 1u)) < m);
-        const uint32_t b_next = (!TAIL && s + 1u < m) ? W::readlane(cb, (s + 1u) & 63u) : 256u;
+        const uint32_t s1 = s + 1u;
+        if ((s1 & 63u) == 0u && s1 < Z.Cn) {
+            const U32 col = lane + (Z.jlo + s1);                              // 1-based column of lane e's byte
+            cb = W::gload_u8(W::ptr_add(bp, col - 1u), col <= Z.m);
+        }
+        const uint32_t b_next = (s1 < Z.Cn) ? W::readlane(cb, s1 & 63u) : 256u;
         const U32 c_next = W::from_lower(c, W::splat(b_next));
         lookup(lds, c_next, lane_off, T);
-        st.rP = W::from_lower(st.sP, st.rP);      // lane 0 keeps 0x80000000: D[0][j] - D[0][j-1] = +1
-        st.rM = W::from_lower(st.sM, st.rM);      // lane 0 keeps 0
-        if (TRANS) st.rX = W::from_lower(st.sX, st.rX);
+        if (!BND) {
+            st.rP = W::from_lower(st.sP, st.rP);      // lane 0 keeps 0x80000000: D[0][j] - D[0][j-1] = +1
+            st.rM = W::from_lower(st.sM, st.rM);      // lane 0 keeps 0
+            if (TRANS) st.rX = W::from_lower(st.sX, st.rX);
+        } else {
+            if ((s & 63u) == 0u) {                    // 64 columns of the boundary above, coalesced
+                const U32 col = lane + (Z.jlo + s);
+                const Bool in = (col >= Z.plo) & (col <= Z.phi);
+                hb[0] = W::load_u32(Z.inP, col, in, 0x80000000u);             // outside the band above: a +1 step
+                hb[1] = W::load_u32(Z.inM, col, in, 0u);
+                hb[2] = TRANS ? W::load_u32(Z.inX, col, in, 0u) : W::splat(0);
+            }
+            st.rP = W::from_lower(st.sP, W::splat(W::readlane(hb[0], s & 63u)));
+            st.rM = W::from_lower(st.sM, W::splat(W::readlane(hb[1], s & 63u)));
+            if (TRANS) st.rX = W::from_lower(st.sX, W::splat(W::readlane(hb[2], s & 63u)));
+        }
         const U32 rP = st.rP, rM = st.rM, rX = st.rX;
         if (!TAIL) {
             step(st, Eq, c, rP, rM, rX);
         } else {
             State nx = st;
             step(nx, Eq, c, rP, rM, rX);
-            const Bool done = lane <= (s - m);
+            const Bool done = lane <= (s - Z.Cn);
 #pragma unroll
             for (int q = 0; q < NWL; q++) {
                 st.Pv[q] = W::sel(done, st.Pv[q], nx.Pv[q]); st.Mv[q] = W::sel(done, st.Mv[q], nx.Mv[q]);
@@ -113,7 +140,25 @@ struct LevWideBits {
             }
             st.sP = nx.sP; st.sM = nx.sM; st.sX = nx.sX; st.sc = nx.sc;
         }
+        if (Z.outP && s >= 63u) {                     // lane 63's row is the stripe's last: hand it to the stripe below
+            const U32 col = W::splat(Z.jlo + (s - 63u));
+            const Bool w = (lane == 63u) & (col <= Z.jlo + (Z.Cn - 1u));
+            W::store_u32(Z.outP, col, st.sP, w);
+            W::store_u32(Z.outM, col, st.sM, w);
+            if (TRANS) W::store_u32(Z.outX, col, st.sX, w);
+        }
         c = c_next;
+    }
+
+    // sum over columns [from, to] of the horizontal steps (+1 / 0 / -1) a boundary line recorded
+    static TA_HD inline uint32_t sum_steps(const uint32_t *bP, const uint32_t *bM, uint32_t from, uint32_t to, U32 lane) {
+        U32 acc = W::splat(0);
+        for (uint64_t j0 = from; j0 <= to; j0 += 64u) {
+            const U32 col = lane + (uint32_t)j0;
+            const Bool in = col <= to;
+            acc = acc + (W::load_u32(bP, col, in, 0u) >> 31) - (W::load_u32(bM, col, in, 0u) >> 31);
+        }
+        return W::wave_sum(acc);
     }
 
     // wave `wave_slot` of `nwaves` resident waves walks the pairs slot, slot + nwaves, ...
@@ -121,6 +166,8 @@ struct LevWideBits {
         const U32 lane = W::lane();
         const U32 lane_off = lane * (NWL * 4u);
         const Bool all = (lane == lane);
+        constexpr uint32_t ROWS = 64u * RB;                      // rows per stripe
+        uint32_t *lines = P.bnd ? P.bnd + (uint64_t)wave_slot * 6u * P.bnd_line : nullptr;
         for (uint32_t slot = wave_slot; slot < P.n; slot += nwaves) {
             const U32 pair = P.subset ? W::load_u32(P.subset, W::splat(slot), all, 0u) : W::splat(slot);
             Ptr xp, yp;
@@ -138,61 +185,107 @@ struct LevWideBits {
             } else if (n == 0) {
                 res = m <= P.k ? m : 0xFFFFFFFFu;                // one gap run (or two empty strings)
             } else {
-                // ---- per-lane nibble tables of this lane's rows [lane*RB, lane*RB + RB)
-#pragma unroll 1
-                for (uint32_t e = 0; e < 33u; e++) {
-#pragma unroll
-                    for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * (64u * NWL * 4u) + 4u * q, W::splat(0));
-                }
-                W::lds_wave_sync();
-                const U32 row0 = lane * RB;
-#pragma unroll 1
-                for (uint32_t r0 = 0; r0 < RB; r0 += 16) {
-                    const U32 i0 = row0 + r0;
-                    auto piece = W::gload16(W::ptr_add(ap, i0), i0 < n);   // blobs carry 16 bytes of slack (TA_BLOB_SLACK)
-                    const U32 w4[4] = {W::qword(piece, 0), W::qword(piece, 1), W::qword(piece, 2), W::qword(piece, 3)};
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const U32 ch = W::byte_of(w4[r >> 2], r & 3);
-                        const Bool ok = (i0 + (uint32_t)r) < n;
-                        const uint32_t bit = 1u << ((r0 + r) & 31u), qo = 4u * ((r0 + r) >> 5);
-                        W::lds_or32(lds, (ch >> 4) * (64u * NWL * 4u) + lane_off + qo, W::splat(bit), ok);
-                        W::lds_or32(lds, (ch & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE + qo, W::splat(bit), ok);
+                // the pair's band (lev_plan.h): row i visits columns [i - below, i + above]
+                const uint32_t tband = (P.u - (m - n)) >> 1;
+                const uint64_t below = tband, above = (uint64_t)tband + (m - n);
+                const uint32_t stripes = (n + ROWS - 1u) / ROWS;
+                uint32_t anchor = 0;                             // D[i0][jlo - 1]
+                uint32_t plo = 1, phi = 0;
+                uint32_t total = 0;
+                for (uint32_t sq = 0; sq < stripes; sq++) {
+                    const uint32_t i0 = sq * ROWS;
+                    const uint32_t nrows = (n - i0 < ROWS) ? n - i0 : ROWS;
+                    const bool last = (sq + 1u == stripes);
+                    Sweep Z;
+                    Z.m = m;
+                    Z.jlo = ((uint64_t)i0 + 1u > below) ? (uint32_t)(i0 + 1u - below) : 1u;
+                    const uint64_t hi64 = (uint64_t)i0 + nrows + above;
+                    const uint32_t jhi = hi64 < m ? (uint32_t)hi64 : m;
+                    Z.Cn = jhi - Z.jlo + 1u;                     // >= 1 because m - n <= u
+                    uint32_t *rd = lines ? lines + (uint64_t)((sq + 1u) & 1u) * 3u * P.bnd_line : nullptr;   // written by stripe sq-1
+                    uint32_t *wr = lines ? lines + (uint64_t)(sq & 1u) * 3u * P.bnd_line : nullptr;
+                    Z.inP = sq ? rd : nullptr; Z.inM = sq ? rd + P.bnd_line : nullptr; Z.inX = sq ? rd + 2u * P.bnd_line : nullptr;
+                    Z.outP = last ? nullptr : wr; Z.outM = last ? nullptr : wr + P.bnd_line; Z.outX = last ? nullptr : wr + 2u * P.bnd_line;
+                    Z.plo = plo; Z.phi = phi;
+                    if (sq) {                                    // D[i0][jlo-1]: down the stripe above at its column plo-1, then right
+                        anchor += ROWS;
+                        if (Z.jlo > plo) anchor += sum_steps(Z.inP, Z.inM, plo, Z.jlo - 1u, lane);
                     }
-                }
-                W::lds_wave_sync();
 
-                State st;
+                    // ---- per-lane nibble tables of this lane's rows [i0 + lane*RB, +RB)
+#pragma unroll 1
+                    for (uint32_t e = 0; e < 33u; e++) {
 #pragma unroll
-                for (int q = 0; q < NWL; q++) {
-                    st.Pv[q] = W::splat(0xFFFFFFFFu); st.Mv[q] = W::splat(0);
-                    st.D0p[q] = W::splat(0xFFFFFFFFu); st.Eqp[q] = W::splat(0);
-                }
-                st.sP = W::splat(0); st.sM = W::splat(0x80000000u); st.sX = W::splat(0); st.sc = W::splat(256);
-                st.rP = W::splat(0x80000000u); st.rM = W::splat(0); st.rX = W::splat(0);
-                const uint32_t t_last = (n - 1u) / RB;           // lane holding row n
-                const uint32_t steps = m + t_last;
+                        for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * (64u * NWL * 4u) + 4u * q, W::splat(0));
+                    }
+                    W::lds_wave_sync();
+                    const U32 row0 = lane * RB + i0;
+#pragma unroll 1
+                    for (uint32_t r0 = 0; r0 < RB; r0 += 16) {
+                        const U32 ia = row0 + r0;
+                        auto piece = W::gload16(W::ptr_add(ap, ia), ia < n);   // blobs carry 16 bytes of slack (TA_BLOB_SLACK)
+                        const U32 w4[4] = {W::qword(piece, 0), W::qword(piece, 1), W::qword(piece, 2), W::qword(piece, 3)};
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const U32 ch = W::byte_of(w4[r >> 2], r & 3);
+                            const Bool ok = (ia + (uint32_t)r) < n;
+                            const uint32_t bit = 1u << ((r0 + r) & 31u), qo = 4u * ((r0 + r) >> 5);
+                            W::lds_or32(lds, (ch >> 4) * (64u * NWL * 4u) + lane_off + qo, W::splat(bit), ok);
+                            W::lds_or32(lds, (ch & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE + qo, W::splat(bit), ok);
+                        }
+                    }
+                    W::lds_wave_sync();
 
-                U32 cb = W::gload_u8(W::ptr_add(bp, lane), lane < m);
-                U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
-                U32 T[2 * NWL];
-                lookup(lds, c, lane_off, T);
-                uint32_t s = 0;
-                for (; s < m; s++) iter<false>(st, lds, lane, lane_off, bp, m, s, cb, c, T);
-                for (; s < steps; s++) iter<true>(st, lds, lane, lane_off, bp, m, s, cb, c, T);   // <= 63 draining steps
-                // D[n][m] = D[0][m] + vertical differences of column m over rows 1..n
-                U32 contrib = W::splat(0);
+                    State st;
 #pragma unroll
-                for (int q = 0; q < NWL; q++) {
-                    const uint32_t lo = 32u * (uint32_t)q;
-                    const U32 first = row0 + lo;                 // 0-based index of this dword's first row
-                    const U32 cnt = W::sel(first >= n, W::splat(0), W::sel(first + 32u <= n, W::splat(32), W::splat(n) - first));
-                    const U32 msk = W::sel(cnt >= 32u, W::splat(0xFFFFFFFFu), W::shlv(W::splat(1), cnt) - 1u);
-                    contrib = W::bcnt(st.Pv[q] & msk, contrib);
-                    contrib = contrib - W::bcnt(st.Mv[q] & msk, W::splat(0));
+                    for (int q = 0; q < NWL; q++) {
+                        st.Pv[q] = W::splat(0xFFFFFFFFu); st.Mv[q] = W::splat(0);   // column jlo-1: D grows by 1 per row (exact for jlo = 1)
+                        st.D0p[q] = W::splat(0xFFFFFFFFu); st.Eqp[q] = W::splat(0);
+                    }
+                    st.sP = W::splat(0); st.sM = W::splat(0x80000000u); st.sX = W::splat(0); st.sc = W::splat(256);
+                    st.rP = W::splat(0x80000000u); st.rM = W::splat(0); st.rX = W::splat(0);
+                    const uint32_t t_last = (nrows - 1u) / RB;   // lane holding the stripe's last row
+                    const uint32_t steps = Z.Cn + t_last;
+
+                    const U32 col0 = lane + Z.jlo;
+                    U32 cb = W::gload_u8(W::ptr_add(bp, col0 - 1u), col0 <= m);
+                    U32 hb[3] = {W::splat(0x80000000u), W::splat(0), W::splat(0)};
+                    U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
+                    U32 T[2 * NWL];
+                    lookup(lds, c, lane_off, T);
+                    uint32_t s = 0;
+                    if (sq == 0) {
+                        for (; s < Z.Cn; s++) iter<false, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                        if (last) for (; s < steps; s++) iter<true, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                        else for (; s < steps; s++) iter<false, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                    } else {
+                        for (; s < Z.Cn; s++) iter<false, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                        if (last) for (; s < steps; s++) iter<true, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                        else for (; s < steps; s++) iter<false, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
+                    }
+                    if (last) {
+                        // D[n][m] = D[i0][jlo-1] + steps right along row i0 to column m + steps down column m to row n
+                        uint32_t right = m - (Z.jlo - 1u);       // row 0, or columns past the band above: +1 each
+                        if (sq && phi >= Z.jlo) {
+                            const uint32_t to = phi < m ? phi : m;
+                            right = sum_steps(Z.inP, Z.inM, Z.jlo, to, lane) + (m - to);
+                        }
+                        U32 contrib = W::splat(0);
+#pragma unroll
+                        for (int q = 0; q < NWL; q++) {
+                            const U32 first = lane * RB + 32u * (uint32_t)q;     // index of this dword's first row within the stripe
+                            const U32 cnt = W::sel(first >= nrows, W::splat(0), W::sel(first + 32u <= nrows, W::splat(32), W::splat(nrows) - first));
+                            const U32 msk = W::sel(cnt >= 32u, W::splat(0xFFFFFFFFu), W::shlv(W::splat(1), cnt) - 1u);
+                            contrib = W::bcnt(st.Pv[q] & msk, contrib);
+                            contrib = contrib - W::bcnt(st.Mv[q] & msk, W::splat(0));
+                        }
+                        total = anchor + right + W::wave_sum(contrib);
+                    } else {
+                        W::mem_fence();                          // lane 63's boundary stores -> this wave's loads in the next stripe
+                    }
+                    plo = Z.jlo; phi = jhi;
                 }
-                const uint32_t d = m + W::wave_sum(contrib);
-                res = d <= P.k ? d : 0xFFFFFFFFu;                 // :539-541
+                res = total <= P.k ? total : 0xFFFFFFFFu;        // :539-541
             }
             W::store_u32(P.out, pair, W::splat(res), lane0);
         }

@@ -105,9 +105,9 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
                            env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
     LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced);
     const bool unit = c->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || tcost == 1);
-    if (env_int("TA_FORCE_WIDEBITS") && unit && max_len <= 4096 && !dp_forced) {
+    if (env_int("TA_FORCE_WIDEBITS") && unit && !dp_forced) {
         ch.kernel = LEV_K_WIDEBITS;
-        ch.rows_per_lane = env_int("TA_FORCE_WIDEBITS") == 32 && max_len <= 2048 ? 32 : (env_int("TA_FORCE_WIDEBITS") == 64 || max_len > 2048 ? 64 : 32);
+        ch.rows_per_lane = env_int("TA_FORCE_WIDEBITS") == 64 ? 64 : 32;
     }
     if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
@@ -118,7 +118,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     } else if (ch.kernel == LEV_K_WIDEBITS) {
         P.u = bp.u; P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
         uint32_t grid = 0, lds = 0;
-        TA_HIP(lev_widebits_launch(P, ch.rows_per_lane, trans, st, &grid, &lds));
+        TA_HIP(lev_widebits_launch(P, ch.rows_per_lane, max_len, trans, st, &grid, &lds));
         li.kernel = 4; li.diags_per_lane = (uint32_t)ch.rows_per_lane; li.lanes_per_pair = 64; li.pairs_per_wave = 1;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else if (pl.ok && !env_int("TA_FORCE_WIDE")) {

@@ -41,8 +41,8 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s);
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out,
                            uint32_t *lds_out);
-hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, bool trans, hipStream_t s, uint32_t *grid_out,
-                               uint32_t *lds_out);
+hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, uint64_t max_len, bool trans, hipStream_t s,
+                               uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
                            uint32_t *threads_out, uint32_t *dpt_out);
 bool lev_wide_fits(uint32_t need_diagonals);

@@ -170,6 +170,8 @@ struct DevWave {
     static __device__ __forceinline__ void lds_or32(uint8_t *lds, U32 off, U32 v, Bool pred) {   // ds_or_b32, no return
         if (pred) (void)__hip_atomic_fetch_or((uint32_t *)(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
+    // this wave's global stores become visible to its own later global loads from other lanes (L1 invalidate)
+    static __device__ __forceinline__ void mem_fence() { __threadfence(); }
     // value of x in lane l (l wave-uniform) -> v_readlane_b32
     static __device__ __forceinline__ uint32_t readlane(U32 x, uint32_t l) { return __builtin_amdgcn_readlane(x, l); }
     static __device__ __forceinline__ U32 gload_u8(Ptr p, Bool pred) { return pred ? (U32)*p : 0u; }
