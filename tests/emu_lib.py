@@ -13,7 +13,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-j", str(os.cpu_count() or 4), "-s"])
         L = C.CDLL(_SO)
         L.emu_lev_band.restype = C.c_int
         L.emu_lev_band.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
