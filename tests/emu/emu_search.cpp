@@ -71,18 +71,48 @@ extern "C" int emu_lev_search(const uint8_t *needle, uint32_t n, const uint8_t *
 // ---- bit-parallel candidate filter (lev_filter_body.h): flagged 64-column blocks of a tiled scan
 #include "lev_filter_body.h"
 
-extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, int has_t,
-                              uint64_t tile, uint64_t halo, uint64_t *blocks_out, uint64_t cap, uint64_t *count) {
-    if (n == 0 || n > 32 || tile == 0 || tile % FILTER_BLOCK) return 1;
-    uint32_t peq[256];
-    for (uint32_t c = 0; c < 256; c++) peq[c] = lev_filter_peq(needle, n, c);
-    std::vector<uint64_t> blocks;
+template <int NWF>
+static void filter_n(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, int has_t, uint64_t tile,
+                     uint64_t halo, std::vector<uint64_t> &blocks) {
+    std::vector<uint32_t> peq(256 * NWF);
+    for (uint32_t c = 0; c < 256; c++)
+        for (uint32_t w = 0; w < (uint32_t)NWF; w++) peq[c * NWF + w] = lev_filter_peq_word(needle, n, NWF, c, w);
     for (uint64_t eb = 0; eb < h; eb += tile) {
         const uint64_t ee = eb + tile < h ? eb + tile : h, cb = eb > halo ? eb - halo : 0;
-        auto pq = [&](uint32_t c) { return peq[c]; };
+        auto pq = [&](uint32_t c, uint32_t (&Eq)[NWF]) { for (int w = 0; w < NWF; w++) Eq[w] = peq[c * NWF + w]; };
         auto mk = [&](uint64_t b) { blocks.push_back(b); };
-        if (has_t) lev_filter_tile<true>(hay, pq, n, k, cb, eb, ee, mk);
-        else lev_filter_tile<false>(hay, pq, n, k, cb, eb, ee, mk);
+        if (has_t) lev_filter_tile_n<NWF, true>(hay, pq, n, k, cb, eb, ee, mk);
+        else lev_filter_tile_n<NWF, false>(hay, pq, n, k, cb, eb, ee, mk);
+    }
+}
+
+extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, int has_t,
+                              uint64_t tile, uint64_t halo, int force_words, uint64_t *blocks_out, uint64_t cap, uint64_t *count) {
+    if (n == 0 || n > 256 || tile == 0 || tile % FILTER_BLOCK) return 1;
+    std::vector<uint64_t> blocks;
+    uint32_t nwf = (n + 31) / 32;
+    if (force_words > (int)nwf) nwf = (uint32_t)force_words;
+    if (nwf == 1) {
+        uint32_t peq[256];
+        for (uint32_t c = 0; c < 256; c++) peq[c] = lev_filter_peq(needle, n, c);
+        for (uint64_t eb = 0; eb < h; eb += tile) {
+            const uint64_t ee = eb + tile < h ? eb + tile : h, cb = eb > halo ? eb - halo : 0;
+            auto pq = [&](uint32_t c) { return peq[c]; };
+            auto mk = [&](uint64_t b) { blocks.push_back(b); };
+            if (has_t) lev_filter_tile<true>(hay, pq, n, k, cb, eb, ee, mk);
+            else lev_filter_tile<false>(hay, pq, n, k, cb, eb, ee, mk);
+        }
+    } else {
+        switch (nwf) {
+            case 2: filter_n<2>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 3: filter_n<3>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 4: filter_n<4>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 5: filter_n<5>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 6: filter_n<6>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 7: filter_n<7>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 8: filter_n<8>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            default: return 2;
+        }
     }
     *count = blocks.size();
     for (uint64_t i = 0; i < blocks.size() && i < cap; i++) blocks_out[i] = blocks[i];

@@ -27,7 +27,7 @@ def lib():
                                        C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
         L.emu_lev_filter.restype = C.c_int
         L.emu_lev_filter.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
-                                     C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+                                     C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -124,7 +124,7 @@ def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False,
     return res
 
 
-def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None):
+def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None, words=0):
     """64-column blocks the bit-parallel filter flags (sorted list of block indices)."""
     n = len(needle)
     if halo is None:
@@ -134,8 +134,8 @@ def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None):
     cap = len(haystack) // 64 + 2
     out = np.zeros(cap, dtype=np.uint64)
     cnt = C.c_uint64()
-    rc = lib().emu_lev_filter(needle, n, hay.ctypes.data, len(haystack), k, int(bool(trans)), tile, halo, out.ctypes.data, cap,
-                              C.byref(cnt))
+    rc = lib().emu_lev_filter(needle, n, hay.ctypes.data, len(haystack), k, int(bool(trans)), tile, halo, words,
+                              out.ctypes.data, cap, C.byref(cnt))
     if rc:
         raise RuntimeError("emu_lev_filter rc=%d" % rc)
     return sorted(int(x) for x in out[:cnt.value])

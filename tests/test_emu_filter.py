@@ -38,3 +38,23 @@ def test_filter_small_alphabet_and_nulls():
             hay = bytes(g.integers(0, 3, size=3000).astype(np.uint8))
             for k in (0, 1, n // 3):
                 assert E.lev_filter_blocks(needle, hay, k, trans, tile=128) == oracle_blocks(needle, hay, k, costs), (n, k, trans)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_filter_long_needles(trans):
+    """Needles of 33..256 bytes: the multi-dword form of the scan (and a short needle forced onto 2 and 3 dwords)."""
+    g = Dg.rng(43)
+    costs = RDAM if trans else LEV
+    for n in (33, 64, 65, 100, 200, 256):
+        needle = Dg.rand_str(g, n)
+        hay = Dg.planted_haystack(200 + n, needle, 8000, 900 + n, max(1, n // 5))
+        for k in (0, n // 6, n // 3):
+            assert E.lev_filter_blocks(needle, hay, k, trans, tile=512) == oracle_blocks(needle, hay, k, costs), (n, k, trans)
+    needle = bytes(g.integers(97, 100, size=40).astype(np.uint8))
+    hay = bytes(g.integers(97, 100, size=3000).astype(np.uint8))
+    for k in (5, 12, 20):
+        assert E.lev_filter_blocks(needle, hay, k, trans, tile=128) == oracle_blocks(needle, hay, k, costs), (k, trans)
+    needle = Dg.rand_str(g, 20)
+    hay = Dg.planted_haystack(77, needle, 5000, 400, 6)
+    for words in (2, 3):
+        assert E.lev_filter_blocks(needle, hay, 7, trans, tile=256, words=words) == oracle_blocks(needle, hay, 7, costs)

@@ -196,3 +196,24 @@ def test_filter_falls_back_when_matches_are_dense():
             for st in (O.ALL, O.BEST):
                 want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
                 assert prod_search(needle, hay, k, st, costs) == want, (k, costs, st)
+
+
+@pytest.mark.parametrize("costs", [(1, 1, 0, None), (1, 1, 0, 1)])
+def test_long_needles_through_the_filter(costs, monkeypatch):
+    """Needles of 33..256 bytes: multi-dword candidate filter + the memory-backed exact kernel on the flagged blocks,
+    against the oracle (All and Best) and against the exact kernel over everything."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0x10F6)
+    for n in (33, 64, 100, 256):
+        needle = Dg.rand_str(g, n)
+        hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 150_000, 9000 + n, max(1, n // 6))
+        for k in (n // 8, n // 3):
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (n, k, st, costs)
+                assert len(want) > 0
+        ht = B.haystack_tensor(hay)
+        got = B.levenshtein_search_dev(needle, ht, n // 3, costs)
+        monkeypatch.setenv("TA_SEARCH_NOFILTER", "1")
+        assert np.array_equal(got, B.levenshtein_search_dev(needle, ht, n // 3, costs))
+        monkeypatch.delenv("TA_SEARCH_NOFILTER")

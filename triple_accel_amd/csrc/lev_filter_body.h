@@ -76,4 +76,90 @@ TA_HD inline void lev_filter_tile(const uint8_t *hay, Peq peq, uint32_t n, uint3
     }
 }
 
+// ---- needles of 33..256 bytes: the same scan on NWF-dword bit-vectors (needle on the top bits of the vector)
+
+// word w (0 = lowest) of the match vector of byte value c
+TA_HD inline uint32_t lev_filter_peq_word(const uint8_t *needle, uint32_t n, uint32_t nwf, uint32_t c, uint32_t w) {
+    const uint32_t pad = 32u * nwf - n;                             // wildcard rows below the needle
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        const uint32_t bit = 32u * w + b;
+        if (bit < pad || (uint32_t)needle[bit - pad] == c) m |= 1u << b;
+    }
+    return m;
+}
+
+template <int NWF>
+struct FilterStateN {
+    uint32_t Pv[NWF], Mv[NWF], D0p[NWF], Eqp[NWF], score;
+};
+
+template <int NWF>
+TA_HD inline void lev_filter_reset_n(FilterStateN<NWF> &s, uint32_t n) {
+    const uint32_t pad = 32u * NWF - n;
+    for (int w = 0; w < NWF; w++) {
+        const uint32_t lo = 32u * (uint32_t)w;
+        const uint32_t wild = pad >= lo + 32u ? 0xFFFFFFFFu : (pad <= lo ? 0u : ((1u << (pad - lo)) - 1u));
+        s.Pv[w] = ~wild; s.Mv[w] = 0; s.D0p[w] = 0xFFFFFFFFu; s.Eqp[w] = 0;
+    }
+    s.score = n;
+}
+
+template <int NWF, bool TRANS>
+TA_HD inline __attribute__((always_inline)) uint32_t lev_filter_step_n(FilterStateN<NWF> &s, const uint32_t (&Eq)[NWF]) {
+    uint32_t D0[NWF], Ph[NWF], Mh[NWF];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWF; w++) {
+        const uint64_t t = (uint64_t)(Eq[w] & s.Pv[w]) + s.Pv[w] + carry;
+        carry = (uint32_t)(t >> 32);
+        D0[w] = (((uint32_t)t) ^ s.Pv[w]) | Eq[w] | s.Mv[w];
+    }
+    if (TRANS) {
+#pragma unroll
+        for (int w = 0; w < NWF; w++) {
+            const uint32_t x = ~s.D0p[w] & Eq[w], xl = w ? (~s.D0p[w - 1] & Eq[w - 1]) : 0u;
+            D0[w] |= ((x << 1) | (xl >> 31)) & s.Eqp[w];
+        }
+#pragma unroll
+        for (int w = 0; w < NWF; w++) { s.D0p[w] = D0[w]; s.Eqp[w] = Eq[w]; }
+    }
+#pragma unroll
+    for (int w = 0; w < NWF; w++) {
+        Ph[w] = s.Mv[w] | ~(D0[w] | s.Pv[w]);
+        Mh[w] = D0[w] & s.Pv[w];
+    }
+    s.score += (Ph[NWF - 1] >> 31);
+    s.score -= (Mh[NWF - 1] >> 31);
+#pragma unroll
+    for (int w = NWF - 1; w >= 0; w--) {
+        const uint32_t Phs = (Ph[w] << 1) | (w ? (Ph[w - 1] >> 31) : 0u);   // row 0 is free: nothing shifts in
+        const uint32_t Mhs = (Mh[w] << 1) | (w ? (Mh[w - 1] >> 31) : 0u);
+        s.Pv[w] = Mhs | ~(D0[w] | Phs);
+        s.Mv[w] = Phs & D0[w];
+    }
+    return s.score;
+}
+
+// as lev_filter_tile; peq(c, Eq) fills the NWF words of byte value c
+template <int NWF, bool TRANS, class Peq, class Mark>
+TA_HD inline void lev_filter_tile_n(const uint8_t *hay, Peq peq, uint32_t n, uint32_t k, uint64_t col_begin,
+                                    uint64_t emit_begin, uint64_t col_end, Mark mark) {
+    FilterStateN<NWF> s;
+    lev_filter_reset_n<NWF>(s, n);
+    bool any = false;
+    for (uint64_t i = col_begin; i < col_end; i++) {
+        uint32_t Eq[NWF];
+        peq(hay[i], Eq);
+        const uint32_t cost = lev_filter_step_n<NWF, TRANS>(s, Eq);
+        if (i >= emit_begin) {
+            any |= cost <= k;
+            if ((i & (FILTER_BLOCK - 1)) == FILTER_BLOCK - 1 || i + 1 == col_end) {
+                if (any) mark(i / FILTER_BLOCK);
+                any = false;
+            }
+        }
+    }
+}
+
 }  // namespace ta

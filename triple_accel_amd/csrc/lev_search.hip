@@ -138,14 +138,77 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
     }
 }
 
+// needles of 33..256 bytes: NWF-dword vectors, match table (256 x NWF dwords) in LDS built from the device copy of the needle
+template <int NWF, bool TRANS>
+__global__ __launch_bounds__(256) void lev_filter_kernel_n(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
+    __shared__ uint32_t peq[256 * NWF];
+    for (int w = 0; w < NWF; w++) peq[threadIdx.x * NWF + w] = lev_filter_peq_word(P.needle_dev, P.needle_len, NWF, threadIdx.x, w);
+    __syncthreads();
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t emit_begin = tile * P.tile;
+    if (emit_begin >= P.hay_len) return;
+    uint64_t emit_end = emit_begin + P.tile;
+    if (emit_end > P.hay_len) emit_end = P.hay_len;
+    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+    const uint32_t *tab = peq;
+    lev_filter_tile_n<NWF, TRANS>(P.hay, [=](uint32_t c, uint32_t (&Eq)[NWF]) {
+#pragma unroll
+                                      for (int w = 0; w < NWF; w++) Eq[w] = tab[c * NWF + w];
+                                  },
+                                  P.needle_len, P.k, col_begin, emit_begin, emit_end, [=](uint64_t blk) {
+                                      const unsigned int idx = atomicAdd(list_count, 1u);
+                                      if (idx < list_cap) list[idx] = (uint32_t)blk;
+                                  });
+}
+
+template <int NWF>
+static hipError_t launch_filter_n(const SearchParams &P, bool trans, uint32_t grid, uint32_t *list, uint32_t list_cap,
+                                  unsigned int *list_count, hipStream_t s) {
+    if (trans) hipLaunchKernelGGL((lev_filter_kernel_n<NWF, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+    else hipLaunchKernelGGL((lev_filter_kernel_n<NWF, false>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+    return hipGetLastError();
+}
+
 hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, uint32_t list_cap, unsigned int *list_count,
                              hipStream_t s) {
     if (P.hay_len == 0) return hipSuccess;
     const uint64_t tiles = (P.hay_len + P.tile - 1) / P.tile;
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
-    if (trans) hipLaunchKernelGGL(lev_filter_kernel<true>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-    else hipLaunchKernelGGL(lev_filter_kernel<false>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-    return hipGetLastError();
+    switch ((P.needle_len + 31u) / 32u) {
+        case 1:
+            if (trans) hipLaunchKernelGGL(lev_filter_kernel<true>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            else hipLaunchKernelGGL(lev_filter_kernel<false>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            return hipGetLastError();
+        case 2: return launch_filter_n<2>(P, trans, grid, list, list_cap, list_count, s);
+        case 3: return launch_filter_n<3>(P, trans, grid, list, list_cap, list_count, s);
+        case 4: return launch_filter_n<4>(P, trans, grid, list, list_cap, list_count, s);
+        case 5: return launch_filter_n<5>(P, trans, grid, list, list_cap, list_count, s);
+        case 6: return launch_filter_n<6>(P, trans, grid, list, list_cap, list_count, s);
+        case 7: return launch_filter_n<7>(P, trans, grid, list, list_cap, list_count, s);
+        case 8: return launch_filter_n<8>(P, trans, grid, list, list_cap, list_count, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// the memory-backed exact kernel (needles > 32 bytes) on the flagged blocks
+__global__ __launch_bounds__(64) void lev_search_mem_list_kernel(SearchParams P, const uint32_t *list, uint32_t n_list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_list) return;
+    const uint64_t emit_begin = (uint64_t)list[t] * FILTER_BLOCK;
+    uint64_t emit_end = emit_begin + FILTER_BLOCK;
+    if (emit_end > P.hay_len) emit_end = P.hay_len;
+    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+    SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, P.anchored};
+    ta_match *hits = P.hits;
+    unsigned long long *count = P.count;
+    const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
+    lev_search_tile_mem(P.hay, P.needle_dev, P.needle_len, C, P.tc != 0, P.col_scratch + t, n_list, col_begin, emit_begin, emit_end,
+                        [=](uint64_t end, uint32_t len, uint32_t cost) {
+                            const uint64_t gend = base + end;
+                            if (gend <= emit_from) return;
+                            unsigned long long idx = atomicAdd(count, 1ull);
+                            if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
+                        });
 }
 
 // the exact (cost, length) kernel on the flagged 64-column blocks only
@@ -180,6 +243,10 @@ static hipError_t launch_list_n(const SearchParams &P, bool trans, const uint32_
 
 hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s) {
     if (n_list == 0) return hipSuccess;
+    if (P.needle_len > 32) {
+        hipLaunchKernelGGL(lev_search_mem_list_kernel, dim3((n_list + 63) / 64), dim3(64), 0, s, P, list, n_list);
+        return hipGetLastError();
+    }
     switch (P.needle_len) {
 #define TA_N(x) case x: return launch_list_n<x>(P, trans, list, n_list, s);
         TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)

@@ -111,7 +111,8 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 &&
                       (!costs->has_transpose || costs->transpose_cost == 1);
     bool filtered = false;
-    if (unit && !anchored && packed && needle_len <= 32 && k < needle_len && h >= 4096 && !getenv("TA_SEARCH_NOFILTER")) {
+    const bool exact_ok = needle_len <= 32 ? packed : true;           // the block-list form exists for the packed and the memory-backed kernel
+    if (unit && !anchored && exact_ok && needle_len <= 256 && k < needle_len && h >= 4096 && !getenv("TA_SEARCH_NOFILTER")) {
         Scratch &ls = tls_scratch(5), &lc = tls_scratch(4);
         uint64_t cap_list = h / FILTER_BLOCK + 2;
         if (cap_list > (4u << 20)) cap_list = 4u << 20;
@@ -129,6 +130,11 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         TA_HIP(hipStreamSynchronize(st));
         // dense matches: the exact kernel over everything is cheaper than (64 + halo) columns per flagged block
         if (n_list <= cap_list && (uint64_t)n_list * (FILTER_BLOCK + P.halo) < h / 2) {
+            if (needle_len > 32 && n_list) {                          // memory-backed column: one per flagged block
+                Scratch &cs = tls_scratch(6);
+                if ((rc = cs.ensure((size_t)(6ull * (needle_len + 1) * 4ull * n_list)))) return rc;
+                P.col_scratch = (uint32_t *)cs.dev;
+            }
             TA_HIP(lev_search_list_launch(P, costs->has_transpose != 0, (const uint32_t *)ls.dev, n_list, st));
             filtered = true;
         }
