@@ -150,15 +150,42 @@ __global__ __launch_bounds__(256) void lev_filter_kernel_n(SearchParams P, uint3
     uint64_t emit_end = emit_begin + P.tile;
     if (emit_end > P.hay_len) emit_end = P.hay_len;
     const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
-    const uint32_t *tab = peq;
-    lev_filter_tile_n<NWF, TRANS>(P.hay, [=](uint32_t c, uint32_t (&Eq)[NWF]) {
+    const uint32_t k = P.k;
+    const uint8_t *hay = P.hay;
+    FilterStateN<NWF> st;
+    lev_filter_reset_n<NWF>(st, P.needle_len);
+    auto stepc = [&](uint32_t c) -> uint32_t {
+        uint32_t Eq[NWF];
 #pragma unroll
-                                      for (int w = 0; w < NWF; w++) Eq[w] = tab[c * NWF + w];
-                                  },
-                                  P.needle_len, P.k, col_begin, emit_begin, emit_end, [=](uint64_t blk) {
-                                      const unsigned int idx = atomicAdd(list_count, 1u);
-                                      if (idx < list_cap) list[idx] = (uint32_t)blk;
-                                  });
+        for (int w = 0; w < NWF; w++) Eq[w] = peq[c * NWF + w];
+        return lev_filter_step_n<NWF, TRANS>(st, Eq);
+    };
+    auto flag = [&](uint64_t col) {
+        const unsigned int idx = atomicAdd(list_count, 1u);
+        if (idx < list_cap) list[idx] = (uint32_t)(col / FILTER_BLOCK);
+    };
+    for (uint64_t i = col_begin; i < emit_begin; i++) stepc(hay[i]);               // left context
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    uint64_t i = emit_begin;
+    const uint64_t full_end = emit_begin + ((emit_end - emit_begin) & ~(uint64_t)(FILTER_BLOCK - 1));
+    u32x4u nxt = (i < full_end) ? *(const u32x4u *)(hay + i) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                        // whole 64-column blocks, 4 x 16 bytes
+        bool any = false;
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const u32x4u cur = nxt;
+            if (i + 16u * (q + 1) < emit_end) nxt = *(const u32x4u *)(hay + i + 16u * (q + 1));   // blobs carry 16 bytes of slack
+#pragma unroll
+            for (int b = 0; b < 16; b++) any |= stepc((cur[b >> 2] >> (8 * (b & 3))) & 0xffu) <= k;
+        }
+        if (any) flag(i);
+        i += FILTER_BLOCK;
+    }
+    if (i < emit_end) {                                           // the shard's last, partial block
+        bool any = false;
+        for (uint64_t j = i; j < emit_end; j++) any |= stepc(hay[j]) <= k;
+        if (any) flag(i);
+    }
 }
 
 template <int NWF>
