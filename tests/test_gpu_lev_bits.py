@@ -184,3 +184,27 @@ def test_widebits_equals_dp_on_cfg3_shape(monkeypatch):
     idx = np.r_[0:8, n - 8:n]
     want = O.levenshtein_exp_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx]))
     assert np.array_equal(bits[idx], want)
+
+
+def test_full_size_cfg3_bits_equals_dp(monkeypatch):
+    """BASELINE cfg3 at full size (100K x 4 KiB, levenshtein_exp): the bit-parallel schedule (band rounds + row-blocked
+    kernel) and the DP schedule (band rounds + DP band / wide kernels) return the same distance for every pair; identical
+    pairs give 0, and d(a, b) == d(b, a)."""
+    import torch
+    from triple_accel_amd import batch as B
+    n, L = 100_000, 4096
+    ar, br = Dg.pairs_random(0x7C03, n // 2, L)
+    am, bm = Dg.pairs_mutated_fixed(0x7C13, n // 2, L, 200)
+    a, b = np.concatenate([ar, am]), np.concatenate([br, bm])
+    b[n - 100:] = a[n - 100:]                                                    # some identical pairs
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    bits = B.levenshtein_exp_batch(sa, sb).cpu().numpy().view(np.uint32)
+    swapped = B.levenshtein_exp_batch(sb, sa).cpu().numpy().view(np.uint32)
+    assert np.array_equal(bits, swapped)
+    assert (bits[n - 100:] == 0).all() and (bits[: n // 2] > 3500).all() and (bits[n // 2: n - 100] <= 400).all()      # <= 200 edits, then cut or padded back to 4096 bytes
+    monkeypatch.setenv("TA_NO_BITS", "1")
+    dp = B.levenshtein_exp_batch(sa, sb).cpu().numpy().view(np.uint32)
+    assert np.array_equal(bits, dp), np.flatnonzero(bits != dp)[:10]
+    idx = np.r_[0:4, n // 2: n // 2 + 4]
+    assert np.array_equal(bits[idx], O.levenshtein_exp_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx])))
+    torch.cuda.synchronize()

@@ -217,3 +217,29 @@ def test_long_needles_through_the_filter(costs, monkeypatch):
         monkeypatch.setenv("TA_SEARCH_NOFILTER", "1")
         assert np.array_equal(got, B.levenshtein_search_dev(needle, ht, n // 3, costs))
         monkeypatch.delenv("TA_SEARCH_NOFILTER")
+
+
+def test_full_size_cfg5_filter_equals_exact(monkeypatch):
+    """BASELINE cfg5 at full size (32-byte needle, k = 16, one 1 GiB shard): the filter path returns exactly the hits of
+    the exact kernel over the whole shard; every planted copy is found; the first 2 MiB agree with the oracle."""
+    import torch
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0x7C05)
+    needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()
+    hay_np = Dg.random_bytes(g, 1 << 30)
+    planted = list(range(1 << 16, hay_np.size - 100, 1 << 20))
+    for pos in planted:
+        mm = np.frombuffer(Dg.mutate(g, needle, 10), dtype=np.uint8)
+        hay_np[pos:pos + mm.size] = mm
+    hay = B.haystack_tensor(hay_np)
+    got = B.levenshtein_search_dev(needle, hay, 16)
+    monkeypatch.setenv("TA_SEARCH_NOFILTER", "1")
+    want = B.levenshtein_search_dev(needle, hay, 16)
+    assert np.array_equal(got, want) and len(got) >= len(planted)
+    ends = got[:, 1]
+    for pos in planted[::37]:
+        assert ((ends > pos) & (ends <= pos + 48)).any(), pos
+    ns = 2 << 20
+    ora = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), 16, O.ALL, (1, 1, 0, None), False)
+    assert [tuple(int(v) for v in r) for r in got if r[1] <= ns] == [w for w in ora if w[1] > 0]
+    torch.cuda.synchronize()
