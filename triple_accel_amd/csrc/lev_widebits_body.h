@@ -94,7 +94,8 @@ struct LevWideBits {
 
     // Step s of the skewed sweep: lane t computes column jlo + s - t.  TAIL (last stripe only): lanes t <= s - Cn hold
     // the last column and freeze.  BND: the stripe's top boundary comes from the stripe above instead of row 0.
-    template <bool TAIL, bool BND>
+    // OUT: lane 63's row is handed to the stripe below.
+    template <bool TAIL, bool BND, bool OUT>
     static TA_HD inline __attribute__((always_inline)) void iter(State &st, const uint8_t *lds, U32 lane, U32 lane_off, Ptr bp,
                                                                 const Sweep &Z, uint32_t s, U32 &cb, U32 (&hb)[3], U32 &c,
                                                                 U32 (&T)[2 * NWL]) {
@@ -140,7 +141,7 @@ struct LevWideBits {
             }
             st.sP = nx.sP; st.sM = nx.sM; st.sX = nx.sX; st.sc = nx.sc;
         }
-        if (Z.outP && s >= 63u) {                     // lane 63's row is the stripe's last: hand it to the stripe below
+        if (OUT && s >= 63u) {                        // lane 63's row is the stripe's last: hand it to the stripe below
             const U32 col = W::splat(Z.jlo + (s - 63u));
             const Bool w = (lane == 63u) & (col <= Z.jlo + (Z.Cn - 1u));
             W::store_u32(Z.outP, col, st.sP, w);
@@ -253,16 +254,15 @@ struct LevWideBits {
                     U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
                     U32 T[2 * NWL];
                     lookup(lds, c, lane_off, T);
+                    // one specialised loop per role of the stripe, so that a single-stripe pair (the common case) carries no
+                    // boundary code at all
                     uint32_t s = 0;
-                    if (sq == 0) {
-                        for (; s < Z.Cn; s++) iter<false, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                        if (last) for (; s < steps; s++) iter<true, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                        else for (; s < steps; s++) iter<false, false>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                    } else {
-                        for (; s < Z.Cn; s++) iter<false, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                        if (last) for (; s < steps; s++) iter<true, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                        else for (; s < steps; s++) iter<false, true>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T);
-                    }
+#define TA_SWEEP(TAILV, BNDV, OUTV, LIMIT) for (; s < (LIMIT); s++) iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T)
+                    if (sq == 0 && last) { TA_SWEEP(false, false, false, Z.Cn); TA_SWEEP(true, false, false, steps); }
+                    else if (sq == 0) { TA_SWEEP(false, false, true, steps); }
+                    else if (!last) { TA_SWEEP(false, true, true, steps); }
+                    else { TA_SWEEP(false, true, false, Z.Cn); TA_SWEEP(true, true, false, steps); }
+#undef TA_SWEEP
                     if (last) {
                         // D[n][m] = D[i0][jlo-1] + steps right along row i0 to column m + steps down column m to row n
                         uint32_t right = m - (Z.jlo - 1u);       // row 0, or columns past the band above: +1 each
