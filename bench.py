@@ -188,7 +188,7 @@ def main():
             traffic = None
 
     cpu = None
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:        # the CPU leg runs at N = 1 only (rank 0)
         t1 = time.perf_counter()
         if wl == "cfg5":
             oracle_search(0, cpu_sample, cores)
