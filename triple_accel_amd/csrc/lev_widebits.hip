@@ -17,12 +17,12 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
                                uint32_t *grid_out, uint32_t *lds_out) {
     LevParams P = P0;
     const int nwl = rows_per_lane / 32;
-    const uint32_t lds = 33u * 64u * (uint32_t)nwl * 4u;
+    const uint32_t lds = 21u * 64u * (uint32_t)nwl * 4u;
     int dev = 0, cus = 256;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t per_cu = nwl == 2 ? 8u : 16u;            // 160 KB of LDS per CU / table bytes, rounded to whole waves per SIMD
+    const uint32_t per_cu = nwl == 2 ? 14u : 28u;           // 160 KB of LDS per CU / table bytes
     const uint32_t resident = (uint32_t)cus * per_cu;
     uint32_t grid = P.n < resident ? P.n : resident;
     P.bnd = nullptr; P.bnd_line = 0;

@@ -10,8 +10,8 @@
 // character, four DPP wave_shr:1 moves.
 //
 // The rows of a lane never change during a pair, so the match vector of a column is a table lookup instead of 64
-// byte compares: per lane two 16-entry tables in LDS, indexed by the high and the low nibble of the column's
-// character (Eq = Hi[c >> 4] & Lo[c & 15]), built once per pair with 2 ds_or_b32 per row.  A 17th Hi row stays
+// byte compares: per lane three small tables in LDS, indexed by bits 7..5, 4..2 and 1..0 of the column's character
+// (Eq = A[c >> 5] & B[(c >> 2) & 7] & C[c & 3]), built once per pair with 3 ds_or_b32 per row.  A 9th A row stays
 // zero: character code 256 = "no character", used for the virtual columns a lane sees before its first real one.
 // Those virtual columns need no predication: with D[i][j] = i + |j| for j <= 0 the state Pv = ~0, Mv = 0 is a fixed
 // point of the step when the block above reports a horizontal difference of -1 and nothing matches.
@@ -26,8 +26,12 @@ template <class W, int NWL, bool TRANS>
 struct LevWideBits {
     static_assert(NWL == 1 || NWL == 2, "32 or 64 rows per lane");
     static constexpr uint32_t RB = 32u * NWL;                    // rows per lane
-    static constexpr uint32_t LO_BASE = 17u * 64u * NWL * 4u;    // byte offset of the low-nibble tables
-    static constexpr uint32_t LDS_BYTES = 33u * 64u * NWL * 4u;
+    // three tables per lane, indexed by bits 7..5, 4..2 and 1..0 of the character: 9 (incl. the all-zero "no
+    // character" row, c = 256) + 8 + 4 rows of 64 lanes x NWL dwords -- 10.5 KB per wavefront at 64 rows per lane
+    static constexpr uint32_t ROW = 64u * NWL * 4u;              // bytes per table row
+    static constexpr uint32_t B_BASE = 9u * ROW, C_BASE = 17u * ROW;
+    static constexpr uint32_t TABLE_ROWS = 21u;
+    static constexpr uint32_t LDS_BYTES = TABLE_ROWS * ROW;
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
@@ -40,11 +44,14 @@ struct LevWideBits {
 
     // the two table rows of character c, NOT yet combined: the AND happens one step later, so the LDS reads of step
     // s + 1 stay in flight during the arithmetic of step s
-    static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&T)[2 * NWL]) {
-        const U32 hi = (c >> 4) * (64u * NWL * 4u) + lane_off;
-        const U32 lo = (c & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE;
+    static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&T)[3 * NWL]) {
+        const U32 ta = (c >> 5) * ROW + lane_off;
+        const U32 tb = ((c >> 2) & 7u) * ROW + lane_off + B_BASE;
+        const U32 tc = (c & 3u) * ROW + lane_off + C_BASE;
 #pragma unroll
-        for (int q = 0; q < NWL; q++) { T[q] = W::lds_read32(lds, hi + 4u * q); T[NWL + q] = W::lds_read32(lds, lo + 4u * q); }
+        for (int q = 0; q < NWL; q++) {
+            T[q] = W::lds_read32(lds, ta + 4u * q); T[NWL + q] = W::lds_read32(lds, tb + 4u * q); T[2 * NWL + q] = W::lds_read32(lds, tc + 4u * q);
+        }
     }
 
     // one column for every lane; rP/rM/rX = top dwords handed down by the lane above (row 0 boundary for lane 0)
@@ -97,11 +104,13 @@ struct LevWideBits {
     // OUT: lane 63's row is handed to the stripe below.
     template <bool TAIL, bool BND, bool OUT>
     static TA_HD inline __attribute__((always_inline)) void iter(State &st, const uint8_t *lds, U32 lane, U32 lane_off, Ptr bp,
-                                                                const Sweep &Z, uint32_t s, U32 &cb, U32 (&hb)[3], U32 &c,
-                                                                U32 (&T)[2 * NWL]) {
+                                                                const Sweep &Z, uint32_t s, U32 &cb, U32 (&hb)[3], const U32 &c,
+                                                                const U32 (&T)[3 * NWL], U32 &c_out, U32 (&T_out)[3 * NWL]) {
+        // (c, T) = this step's character and table rows; (c_out, T_out) receive the next step's -- two register sets
+        // that the caller alternates, so the lookups stay in flight across the loop edge without copies
         U32 Eq[NWL];
 #pragma unroll
-        for (int q = 0; q < NWL; q++) Eq[q] = T[q] & T[NWL + q];
+        for (int q = 0; q < NWL; q++) Eq[q] = T[q] & T[NWL + q] & T[2 * NWL + q];
         // next step's character and match vector first: the LDS lookups overlap this step's arithmetic
         const uint32_t s1 = s + 1u;
         if ((s1 & 63u) == 0u && s1 < Z.Cn) {
@@ -109,8 +118,8 @@ struct LevWideBits {
             cb = W::gload_u8(W::ptr_add(bp, col - 1u), col <= Z.m);
         }
         const uint32_t b_next = (s1 < Z.Cn) ? W::readlane(cb, s1 & 63u) : 256u;
-        const U32 c_next = W::from_lower(c, W::splat(b_next));
-        lookup(lds, c_next, lane_off, T);
+        c_out = W::from_lower(c, W::splat(b_next));
+        lookup(lds, c_out, lane_off, T_out);
         if (!BND) {
             st.rP = W::from_lower(st.sP, st.rP);      // lane 0 keeps 0x80000000: D[0][j] - D[0][j-1] = +1
             st.rM = W::from_lower(st.sM, st.rM);      // lane 0 keeps 0
@@ -148,7 +157,6 @@ struct LevWideBits {
             W::store_u32(Z.outM, col, st.sM, w);
             if (TRANS) W::store_u32(Z.outX, col, st.sX, w);
         }
-        c = c_next;
     }
 
     // sum over columns [from, to] of the horizontal steps (+1 / 0 / -1) a boundary line recorded
@@ -215,9 +223,9 @@ struct LevWideBits {
 
                     // ---- per-lane nibble tables of this lane's rows [i0 + lane*RB, +RB)
 #pragma unroll 1
-                    for (uint32_t e = 0; e < 33u; e++) {
+                    for (uint32_t e = 0; e < TABLE_ROWS; e++) {
 #pragma unroll
-                        for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * (64u * NWL * 4u) + 4u * q, W::splat(0));
+                        for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * ROW + 4u * q, W::splat(0));
                     }
                     W::lds_wave_sync();
                     const U32 row0 = lane * RB + i0;
@@ -231,8 +239,9 @@ struct LevWideBits {
                             const U32 ch = W::byte_of(w4[r >> 2], r & 3);
                             const Bool ok = (ia + (uint32_t)r) < n;
                             const uint32_t bit = 1u << ((r0 + r) & 31u), qo = 4u * ((r0 + r) >> 5);
-                            W::lds_or32(lds, (ch >> 4) * (64u * NWL * 4u) + lane_off + qo, W::splat(bit), ok);
-                            W::lds_or32(lds, (ch & 15u) * (64u * NWL * 4u) + lane_off + LO_BASE + qo, W::splat(bit), ok);
+                            W::lds_or32(lds, (ch >> 5) * ROW + lane_off + qo, W::splat(bit), ok);
+                            W::lds_or32(lds, ((ch >> 2) & 7u) * ROW + lane_off + B_BASE + qo, W::splat(bit), ok);
+                            W::lds_or32(lds, (ch & 3u) * ROW + lane_off + C_BASE + qo, W::splat(bit), ok);
                         }
                     }
                     W::lds_wave_sync();
@@ -252,12 +261,22 @@ struct LevWideBits {
                     U32 cb = W::gload_u8(W::ptr_add(bp, col0 - 1u), col0 <= m);
                     U32 hb[3] = {W::splat(0x80000000u), W::splat(0), W::splat(0)};
                     U32 c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
-                    U32 T[2 * NWL];
+                    U32 T[3 * NWL], T2[3 * NWL], c2;
                     lookup(lds, c, lane_off, T);
                     // one specialised loop per role of the stripe, so that a single-stripe pair (the common case) carries no
                     // boundary code at all
                     uint32_t s = 0;
-#define TA_SWEEP(TAILV, BNDV, OUTV, LIMIT) for (; s < (LIMIT); s++) iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T)
+#define TA_SWEEP(TAILV, BNDV, OUTV, LIMIT)                                                                               \
+    for (; s + 1u < (LIMIT); s += 2u) {                                                                                  \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T, c2, T2);                                \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s + 1u, cb, hb, c2, T2, c, T);                           \
+    }                                                                                                                    \
+    if (s < (LIMIT)) {                                                                                                   \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T, c2, T2);                                \
+        c = c2;                                                                                                          \
+        for (int q_ = 0; q_ < 3 * NWL; q_++) T[q_] = T2[q_];                                                             \
+        s++;                                                                                                             \
+    }
                     if (sq == 0 && last) { TA_SWEEP(false, false, false, Z.Cn); TA_SWEEP(true, false, false, steps); }
                     else if (sq == 0) { TA_SWEEP(false, false, true, steps); }
                     else if (!last) { TA_SWEEP(false, true, true, steps); }
