@@ -1,5 +1,6 @@
 // lev_widebits.hip -- gfx950 instantiations of the row-blocked bit-parallel kernel (lev_widebits_body.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "lev_widebits_body.h"
 #include "ta_internal.h"
@@ -23,7 +24,8 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t per_cu = nwl == 2 ? 14u : 28u;           // 160 KB of LDS per CU / table bytes
-    const uint32_t resident = (uint32_t)cus * per_cu;
+    uint32_t resident = (uint32_t)cus * per_cu;
+    if (const char *e = getenv("TA_WB_WAVES_PER_CU")) { int v = atoi(e); if (v > 0) resident = (uint32_t)cus * (uint32_t)v; }
     uint32_t grid = P.n < resident ? P.n : resident;
     P.bnd = nullptr; P.bnd_line = 0;
     if (max_len > 64ull * (uint64_t)rows_per_lane) {

@@ -45,12 +45,17 @@ struct LevWideBits {
     // the two table rows of character c, NOT yet combined: the AND happens one step later, so the LDS reads of step
     // s + 1 stay in flight during the arithmetic of step s
     static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&T)[3 * NWL]) {
-        const U32 ta = (c >> 5) * ROW + lane_off;
-        const U32 tb = ((c >> 2) & 7u) * ROW + lane_off + B_BASE;
-        const U32 tc = (c & 3u) * ROW + lane_off + C_BASE;
+        // row * ROW | lane_off (disjoint bits: lane_off < ROW): one shift and one v_and_or_b32 per table; the table bases
+        // ride in the ds_read offset field
+        constexpr int SH = NWL == 2 ? 9 : 8;                     // log2(ROW)
+        const U32 ta = ((c << (SH - 5)) & (15u << SH)) | lane_off;
+        const U32 tb = ((c << (SH - 2)) & (7u << SH)) | lane_off;
+        const U32 tc = ((c << SH) & (3u << SH)) | lane_off;
 #pragma unroll
         for (int q = 0; q < NWL; q++) {
-            T[q] = W::lds_read32(lds, ta + 4u * q); T[NWL + q] = W::lds_read32(lds, tb + 4u * q); T[2 * NWL + q] = W::lds_read32(lds, tc + 4u * q);
+            T[q] = W::lds_read32(lds, ta + 4u * q);
+            T[NWL + q] = W::lds_read32(lds, tb + (B_BASE + 4u * q));
+            T[2 * NWL + q] = W::lds_read32(lds, tc + (C_BASE + 4u * q));
         }
     }
 
