@@ -115,16 +115,24 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
     uint64_t i = emit_begin;
     const uint64_t full_end = emit_begin + ((emit_end - emit_begin) & ~(uint64_t)(FILTER_BLOCK - 1));
-    u32x4u nxt = (i < full_end) ? *(const u32x4u *)(hay + i) : u32x4u{0, 0, 0, 0};
-    while (i < full_end) {                                        // whole 64-column blocks, 4 x 16 bytes
+    // a whole 64-byte block per lane is requested at once, one block ahead: each 128-byte line is touched by two bursts
+    // only, so it need not survive in L2 while the lane chews through it
+    u32x4u nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nxt[q] = (i + 16u * q < emit_end) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                        // whole 64-column blocks
+        u32x4u cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)                               // blobs carry 16 bytes of slack
+            if (i + FILTER_BLOCK + 16u * q < emit_end) nxt[q] = *(const u32x4u *)(hay + i + FILTER_BLOCK + 16u * q);
         bool any = false;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u32x4u cur = nxt;
-            if (i + 16u * (q + 1) < emit_end) nxt = *(const u32x4u *)(hay + i + 16u * (q + 1));   // blobs carry 16 bytes of slack
 #pragma unroll
             for (int b = 0; b < 16; b++) {
-                const uint32_t c = (cur[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                const uint32_t c = (cur[q][b >> 2] >> (8 * (b & 3))) & 0xffu;
                 any |= lev_filter_step<TRANS>(st, peq[c]) <= k;
             }
         }
@@ -168,15 +176,21 @@ __global__ __launch_bounds__(256) void lev_filter_kernel_n(SearchParams P, uint3
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
     uint64_t i = emit_begin;
     const uint64_t full_end = emit_begin + ((emit_end - emit_begin) & ~(uint64_t)(FILTER_BLOCK - 1));
-    u32x4u nxt = (i < full_end) ? *(const u32x4u *)(hay + i) : u32x4u{0, 0, 0, 0};
-    while (i < full_end) {                                        // whole 64-column blocks, 4 x 16 bytes
+    u32x4u nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nxt[q] = (i + 16u * q < emit_end) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                        // whole 64-column blocks, requested one block ahead
+        u32x4u cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)                               // blobs carry 16 bytes of slack
+            if (i + FILTER_BLOCK + 16u * q < emit_end) nxt[q] = *(const u32x4u *)(hay + i + FILTER_BLOCK + 16u * q);
         bool any = false;
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
-            const u32x4u cur = nxt;
-            if (i + 16u * (q + 1) < emit_end) nxt = *(const u32x4u *)(hay + i + 16u * (q + 1));   // blobs carry 16 bytes of slack
 #pragma unroll
-            for (int b = 0; b < 16; b++) any |= stepc((cur[b >> 2] >> (8 * (b & 3))) & 0xffu) <= k;
+            for (int b = 0; b < 16; b++) any |= stepc((cur[q][b >> 2] >> (8 * (b & 3))) & 0xffu) <= k;
         }
         if (any) flag(i);
         i += FILTER_BLOCK;
