@@ -118,3 +118,33 @@ extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *
     for (uint64_t i = 0; i < blocks.size() && i < cap; i++) blocks_out[i] = blocks[i];
     return 0;
 }
+
+// ---- shift-add hamming_search scan (ham_search_body.h)
+#include "ham_search_body.h"
+
+template <int NWS>
+static void ham_n(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, std::vector<Hit> &hits) {
+    std::vector<uint32_t> tab(256 * NWS);
+    for (uint32_t c = 0; c < 256; c++)
+        for (uint32_t w = 0; w < (uint32_t)NWS; w++) tab[c * NWS + w] = ham_sa_table_word(needle, n, c, w);
+    const uint64_t offsets = h - n + 1;
+    for (uint64_t ob = 0; ob < offsets; ob += tile) {
+        const uint64_t oe = ob + tile < offsets ? ob + tile : offsets;
+        ham_sa_tile<NWS>(hay, [&](uint32_t c, uint32_t (&Tc)[NWS]) { for (int w = 0; w < NWS; w++) Tc[w] = tab[c * NWS + w]; }, n, k, ob, oe,
+                         [&](uint64_t p, uint32_t cnt) { hits.push_back(Hit{p, p + n, cnt, 0u}); });
+    }
+}
+
+extern "C" int emu_ham_search(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, int words,
+                              Hit *out, uint64_t cap, uint64_t *count) {
+    if (n == 0 || n > 32 || n > h || tile == 0) return 1;
+    std::vector<Hit> hits;
+    int nws = (int)((n + 3) / 4);
+    if (words > nws) nws = words;
+    if (nws <= 2) ham_n<2>(needle, n, hay, h, k, tile, hits);
+    else if (nws <= 4) ham_n<4>(needle, n, hay, h, k, tile, hits);
+    else ham_n<8>(needle, n, hay, h, k, tile, hits);
+    *count = hits.size();
+    for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];
+    return 0;
+}

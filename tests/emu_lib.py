@@ -28,6 +28,9 @@ def lib():
         L.emu_lev_filter.restype = C.c_int
         L.emu_lev_filter.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
                                      C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.emu_ham_search.restype = C.c_int
+        L.emu_ham_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int,
+                                     C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -139,3 +142,17 @@ def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None, wor
     if rc:
         raise RuntimeError("emu_lev_filter rc=%d" % rc)
     return sorted(int(x) for x in out[:cnt.value])
+
+
+def ham_search(needle, haystack, k, tile=512, words=0):
+    """All-mode hits [(start, end, k)] of the shift-add hamming_search scan over a tiled haystack."""
+    n = len(needle)
+    hay = np.zeros(len(haystack) + 16, dtype=np.uint8)
+    hay[:len(haystack)] = np.frombuffer(haystack, dtype=np.uint8)
+    cap = len(haystack) + 2
+    out = np.zeros((cap, 3), dtype=np.uint64)
+    cnt = C.c_uint64()
+    rc = lib().emu_ham_search(needle, n, hay.ctypes.data, len(haystack), k, tile, words, out.ctypes.data, cap, C.byref(cnt))
+    if rc:
+        raise RuntimeError("emu_ham_search rc=%d" % rc)
+    return [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]

@@ -1,0 +1,36 @@
+"""not-gpu: the shift-add hamming_search scan (ham_search_body.h) against the oracle's scalar hamming_search."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+
+def test_shift_add_equals_oracle():
+    g = Dg.rng(0x4A)
+    for n in (1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 31, 32):
+        needle = bytes(g.integers(1, 256, size=n).astype(np.uint8))
+        hay = bytearray(g.integers(1, 256, size=3000).astype(np.uint8).tobytes())
+        for pos in range(50, 2900, 211):                                      # planted copies with a few substitutions
+            m = bytearray(needle)
+            for _ in range(int(g.integers(0, 4))):
+                m[int(g.integers(0, n))] = int(g.integers(1, 256))
+            hay[pos:pos + n] = m
+        hay = bytes(hay)
+        for k in sorted({0, 1, n // 2, n}):
+            want = O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+            for tile in (64, 1000):
+                assert E.ham_search(needle, hay, k, tile=tile) == want, (n, k, tile)
+            assert E.ham_search(needle, hay, k, tile=500, words=8) == want
+
+
+def test_shift_add_small_alphabet_and_edges():
+    g = Dg.rng(0x4B)
+    for n in (3, 7, 20, 32):
+        needle = bytes(g.integers(97, 99, size=n).astype(np.uint8))
+        hay = bytes(g.integers(97, 99, size=400).astype(np.uint8))
+        for k in (0, n // 3, n - 1):
+            assert E.ham_search(needle, hay, k, tile=96) == O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+    assert E.ham_search(b"abc", b"abc", 0) == [(0, 3, 0)]
+    assert E.ham_search(b"abc", b"abd", 1) == [(0, 3, 1)]

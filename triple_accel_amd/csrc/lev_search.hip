@@ -1,6 +1,8 @@
 // lev_search.hip -- gfx950 kernels for levenshtein_search / hamming_search over a haystack shard in HBM.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
+#include "ham_search_body.h"
 #include "lev_filter_body.h"
 #include "lev_search_body.h"
 #include "ta_internal.h"
@@ -346,8 +348,80 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uin
     }
 }
 
-hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s) {
+// needles of up to 32 bytes: shift-add scan (ham_search_body.h), one lane per tile of P.tile offsets, table in LDS,
+// haystack requested 64 bytes per lane one block ahead
+template <int NWS>
+__global__ __launch_bounds__(256) void hamming_search_sa_kernel(SearchParams P) {
+    __shared__ uint32_t tab[256 * NWS];
+    for (int w = 0; w < NWS; w++) tab[threadIdx.x * NWS + w] = ham_sa_table_word(P.needle, P.needle_len, threadIdx.x, w);
+    __syncthreads();
+    const uint32_t n = P.needle_len, k = P.k;
+    const uint64_t offsets = P.hay_len - n + 1;
+    const uint64_t ob = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * P.tile;
+    if (ob >= offsets) return;
+    const uint64_t oe = ob + P.tile < offsets ? ob + P.tile : offsets;
+    const uint8_t *hay = P.hay;
+    HamSaState<NWS> st;
+#pragma unroll
+    for (int w = 0; w < NWS; w++) st.S[w] = 0;
+    auto stepc = [&](uint32_t c) -> uint32_t {
+        uint32_t Tc[NWS];
+#pragma unroll
+        for (int w = 0; w < NWS; w++) Tc[w] = tab[c * NWS + w];
+        return ham_sa_step<NWS>(st, Tc, n);
+    };
+    auto emit = [&](uint64_t p, uint32_t cnt) {
+        unsigned long long idx = atomicAdd(P.count, 1ull);
+        if (idx < P.cap) P.hits[idx] = ta_match{P.base + p, P.base + p + n, cnt, 0u};
+    };
+    uint64_t i = ob;
+    for (; i < ob + (n - 1); i++) stepc(hay[i]);                  // the first n-1 bytes complete no offset
+    const uint64_t end = oe + (n - 1);                            // one past the last byte this tile reads
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    const uint64_t full_end = i + ((end - i) & ~(uint64_t)63);
+    u32x4u nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nxt[q] = (i + 16u * q < end) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {
+        u32x4u cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)                               // blobs carry 16 bytes of slack
+            if (i + 64u + 16u * q < end) nxt[q] = *(const u32x4u *)(hay + i + 64u + 16u * q);
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t cnt = stepc((cur[q][b >> 2] >> (8 * (b & 3))) & 0xffu);
+                if (cnt <= k) emit(i + 16u * q + b - (n - 1), cnt);
+            }
+        }
+        i += 64;
+    }
+    for (; i < end; i++) {
+        const uint32_t cnt = stepc(hay[i]);
+        if (cnt <= k) emit(i - (n - 1), cnt);
+    }
+}
+
+hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s) {
+    SearchParams P = P0;
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
+    if (P.needle_len <= 32 && !getenv("TA_HAMMING_SEARCH_SWAR")) {
+        const uint64_t offsets = P.hay_len - P.needle_len + 1;
+        uint64_t tile = (offsets + 262143) / 262144;              // two sets of resident lanes
+        if (tile < 8ull * P.needle_len) tile = 8ull * P.needle_len;
+        if (tile < 64) tile = 64;
+        P.tile = (uint32_t)(tile > 0x7FFFFFFFull ? 0x7FFFFFFFull : tile);
+        const uint64_t lanes = (offsets + P.tile - 1) / P.tile;
+        const uint32_t grid = (uint32_t)((lanes + 255) / 256);
+        const uint32_t nws = (P.needle_len + 3) / 4;
+        if (nws <= 2) hipLaunchKernelGGL(hamming_search_sa_kernel<2>, dim3(grid), dim3(256), 0, s, P);
+        else if (nws <= 4) hipLaunchKernelGGL(hamming_search_sa_kernel<4>, dim3(grid), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL(hamming_search_sa_kernel<8>, dim3(grid), dim3(256), 0, s, P);
+        return hipGetLastError();
+    }
     const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 3u);
     const uint64_t groups = (P.hay_len - P.needle_len + delta) / 4 + 1;
     hipLaunchKernelGGL(hamming_search_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, P, delta);
