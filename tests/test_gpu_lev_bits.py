@@ -208,3 +208,20 @@ def test_full_size_cfg3_bits_equals_dp(monkeypatch):
     idx = np.r_[0:4, n // 2: n // 2 + 4]
     assert np.array_equal(bits[idx], O.levenshtein_exp_batch(O.csr_from_fixed(a[idx]), O.csr_from_fixed(b[idx])))
     torch.cuda.synchronize()
+
+
+def test_unforced_dispatch_sweep():
+    """Whatever kernel lev_choose picks (bit-parallel band, row-blocked bit-parallel, DP band, DP wide), the answer is the
+    oracle's: string lengths from 60 to 6000, k from tight to unbounded, unit and weighted cost families."""
+    g = Dg.rng(0xD15)
+    seen = set()
+    for n in (60, 130, 260, 600, 1100, 2100, 3000, 6000):
+        x = Dg.rand_str(g, n)
+        a = [x, x, x, x[: n - 7]]
+        b = [Dg.mutate(g, x, max(2, n // 25), True), Dg.rand_str(g, n), x, x]
+        for costs in [LEV, RDAM, (2, 1, 0, None), (1, 1, 1, 1)]:
+            for k in (n // 20, 127, 128, n // 2, 0xFFFFFFFF):
+                got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+                seen.add(kernel_id())
+                assert np.array_equal(got, want), (n, k, costs, kernel_id(), got, want)
+    assert seen == {1, 2, 3, 4}, seen
