@@ -29,6 +29,7 @@ struct LevWideBits {
     // three tables per lane, indexed by bits 7..5, 4..2 and 1..0 of the character: 9 (incl. the all-zero "no
     // character" row, c = 256) + 8 + 4 rows of 64 lanes x NWL dwords -- 10.5 KB per wavefront at 64 rows per lane
     static constexpr uint32_t ROW = 64u * NWL * 4u;              // bytes per table row
+    static constexpr int SH = NWL == 2 ? 9 : 8;                  // log2(ROW)
     static constexpr uint32_t B_BASE = 9u * ROW, C_BASE = 17u * ROW;
     static constexpr uint32_t TABLE_ROWS = 21u;
     static constexpr uint32_t LDS_BYTES = TABLE_ROWS * ROW;
@@ -45,12 +46,9 @@ struct LevWideBits {
     // the two table rows of character c, NOT yet combined: the AND happens one step later, so the LDS reads of step
     // s + 1 stay in flight during the arithmetic of step s
     static TA_HD inline __attribute__((always_inline)) void lookup(const uint8_t *lds, U32 c, U32 lane_off, U32 (&T)[3 * NWL]) {
-        // row * ROW | lane_off (disjoint bits: lane_off < ROW): one shift and one v_and_or_b32 per table; the table bases
-        // ride in the ds_read offset field
-        constexpr int SH = NWL == 2 ? 9 : 8;                     // log2(ROW)
-        const U32 ta = ((c << (SH - 5)) & (15u << SH)) | lane_off;
-        const U32 tb = ((c << (SH - 2)) & (7u << SH)) | lane_off;
-        const U32 tc = ((c << SH) & (3u << SH)) | lane_off;
+        const U32 ta = (c >> 5) * ROW + lane_off;
+        const U32 tb = ((c >> 2) & 7u) * ROW + lane_off;
+        const U32 tc = (c & 3u) * ROW + lane_off;
 #pragma unroll
         for (int q = 0; q < NWL; q++) {
             T[q] = W::lds_read32(lds, ta + 4u * q);

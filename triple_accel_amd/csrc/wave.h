@@ -76,6 +76,17 @@ struct DevWave {
     static __device__ __forceinline__ U32 bcnt(U32 x, U32 acc) { return (U32)__builtin_popcount(x) + acc; }
     // ({hi,lo} >> N)[31:0], N in 1..31 -> v_alignbit_b32
     template <int N> static __device__ __forceinline__ U32 alignbit(U32 hi, U32 lo) { return __builtin_amdgcn_alignbit(hi, lo, N); }
+    // bits [off, off + width) of x -> v_bfe_u32 (kept opaque so that a following shift is not folded back into a mask)
+    static __device__ __forceinline__ U32 bfe(U32 x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+    // (bits [OFF, OFF + WIDTH) of x << SH) + base as exactly v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise re-canonicalises the
+    // field extract into shift + mask + add: three instructions per table address)
+    template <int OFF, int WIDTH, int SH> static __device__ __forceinline__ U32 field_addr(U32 x, U32 base) {
+        U32 r;
+        asm("v_bfe_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(r) : "v"(x), "n"(OFF), "n"(WIDTH), "n"(SH), "v"(base));
+        return r;
+    }
+    // (a << s) + b -> v_lshl_add_u32
+    static __device__ __forceinline__ U32 lshl_add(U32 a, uint32_t s, U32 b) { return (a << s) + b; }
     // per-lane shift amounts (< 32)
     static __device__ __forceinline__ U32 shlv(U32 x, U32 s) { return x << s; }
     static __device__ __forceinline__ U32 shrv(U32 x, U32 s) { return x >> s; }
