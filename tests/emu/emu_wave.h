@@ -95,9 +95,6 @@ struct EmuWave {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> N); return r;
     }
     static U32 bfe(const U32 &x, uint32_t off, uint32_t width) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] >> off) & ((1u << width) - 1u); return r; }
-    template <int OFF, int WIDTH, int SH> static U32 field_addr(const U32 &x, const U32 &base) {
-        V32 r; for (int i = 0; i < 64; i++) r.v[i] = (((x.v[i] >> OFF) & ((1u << WIDTH) - 1u)) << SH) + base.v[i]; return r;
-    }
     static U32 lshl_add(const U32 &a, uint32_t s, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] << s) + b.v[i]; return r; }
     static U32 shlv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] << (s.v[i] & 31); return r; }
     static U32 shrv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] >> (s.v[i] & 31); return r; }

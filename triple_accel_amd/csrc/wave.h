@@ -78,13 +78,8 @@ struct DevWave {
     template <int N> static __device__ __forceinline__ U32 alignbit(U32 hi, U32 lo) { return __builtin_amdgcn_alignbit(hi, lo, N); }
     // bits [off, off + width) of x -> v_bfe_u32 (kept opaque so that a following shift is not folded back into a mask)
     static __device__ __forceinline__ U32 bfe(U32 x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
-    // (bits [OFF, OFF + WIDTH) of x << SH) + base as exactly v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise re-canonicalises the
-    // field extract into shift + mask + add: three instructions per table address)
-    template <int OFF, int WIDTH, int SH> static __device__ __forceinline__ U32 field_addr(U32 x, U32 base) {
-        U32 r;
-        asm("v_bfe_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(r) : "v"(x), "n"(OFF), "n"(WIDTH), "n"(SH), "v"(base));
-        return r;
-    }
+    // NOTE: no real instructions in inline asm in this file -- hipcc's hazard recogniser does not look inside asm
+    // statements (a v_dot4 result consumed by an asm VALU instruction two slots later read a stale value on gfx950).
     // (a << s) + b -> v_lshl_add_u32
     static __device__ __forceinline__ U32 lshl_add(U32 a, uint32_t s, U32 b) { return (a << s) + b; }
     // per-lane shift amounts (< 32)
