@@ -1,0 +1,62 @@
+"""-m gpu: the sharded search with the real HIP kernels as the per-rank search -- two processes (gloo for the tiny
+control-plane gathers, both ranks on cuda:0 since the test box has one GPU) must return the monolithic oracle result.
+On a multi-GPU node the same code runs one rank per GPU over RCCL (bench.py / dist.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, needle, hay, k, costs, cuts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import triple_accel_amd as T
+        from triple_accel_amd import dist as D
+        torch.cuda.set_device(0)
+        shard = hay[cuts[rank]:cuts[rank + 1]]
+        res = {}
+        for st in (T.SearchType.All, T.SearchType.Best):
+            ms = D.levenshtein_search_sharded(needle, shard, k, st, T.EditCosts(*costs))     # default local search: the HIP kernels
+            res[int(st)] = [tuple(m) for m in ms]
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("costs", [(1, 1, 0, None), (2, 1, 1, None)])
+def test_two_rank_sharded_search_with_hip_kernels(costs):
+    import datagen as Dg
+    import oracle_lib as O
+    g = Dg.rng(321)
+    needle = Dg.rand_str(g, 24)
+    k = 8
+    hay = Dg.planted_haystack(11, needle, 600_000, 5000, 6)
+    cuts = [0, 250_013, 600_000]                       # the cut runs through a planted copy's neighbourhood
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + costs[0]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, needle, hay, k, costs, cuts, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for st in (O.ALL, O.BEST):
+        want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+        assert len(want) > 0
+        for r in range(world):
+            assert out[r][int(st)] == want, (st, r)
