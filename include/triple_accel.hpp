@@ -54,11 +54,41 @@ inline std::uint32_t hamming(bytes a, bytes b) {                                
 inline std::optional<std::uint32_t> levenshtein_simd_k(bytes a, bytes b, std::uint32_t k) {   // src/levenshtein.rs:677
     std::uint32_t o; check_(ta_levenshtein_simd_k(a.data(), a.size(), b.data(), b.size(), k, &o)); return opt_(o);
 }
-// :714 -- (distance, traceback); trace_on = true is not on the GPU path yet (unsupported_error)
-inline std::optional<std::pair<std::uint32_t, std::nullopt_t>> levenshtein_simd_k_with_opts(bytes a, bytes b, std::uint32_t k, bool trace_on, const EditCosts &costs) {
-    std::uint32_t o; check_(ta_levenshtein_simd_k_with_opts(a.data(), a.size(), b.data(), b.size(), k, trace_on, costs.raw(), &o));
+// src/lib.rs:145-168
+enum class EditType { Match = 0, Mismatch = 1, AGap = 2, BGap = 3, Transpose = 4 };
+struct Edit { EditType edit; std::size_t count; bool operator==(const Edit &o) const { return edit == o.edit && count == o.count; } };
+using Traceback = std::optional<std::vector<Edit>>;
+
+inline std::vector<Edit> take_edits_(ta_edit *e, std::size_t n) {
+    std::vector<Edit> v; v.reserve(n);
+    for (std::size_t i = 0; i < n; i++) v.push_back(Edit{(EditType)e[i].edit, (std::size_t)e[i].count});
+    ta_free(e);
+    return v;
+}
+// :714 -- Some((distance, traceback)) / None; trace_on = true returns the run-length edit script (bands wider than
+// 4222 diagonals: unsupported_error -- use the scalar routine there)
+inline std::optional<std::pair<std::uint32_t, Traceback>> levenshtein_simd_k_with_opts(bytes a, bytes b, std::uint32_t k, bool trace_on, const EditCosts &costs) {
+    std::uint32_t o;
+    if (trace_on) {
+        ta_edit *e = nullptr; std::size_t n = 0;
+        check_(ta_levenshtein_trace(a.data(), a.size(), b.data(), b.size(), k, costs.raw(), &o, &e, &n));
+        if (o == TA_NONE) return std::nullopt;
+        return std::make_pair(o, Traceback(take_edits_(e, n)));
+    }
+    check_(ta_levenshtein_simd_k_with_opts(a.data(), a.size(), b.data(), b.size(), k, 0, costs.raw(), &o));
     if (o == TA_NONE) return std::nullopt;
-    return std::make_pair(o, std::nullopt);
+    return std::make_pair(o, Traceback(std::nullopt));
+}
+// :1480
+inline std::pair<std::uint32_t, Traceback> levenshtein_exp_with_opts(bytes a, bytes b, bool trace_on, const EditCosts &costs) {
+    std::uint32_t o;
+    if (trace_on) {
+        ta_edit *e = nullptr; std::size_t n = 0;
+        check_(ta_levenshtein_exp_trace(a.data(), a.size(), b.data(), b.size(), costs.raw(), &o, &e, &n));
+        return std::make_pair(o, Traceback(take_edits_(e, n)));
+    }
+    check_(ta_levenshtein_exp_with_opts(a.data(), a.size(), b.data(), b.size(), 0, costs.raw(), &o));
+    return std::make_pair(o, Traceback(std::nullopt));
 }
 inline std::uint32_t levenshtein(bytes a, bytes b) { std::uint32_t o; check_(ta_levenshtein(a.data(), a.size(), b.data(), b.size(), &o)); return o; }          // :1397
 inline std::uint32_t rdamerau(bytes a, bytes b) { std::uint32_t o; check_(ta_rdamerau(a.data(), a.size(), b.data(), b.size(), &o)); return o; }                // :1419
