@@ -131,6 +131,7 @@ struct EmuWave {
     static void store_u32(uint32_t *p, const U32 &idx, const U32 &v, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) p[idx.v[i]] = v.v[i];
     }
+    static Ptr ptr_splat(const uint8_t *p) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p; return r; }
     static Ptr ptr_add(const Ptr &p, const U32 &off) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] + off.v[i]; return r; }
     static Ptr sel_ptr(const Bool &c, const Ptr &a, const Ptr &b) { VP r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 

@@ -32,3 +32,34 @@ extern "C" int emu_lev_widebits(const uint8_t *a_blob, const uint64_t *a_off, co
     free(lds);
     return 0;
 }
+
+// one huge pair as tiles: the launches of the host driver are simulated diagonal by diagonal; within a diagonal the
+// tiles run in the given order (0 = ascending stripes, 1 = descending) -- both must give the same answer
+template <int NWL, bool TR>
+static uint32_t huge_run(const uint8_t *a, uint32_t alen, const uint8_t *b, uint32_t blen, uint32_t k, uint32_t CB, int order) {
+    using K = LevWideBits<EmuWave, NWL, TR>;
+    const bool swap = alen > blen;
+    typename K::Huge H;
+    H.ap = swap ? b : a; H.bp = swap ? a : b;
+    H.n = swap ? blen : alen; H.m = swap ? alen : blen;
+    H.u = lev_batch_unit_k(k, 1, 1, 0, H.m); H.k = k; H.CB = CB;
+    if (H.m - H.n > H.u) return 0xFFFFFFFFu;
+    if (H.n == 0) return H.m <= k ? H.m : 0xFFFFFFFFu;
+    const uint32_t stripes = K::huge_stripes(H.n);
+    H.line = (uint64_t)H.m + 66;
+    std::vector<uint32_t> lines((size_t)stripes * 3 * H.line, 0xDEADBEEFu), state((size_t)stripes * 64 * 16, 0xDEADBEEFu);
+    uint32_t out = 0xDEADBEEFu;
+    H.lines = lines.data(); H.state = state.data(); H.out = &out;
+    uint8_t *lds = (uint8_t *)calloc(33 * 64 * 2 * 4 + 64, 1);
+    const uint32_t D = K::huge_diagonals(H.n, H.m, H.u, CB);
+    for (uint32_t d = 0; d < D; d++)
+        for (uint32_t i = 0; i < stripes; i++) K::run_tile(H, order ? stripes - 1 - i : i, d, lds);
+    free(lds);
+    return out;
+}
+
+extern "C" uint32_t emu_lev_widebits_huge(const uint8_t *a, uint32_t alen, const uint8_t *b, uint32_t blen, uint32_t k, int has_t,
+                                          int nwl, uint32_t CB, int order) {
+    if (nwl == 1) return has_t ? huge_run<1, true>(a, alen, b, blen, k, CB, order) : huge_run<1, false>(a, alen, b, blen, k, CB, order);
+    return has_t ? huge_run<2, true>(a, alen, b, blen, k, CB, order) : huge_run<2, false>(a, alen, b, blen, k, CB, order);
+}

@@ -31,6 +31,8 @@ def lib():
         L.emu_ham_search.restype = C.c_int
         L.emu_ham_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int,
                                      C.c_void_p, C.c_uint64, C.c_void_p]
+        L.emu_lev_widebits_huge.restype = C.c_uint32
+        L.emu_lev_widebits_huge.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -156,3 +158,11 @@ def ham_search(needle, haystack, k, tile=512, words=0):
     if rc:
         raise RuntimeError("emu_ham_search rc=%d" % rc)
     return [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]
+
+
+def lev_widebits_huge(a, b, k, trans=False, nwl=1, tile_steps=256, order=0):
+    """One pair through the tiled (many-wavefront) form of the row-blocked kernel; order = tile order inside a launch."""
+    a = bytes(a) + b"\0" * 16
+    b = bytes(b) + b"\0" * 16
+    v = lib().emu_lev_widebits_huge(a, len(a) - 16, b, len(b) - 16, k, int(bool(trans)), nwl, tile_steps, order)
+    return None if v == 0xFFFFFFFF else int(v)

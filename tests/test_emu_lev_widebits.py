@@ -96,3 +96,22 @@ def test_widebits_several_stripes_and_band_limited_columns():
             assert got == oracle(a, b, k, trans), (trans, k)
     got = E.lev_widebits(a[:3], b[:3], 0xFFFFFFFF, True, nwl=2, nwaves=1)      # 4096-row stripes: 2 stripes
     assert got == oracle(a[:3], b[:3], 0xFFFFFFFF, True)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_widebits_huge_pair_as_tiles(trans):
+    """The many-wavefront form for ONE long pair: stripes x tiles launched diagonal by diagonal.  Every tile size and
+    both tile orders inside a launch must reproduce the oracle -- a wrong dependency offset between the stripes'
+    tile grids shows up as a read of an unwritten boundary entry (the buffers are poisoned)."""
+    g = Dg.rng(0x4867)
+    x = Dg.rand_str(g, 6500)
+    y = Dg.mutate(g, x, 200, True)
+    z = bytes(g.integers(97, 100, size=5000).astype(np.uint8))
+    w = bytes(g.integers(97, 100, size=4600).astype(np.uint8))
+    cases = [(x, y, 0xFFFFFFFF), (y, x, 400), (x, y, 230), (z, w, 0xFFFFFFFF), (x[:2048], y[:2048], 0xFFFFFFFF), (x[:2049], y[:3000], 0xFFFFFFFF),
+             (x, x[:6000], 600), (x[:100], y[:4000], 0xFFFFFFFF)]
+    for a, b, k in cases:
+        want = oracle([a], [b], k, trans)[0]
+        for tile_steps, order in [(64, 0), (256, 1), (1024, 0), (4096, 1)]:
+            assert E.lev_widebits_huge(a, b, k, trans, nwl=1, tile_steps=tile_steps, order=order) == want, (len(a), len(b), k, tile_steps, order)
+    assert E.lev_widebits_huge(x, y, 0xFFFFFFFF, trans, nwl=2, tile_steps=512, order=1) == oracle([x], [y], 0xFFFFFFFF, trans)[0]

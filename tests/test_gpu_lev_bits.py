@@ -225,3 +225,29 @@ def test_unforced_dispatch_sweep():
                 seen.add(kernel_id())
                 assert np.array_equal(got, want), (n, k, costs, kernel_id(), got, want)
     assert seen == {1, 2, 3, 4}, seen
+
+
+def test_one_long_pair_is_spread_over_many_wavefronts(monkeypatch):
+    """The single-call API on long strings: the pair's stripes are cut into tiles and launched diagonal by diagonal.  Same
+    answers as the one-wavefront form (TA_WB_NO_TILES=1) and as the oracle, for several tile lengths, both cost families,
+    bounded k (band-limited stripes) and the exp loop."""
+    import triple_accel_amd as T
+    g = Dg.rng(0x7117)
+    x = Dg.rand_str(g, 30000)
+    y = Dg.mutate(g, x, 700, True)
+    z = Dg.rand_str(g, 26000)
+    for tile in ("", "64", "1024"):
+        if tile:
+            monkeypatch.setenv("TA_WB_TILE_STEPS", tile)
+        for a, b in ((x, y), (y, x), (x, z)):
+            assert T.levenshtein(a, b) == O.levenshtein(a, b), (tile, len(a), len(b))
+            assert kernel_id() == 4 and T.last_launch_info()["grid"] > 10        # `grid` reports the number of launches here
+        assert T.rdamerau(x, y) == O.rdamerau(x, y)
+        assert T.levenshtein_simd_k(x, y, 2000) == O.levenshtein_simd_k_with_opts(x, y, 2000, False, LEV)[0]
+        assert T.levenshtein_simd_k(x, y, 500) == O.levenshtein_simd_k_with_opts(x, y, 500, False, LEV)[0] == 490   # band barely wide enough
+        assert T.levenshtein_simd_k(x, y, 489) is None
+    monkeypatch.delenv("TA_WB_TILE_STEPS")
+    assert T.levenshtein_exp(x, y) == O.levenshtein_exp(x, y)
+    d_tiles = T.levenshtein(x, z)
+    monkeypatch.setenv("TA_WB_NO_TILES", "1")
+    assert T.levenshtein(x, z) == d_tiles

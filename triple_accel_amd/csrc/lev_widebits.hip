@@ -46,4 +46,50 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
     return hipGetLastError();
 }
 
+// ---- one huge pair: tiles of the stripes' sweeps, one launch per diagonal of the (stripe, tile) grid (lev_widebits_body.h)
+template <int NWL, bool TRANS>
+__global__ __launch_bounds__(64) void lev_widebits_huge_kernel(typename LevWideBits<DevWave, NWL, TRANS>::Huge H, uint32_t d) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    LevWideBits<DevWave, NWL, TRANS>::run_tile(H, blockIdx.x, d, lds);
+}
+
+template <int NWL, bool TRANS>
+static hipError_t huge_launch_t(const uint8_t *ap, const uint8_t *bp, uint32_t n, uint32_t m, uint32_t u, uint32_t k, uint32_t *out,
+                                hipStream_t s, uint32_t *launches_out) {
+    using K = LevWideBits<DevWave, NWL, TRANS>;
+    typename K::Huge H;
+    H.ap = ap; H.bp = bp; H.n = n; H.m = m; H.u = u; H.k = k; H.out = out;
+    const uint32_t stripes = K::huge_stripes(n);
+    uint64_t cb = ((uint64_t)m / 16 + 63) & ~(uint64_t)63;         // ~16 tiles per stripe, 1024..8192 steps each
+    if (cb < 1024) cb = 1024;
+    if (cb > 8192) cb = 8192;
+    if (const char *e = getenv("TA_WB_TILE_STEPS")) { long v = atol(e); if (v >= 64) cb = (uint64_t)v & ~(uint64_t)63; }
+    H.CB = (uint32_t)cb;
+    H.line = (uint64_t)m + 66;
+    Scratch &ls = tls_scratch(6), &ss = tls_scratch(8);    // (slots 4 and 5 hold the exp loop's subsets while this runs)
+    if (ls.ensure((size_t)stripes * 3 * H.line * sizeof(uint32_t)) != TA_OK) return hipErrorOutOfMemory;
+    if (ss.ensure((size_t)stripes * 64 * 16 * sizeof(uint32_t)) != TA_OK) return hipErrorOutOfMemory;
+    H.lines = (uint32_t *)ls.dev; H.state = (uint32_t *)ss.dev;
+    const uint32_t D = K::huge_diagonals(n, m, u, H.CB);
+    const uint32_t lds = K::LDS_BYTES;
+    for (uint32_t d = 0; d < D; d++) {
+        // stripes q with a tile on this diagonal form a contiguous range; launching all stripes keeps the host loop trivial
+        hipLaunchKernelGGL((lev_widebits_huge_kernel<NWL, TRANS>), dim3(stripes), dim3(64), lds, s, H, d);
+    }
+    if (launches_out) *launches_out = D;
+    return hipGetLastError();
+}
+
+// a and b are device pointers to the ONE pair's strings (with read slack); out = the pair's result slot
+hipError_t lev_widebits_huge_launch(const uint8_t *a, uint32_t a_len, const uint8_t *b, uint32_t b_len, uint32_t u, uint32_t k,
+                                    int rows_per_lane, bool trans, uint32_t *out, hipStream_t s, uint32_t *launches_out) {
+    const bool swap = a_len > b_len;                             // rows <- the shorter string
+    const uint8_t *ap = swap ? b : a, *bp = swap ? a : b;
+    const uint32_t n = swap ? b_len : a_len, m = swap ? a_len : b_len;
+    if (rows_per_lane == 64) return trans ? huge_launch_t<2, true>(ap, bp, n, m, u, k, out, s, launches_out)
+                                          : huge_launch_t<2, false>(ap, bp, n, m, u, k, out, s, launches_out);
+    return trans ? huge_launch_t<1, true>(ap, bp, n, m, u, k, out, s, launches_out)
+                 : huge_launch_t<1, false>(ap, bp, n, m, u, k, out, s, launches_out);
+}
+
 }  // namespace ta

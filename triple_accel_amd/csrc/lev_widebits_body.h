@@ -312,6 +312,201 @@ struct LevWideBits {
             W::store_u32(P.out, pair, W::splat(res), lane0);
         }
     }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // ONE huge pair spread over many wavefronts.  The sweep of stripe q is cut into tiles of CB steps; tile (q, kb)
+    // needs the state tile (q, kb-1) left behind and the boundary line stripe q-1 has written up to the columns it
+    // reads -- which, with the tile grid of stripe q shifted by off_q steps against stripe q-1 (the 63-step lane skew,
+    // the 64-column read-ahead of the boundary chunks, and the band's column offset between the stripes), is complete
+    // once tile (q-1, kb) has run.  So all tiles with q + kb = d are independent: the host launches d = 0, 1, 2, ...
+    // on one stream (no flags, no spinning), every launch one wavefront per stripe.
+    struct Huge {
+        const uint8_t *ap, *bp;      // rows (the shorter string) / columns
+        uint32_t n, m, u, k;
+        uint32_t CB;                 // steps per tile, a multiple of 64
+        uint32_t *lines;             // stripes x {HP, HN, transposition term} boundary lines of `line` u32 each
+        uint64_t line;
+        uint32_t *state;             // stripes x 64 lanes x 16 dwords
+        uint32_t *out;
+    };
+    struct Stripe {
+        uint32_t i0, nrows, jlo, jhi, Cn, steps, plo, phi;
+        uint64_t off;                // steps by which this stripe's tile grid trails stripe 0's
+    };
+    static constexpr uint32_t HUGE_ROWS = 64u * RB;
+
+    static TA_HD inline uint32_t huge_stripes(uint32_t n) { return (n + HUGE_ROWS - 1u) / HUGE_ROWS; }
+
+    static TA_HD inline Stripe huge_stripe(uint32_t n, uint32_t m, uint32_t u, uint32_t q) {
+        const uint32_t tband = (u - (m - n)) >> 1;
+        const uint64_t below = tband, above = (uint64_t)tband + (m - n);
+        Stripe S{};
+        uint32_t plo = 1, phi = 0, jlo_prev = 1;
+        uint64_t off = 0;
+        for (uint32_t i = 0; i <= q; i++) {
+            S.i0 = i * HUGE_ROWS;
+            S.nrows = (n - S.i0 < HUGE_ROWS) ? n - S.i0 : HUGE_ROWS;
+            S.jlo = ((uint64_t)S.i0 + 1u > below) ? (uint32_t)(S.i0 + 1u - below) : 1u;
+            const uint64_t hi64 = (uint64_t)S.i0 + S.nrows + above;
+            S.jhi = hi64 < m ? (uint32_t)hi64 : m;
+            S.Cn = S.jhi - S.jlo + 1u;
+            S.steps = S.Cn + (S.nrows - 1u) / RB;
+            if (i) off = (off + (S.jlo - jlo_prev) + 128u + 63u) & ~(uint64_t)63;
+            S.off = off; S.plo = plo; S.phi = phi;
+            plo = S.jlo; phi = S.jhi; jlo_prev = S.jlo;
+        }
+        return S;
+    }
+    // number of launches: the last diagonal that holds a tile, plus one
+    static TA_HD inline uint32_t huge_diagonals(uint32_t n, uint32_t m, uint32_t u, uint32_t CB) {
+        const uint32_t stripes = huge_stripes(n);
+        uint64_t dmax = 0;
+        for (uint32_t q = 0; q < stripes; q++) {
+            const Stripe S = huge_stripe(n, m, u, q);
+            const uint64_t d = q + (S.off + S.steps - 1u) / CB;
+            if (d > dmax) dmax = d;
+        }
+        return (uint32_t)(dmax + 1u);
+    }
+
+    static TA_HD inline void build_tables(uint8_t *lds, U32 lane, U32 lane_off, Ptr ap, uint32_t n, uint32_t i0) {
+#pragma unroll 1
+        for (uint32_t e = 0; e < TABLE_ROWS; e++) {
+#pragma unroll
+            for (int q = 0; q < NWL; q++) W::lds_write32(lds, lane_off + e * ROW + 4u * q, W::splat(0));
+        }
+        W::lds_wave_sync();
+        const U32 row0 = lane * RB + i0;
+#pragma unroll 1
+        for (uint32_t r0 = 0; r0 < RB; r0 += 16) {
+            const U32 ia = row0 + r0;
+            auto piece = W::gload16(W::ptr_add(ap, ia), ia < n);
+            const U32 w4[4] = {W::qword(piece, 0), W::qword(piece, 1), W::qword(piece, 2), W::qword(piece, 3)};
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const U32 ch = W::byte_of(w4[r >> 2], r & 3);
+                const Bool ok = (ia + (uint32_t)r) < n;
+                const uint32_t bit = 1u << ((r0 + r) & 31u), qo = 4u * ((r0 + r) >> 5);
+                W::lds_or32(lds, (ch >> 5) * ROW + lane_off + qo, W::splat(bit), ok);
+                W::lds_or32(lds, ((ch >> 2) & 7u) * ROW + lane_off + B_BASE + qo, W::splat(bit), ok);
+                W::lds_or32(lds, (ch & 3u) * ROW + lane_off + C_BASE + qo, W::splat(bit), ok);
+            }
+        }
+        W::lds_wave_sync();
+    }
+
+    // tile (q, d - q) of the huge pair; n >= 1, m - n <= u checked by the host
+    static TA_HD inline void run_tile(const Huge &H, uint32_t q, uint32_t d, uint8_t *lds) {
+        const uint32_t stripes = huge_stripes(H.n);
+        if (q >= stripes || d < q) return;
+        const uint32_t kb = d - q;
+        const Stripe S = huge_stripe(H.n, H.m, H.u, q);
+        const uint64_t lo = (uint64_t)kb * H.CB, hi = lo + H.CB;
+        if (hi <= S.off) return;
+        const uint32_t s_begin = lo > S.off ? (uint32_t)(lo - S.off) : 0u;
+        if (s_begin >= S.steps) return;
+        const uint32_t s_end = (hi - S.off < S.steps) ? (uint32_t)(hi - S.off) : S.steps;
+        const bool last = (q + 1u == stripes);
+
+        const U32 lane = W::lane();
+        const U32 lane_off = lane * (NWL * 4u);
+        const Bool all = (lane == lane);
+        const Ptr ap = W::ptr_splat(H.ap), bp = W::ptr_splat(H.bp);
+        Sweep Z;
+        Z.m = H.m; Z.jlo = S.jlo; Z.Cn = S.Cn; Z.plo = S.plo; Z.phi = S.phi;
+        uint32_t *rd = q ? H.lines + (uint64_t)(q - 1u) * 3u * H.line : nullptr;
+        uint32_t *wr = last ? nullptr : H.lines + (uint64_t)q * 3u * H.line;
+        Z.inP = rd; Z.inM = rd ? rd + H.line : nullptr; Z.inX = rd ? rd + 2u * H.line : nullptr;
+        Z.outP = wr; Z.outM = wr ? wr + H.line : nullptr; Z.outX = wr ? wr + 2u * H.line : nullptr;
+
+        build_tables(lds, lane, lane_off, ap, H.n, S.i0);
+
+        State st;
+        U32 c;
+        uint32_t *sv = H.state + (uint64_t)q * 64u * 16u;
+        const U32 svi = lane * 16u;
+        if (s_begin == 0) {
+#pragma unroll
+            for (int w = 0; w < NWL; w++) {
+                st.Pv[w] = W::splat(0xFFFFFFFFu); st.Mv[w] = W::splat(0);
+                st.D0p[w] = W::splat(0xFFFFFFFFu); st.Eqp[w] = W::splat(0);
+            }
+            st.sP = W::splat(0); st.sM = W::splat(0x80000000u); st.sX = W::splat(0); st.sc = W::splat(256);
+            st.rP = W::splat(0x80000000u); st.rM = W::splat(0); st.rX = W::splat(0);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NWL; w++) {
+                st.Pv[w] = W::load_u32(sv, svi + (uint32_t)w, all, 0u); st.Mv[w] = W::load_u32(sv, svi + 2u + (uint32_t)w, all, 0u);
+                st.D0p[w] = W::load_u32(sv, svi + 4u + (uint32_t)w, all, 0u); st.Eqp[w] = W::load_u32(sv, svi + 6u + (uint32_t)w, all, 0u);
+            }
+            st.sP = W::load_u32(sv, svi + 8u, all, 0u); st.sM = W::load_u32(sv, svi + 9u, all, 0u); st.sX = W::load_u32(sv, svi + 10u, all, 0u);
+            st.sc = W::load_u32(sv, svi + 11u, all, 0u); st.rP = W::load_u32(sv, svi + 12u, all, 0u); st.rM = W::load_u32(sv, svi + 13u, all, 0u);
+            st.rX = W::load_u32(sv, svi + 14u, all, 0u);
+        }
+        const U32 colb = lane + (S.jlo + s_begin);                 // the 64 columns of b whose chunk holds step s_begin + 1
+        U32 cb = W::gload_u8(W::ptr_add(bp, colb - 1u), colb <= H.m);
+        if (s_begin == 0) c = W::from_lower(st.sc, W::splat(W::readlane(cb, 0)));
+        else c = W::load_u32(sv, svi + 15u, all, 0u);
+        U32 hb[3] = {W::splat(0x80000000u), W::splat(0), W::splat(0)};
+        U32 T[3 * NWL], T2[3 * NWL], c2;
+        lookup(lds, c, lane_off, T);
+
+        uint32_t s = s_begin;
+        const uint32_t lim_main = s_end < S.Cn ? s_end : S.Cn;     // steps below Cn: no lane has finished yet
+#define TA_SWEEP(TAILV, BNDV, OUTV, LIMIT)                                                                               \
+    for (; s + 1u < (LIMIT); s += 2u) {                                                                                  \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T, c2, T2);                                \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s + 1u, cb, hb, c2, T2, c, T);                           \
+    }                                                                                                                    \
+    if (s < (LIMIT)) {                                                                                                   \
+        iter<TAILV, BNDV, OUTV>(st, lds, lane, lane_off, bp, Z, s, cb, hb, c, T, c2, T2);                                \
+        c = c2;                                                                                                          \
+        for (int q_ = 0; q_ < 3 * NWL; q_++) T[q_] = T2[q_];                                                             \
+        s++;                                                                                                             \
+    }
+        if (q == 0 && last) { TA_SWEEP(false, false, false, lim_main); TA_SWEEP(true, false, false, s_end); }
+        else if (q == 0) { TA_SWEEP(false, false, true, s_end); }
+        else if (!last) { TA_SWEEP(false, true, true, s_end); }
+        else { TA_SWEEP(false, true, false, lim_main); TA_SWEEP(true, true, false, s_end); }
+#undef TA_SWEEP
+
+        if (s_end < S.steps) {                                    // hand the sweep over to tile (q, kb + 1)
+#pragma unroll
+            for (int w = 0; w < NWL; w++) {
+                W::store_u32(sv, svi + (uint32_t)w, st.Pv[w], all); W::store_u32(sv, svi + 2u + (uint32_t)w, st.Mv[w], all);
+                W::store_u32(sv, svi + 4u + (uint32_t)w, st.D0p[w], all); W::store_u32(sv, svi + 6u + (uint32_t)w, st.Eqp[w], all);
+            }
+            W::store_u32(sv, svi + 8u, st.sP, all); W::store_u32(sv, svi + 9u, st.sM, all); W::store_u32(sv, svi + 10u, st.sX, all);
+            W::store_u32(sv, svi + 11u, st.sc, all); W::store_u32(sv, svi + 12u, st.rP, all); W::store_u32(sv, svi + 13u, st.rM, all);
+            W::store_u32(sv, svi + 14u, st.rX, all); W::store_u32(sv, svi + 15u, c, all);
+        } else if (last) {
+            // D[n][m] = D[i0][jlo-1] of the last stripe (re-anchored stripe by stripe) + steps right along row i0 to column m
+            // + steps down column m to row n
+            uint32_t anchor = 0;
+            for (uint32_t i = 1; i <= q; i++) {
+                const Stripe Si = huge_stripe(H.n, H.m, H.u, i);
+                const uint32_t *lp = H.lines + (uint64_t)(i - 1u) * 3u * H.line;
+                anchor += HUGE_ROWS;
+                if (Si.jlo > Si.plo) anchor += sum_steps(lp, lp + H.line, Si.plo, Si.jlo - 1u, lane);
+            }
+            uint32_t right = H.m - (S.jlo - 1u);
+            if (q && S.phi >= S.jlo) {
+                const uint32_t to = S.phi < H.m ? S.phi : H.m;
+                right = sum_steps(Z.inP, Z.inM, S.jlo, to, lane) + (H.m - to);
+            }
+            U32 contrib = W::splat(0);
+#pragma unroll
+            for (int w = 0; w < NWL; w++) {
+                const U32 first = lane * RB + 32u * (uint32_t)w;
+                const U32 cnt = W::sel(first >= S.nrows, W::splat(0), W::sel(first + 32u <= S.nrows, W::splat(32), W::splat(S.nrows) - first));
+                const U32 msk = W::sel(cnt >= 32u, W::splat(0xFFFFFFFFu), W::shlv(W::splat(1), cnt) - 1u);
+                contrib = W::bcnt(st.Pv[w] & msk, contrib);
+                contrib = contrib - W::bcnt(st.Mv[w] & msk, W::splat(0));
+            }
+            const uint32_t total = anchor + right + W::wave_sum(contrib);
+            W::store_u32(H.out, W::splat(0), W::splat(total <= H.k ? total : 0xFFFFFFFFu), lane == 0u);   // :539-541
+        }
+    }
 };
 
 }  // namespace ta

@@ -44,7 +44,7 @@ int Scratch::ensure(size_t bytes) {
 }
 Scratch::~Scratch() { /* device memory is reclaimed at process exit; hipFree during TLS teardown is unsafe */ }
 Scratch &tls_scratch(int which) {
-    static thread_local Scratch s[8];
+    static thread_local Scratch s[12];
     return s[which];
 }
 
@@ -115,6 +115,15 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         TA_HIP(lev_bits_launch(P, bp, trans, st, &grid, &lds));
         li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
+    } else if (ch.kernel == LEV_K_WIDEBITS && n_work == 1 && !a->off && !b->off && a->len <= 0xFFFFFFF0ull && b->len <= 0xFFFFFFF0ull &&
+               (a->len < b->len ? a->len : b->len) > 2ull * 64ull * (uint64_t)ch.rows_per_lane &&
+               (a->len > b->len ? a->len - b->len : b->len - a->len) <= bp.u && !env_int("TA_WB_NO_TILES")) {
+        // ONE long pair (the single-call API): its stripes' sweeps are cut into tiles and spread over many wavefronts
+        uint32_t launches = 0;
+        TA_HIP(lev_widebits_huge_launch(a->blob, (uint32_t)a->len, b->blob, (uint32_t)b->len, bp.u, k, ch.rows_per_lane, trans, out_dev, st,
+                                        &launches));
+        li.kernel = 4; li.diags_per_lane = (uint32_t)ch.rows_per_lane; li.lanes_per_pair = 64; li.pairs_per_wave = 1;
+        li.grid = launches; li.lds_bytes = 0; li.band_offset = 0;
     } else if (ch.kernel == LEV_K_WIDEBITS) {
         P.u = bp.u; P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
         uint32_t grid = 0, lds = 0;

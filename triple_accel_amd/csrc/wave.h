@@ -140,6 +140,7 @@ struct DevWave {
         if (pred) p[idx] = v;
     }
     static __device__ __forceinline__ Ptr ptr_add(Ptr p, U32 off) { return p + off; }
+    static __device__ __forceinline__ Ptr ptr_splat(const uint8_t *p) { return p; }
     static __device__ __forceinline__ Ptr sel_ptr(Bool c, Ptr a, Ptr b) { return c ? a : b; }
     // 16 bytes from an arbitrarily aligned global address (zeros where !pred)
     static __device__ __forceinline__ Q128 gload16(Ptr p, Bool pred) {
