@@ -251,3 +251,14 @@ def test_one_long_pair_is_spread_over_many_wavefronts(monkeypatch):
     d_tiles = T.levenshtein(x, z)
     monkeypatch.setenv("TA_WB_NO_TILES", "1")
     assert T.levenshtein(x, z) == d_tiles
+
+
+def test_a_few_long_pairs_in_a_fixed_length_batch():
+    """Up to 16 long fixed-length pairs take the tiled form pair after pair; more of them the one-wavefront-per-pair form."""
+    from triple_accel_amd import batch as B
+    for n in (3, 20):
+        am, bm = Dg.pairs_mutated_fixed(0x7C20 + n, n, 10000, 300)
+        got = B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), 0xFFFFFFFF).cpu().numpy().view(np.uint32)
+        assert kernel_id() == 4
+        want = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 0xFFFFFFFF)
+        assert np.array_equal(got, want), (n, got, want)

@@ -115,13 +115,16 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         TA_HIP(lev_bits_launch(P, bp, trans, st, &grid, &lds));
         li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
-    } else if (ch.kernel == LEV_K_WIDEBITS && n_work == 1 && !a->off && !b->off && a->len <= 0xFFFFFFF0ull && b->len <= 0xFFFFFFF0ull &&
+    } else if (ch.kernel == LEV_K_WIDEBITS && (n_work == 1 || (n_work <= 16 && !subset)) && !a->off && !b->off &&
+               a->len <= 0xFFFFFFF0ull && b->len <= 0xFFFFFFF0ull &&
                (a->len < b->len ? a->len : b->len) > 2ull * 64ull * (uint64_t)ch.rows_per_lane &&
                (a->len > b->len ? a->len - b->len : b->len - a->len) <= bp.u && !env_int("TA_WB_NO_TILES")) {
-        // ONE long pair (the single-call API): its stripes' sweeps are cut into tiles and spread over many wavefronts
+        // ONE long pair (the single-call API) or a handful of them (fixed-length batch): a pair's stripe sweeps are cut into
+        // tiles and spread over many wavefronts, pair after pair
         uint32_t launches = 0;
-        TA_HIP(lev_widebits_huge_launch(a->blob, (uint32_t)a->len, b->blob, (uint32_t)b->len, bp.u, k, ch.rows_per_lane, trans, out_dev, st,
-                                        &launches));
+        for (uint32_t p = 0; p < n_work; p++)
+            TA_HIP(lev_widebits_huge_launch(a->blob + (uint64_t)p * a->stride, (uint32_t)a->len, b->blob + (uint64_t)p * b->stride,
+                                            (uint32_t)b->len, bp.u, k, ch.rows_per_lane, trans, out_dev + p, st, &launches));
         li.kernel = 4; li.diags_per_lane = (uint32_t)ch.rows_per_lane; li.lanes_per_pair = 64; li.pairs_per_wave = 1;
         li.grid = launches; li.lds_bytes = 0; li.band_offset = 0;
     } else if (ch.kernel == LEV_K_WIDEBITS) {
