@@ -15,19 +15,26 @@ extern int g_emu_force_ch;
 // ---- bit-parallel band kernel (lev_bits_body.h)
 #include "lev_bits_body.h"
 
-template <int NA> static void run_bits(const LevParams &P, bool trans, uint32_t waves) {
+template <int NA> static void run_bits(const LevParams &P, bool trans, bool stat, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     for (uint32_t w = 0; w < waves; w++) {
-        if (trans) LevBits<EmuWave, NA, true>::run(P, w, lds);
-        else LevBits<EmuWave, NA, false>::run(P, w, lds);
+        if constexpr (NA >= 8) {
+            if (stat) {
+                if (trans) LevBits<EmuWave, NA, true, true>::run(P, w, lds);
+                else LevBits<EmuWave, NA, false, true>::run(P, w, lds);
+                continue;
+            }
+        }
+        if (trans) LevBits<EmuWave, NA, true, false>::run(P, w, lds);
+        else LevBits<EmuWave, NA, false, false>::run(P, w, lds);
     }
     free(lds);
 }
 
 extern "C" int emu_lev_bits(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
-                            uint32_t n, uint32_t k, int has_t, uint64_t max_len, int force_NA, uint32_t *out,
-                            uint32_t *plan_out /* NA, u, Tw */) {
-    LevBitsPlan pl = lev_bits_make_plan(k, 1, 1, 0, has_t != 0, 1, max_len, force_NA, g_emu_force_ch);
+                            uint32_t n, uint32_t k, int has_t, uint64_t max_len, int force_NA, int force_static, uint32_t *out,
+                            uint32_t *plan_out /* NA, u, Tw, static */) {
+    LevBitsPlan pl = lev_bits_make_plan(k, 1, 1, 0, has_t != 0, 1, max_len, force_NA, g_emu_force_ch, force_static);
     if (!pl.ok) return 1;
     LevParams P;
     P.a = StrView{a_blob, a_off, 0, 0};
@@ -35,10 +42,10 @@ extern "C" int emu_lev_bits(const uint8_t *a_blob, const uint64_t *a_off, const 
     P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
-    if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; }
+    if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.stat; }
     const uint32_t waves = (n + 63) / 64;
     switch (pl.NA) {
-#define CASE(d) case d: run_bits<d>(P, has_t != 0, waves); break;
+#define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, waves); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
         CASE(13) CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(26) CASE(28) CASE(30) CASE(32)
 #undef CASE

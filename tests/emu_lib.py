@@ -21,7 +21,7 @@ def lib():
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_lev_bits.restype = C.c_int
         L.emu_lev_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
-                                   C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+                                   C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_lev_widebits.restype = C.c_int
         L.emu_lev_widebits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                        C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
@@ -71,22 +71,23 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
     return res, dict(D=int(plan[0]), L=int(plan[1]), PW=int(plan[2]), u=int(plan[3]), o=int(plan[4]))
 
 
-def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0):
-    """Bit-parallel band kernel body (unit costs).  -> (list of dist|None, plan dict)"""
+def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
+    """Bit-parallel band kernel body (unit costs).  static: 0 planner's choice, 1 sliding window, 2 static window.
+    -> (list of dist|None, plan dict)"""
     lib().emu_lev_set_chunk(int(chunk))
     n = len(a_list)
     ab, ao = pack(a_list)
     bb, bo = pack(b_list)
     out = np.full(n, 0xDEADBEEF, dtype=np.uint32)
-    plan = np.zeros(3, dtype=np.uint32)
+    plan = np.zeros(4, dtype=np.uint32)
     max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
     rc = lib().emu_lev_bits(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, int(bool(trans)),
-                            max_len, force_NA, out.ctypes.data, plan.ctypes.data)
+                            max_len, force_NA, static, out.ctypes.data, plan.ctypes.data)
     lib().emu_lev_set_chunk(0)
     if rc:
         raise RuntimeError("emu_lev_bits rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
-    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
+    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=bool(plan[3]))
 
 
 def lev_widebits(a_list, b_list, k, trans=False, nwl=2, nwaves=3):

@@ -94,3 +94,32 @@ def test_bits_rejects_what_it_cannot_hold():
         E.lev_bits([b"a" * 300], [b"b" * 300], 126, True)      # 127 + 2 > 128
     got, _ = E.lev_bits([b"a" * 300], [b"b" * 300], 127, False)
     assert got == [None]
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bits_static_window_form(trans):
+    """The static-window form (registers move a dword every 4th column, sub-column s reads bit i from byte i + s) against
+    the oracle and against the sliding form: every window width it exists for, k at the edge of what the window holds,
+    ragged lengths (groups of 4 columns cut by a pair's end), several chunks."""
+    a, b = make_pairs(0x57A7, 130, 300, 20, trans)
+    for na in (8, 9, 12, 16, 18, 24, 32):
+        kmax = 4 * na - 3 - 1 - (2 if trans else 0)                     # widest band this window holds
+        for k in sorted({0, 5, kmax - 1, kmax}):
+            got, plan = E.lev_bits(a, b, k, trans, force_NA=na, static=2)
+            assert plan["static"] and plan["NA"] == na
+            assert got == oracle(a, b, k, trans), (na, k, trans, plan)
+    ea, eb = _edge_pairs(0xB175 + 32, 70, 80, 32)
+    for k in (31, 32, 33):
+        got, plan = E.lev_bits(ea, eb, k, trans, static=2)
+        slid, plan2 = E.lev_bits(ea, eb, k, trans, static=1)
+        assert plan["static"] and not plan2["static"]
+        assert got == slid == oracle(ea, eb, k, trans), (k, trans, plan, plan2)
+
+
+def test_bits_planner_picks_the_static_form_from_8_dwords():
+    got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 32, False)
+    assert plan["static"] and plan["NA"] == 9                                 # cfg2: 33 diagonals in a 36-byte window
+    got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 8, True)
+    assert not plan["static"] and plan["NA"] == 3                             # cfg4: too narrow to pay for itself
+    got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 33, False)
+    assert plan["static"] and plan["NA"] == 10

@@ -28,14 +28,33 @@ def test_bits_ragged_vs_oracle(costs):
 
 
 def test_bits_every_window_width(monkeypatch):
+    """Every instantiated window width, in the sliding form (TA_BITS_STATIC=1) and, from 8 dwords on, the static form (=2)."""
     a, b = ragged_pairs(22, 3000, 90, 9, True)
     for na in list(range(1, 17)) + list(range(18, 33, 2)):
         monkeypatch.setenv("TA_FORCE_NA", str(na))
-        for costs in (LEV, RDAM):
-            k = max(0, min(4 * na - 1 - (2 if costs[3] else 0), 9))
-            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
-            assert kernel_id() == 3
-            assert np.array_equal(got, want), (na, k, costs, np.flatnonzero(got != want)[:10])
+        for mode in ("1", "2") if na >= 8 else ("1",):
+            monkeypatch.setenv("TA_BITS_STATIC", mode)
+            for costs in (LEV, RDAM):
+                k = max(0, min(4 * na - 4 - (2 if costs[3] else 0), 9))
+                got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+                assert kernel_id() == 3
+                assert np.array_equal(got, want), (na, mode, k, costs, np.flatnonzero(got != want)[:10])
+
+
+def test_bits_static_equals_sliding_on_long_ragged_strings(monkeypatch):
+    g = Dg.rng(0x57A7)
+    a, b = [], []
+    for n in (3, 64, 65, 255, 256, 257, 1000, 3001):
+        x = Dg.rand_str(g, n)
+        a += [x, x, x[: n // 2]]
+        b += [Dg.mutate(g, x, 30, True), Dg.rand_str(g, n + 2), x]
+    for k, costs in [(32, LEV), (33, LEV), (35, RDAM), (60, LEV), (100, RDAM), (125, LEV)]:
+        monkeypatch.setenv("TA_BITS_STATIC", "2")
+        st = gpu_k(a, b, k, costs)
+        assert kernel_id() == 3
+        monkeypatch.setenv("TA_BITS_STATIC", "1")
+        sl = gpu_k(a, b, k, costs)
+        assert np.array_equal(st, sl) and np.array_equal(st, oracle_k(a, b, k, costs)), (k, costs)
 
 
 def test_bits_chunk_lengths_and_long_strings(monkeypatch):

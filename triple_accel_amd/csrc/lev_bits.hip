@@ -8,18 +8,26 @@ namespace ta {
 
 constexpr int BITS_WAVES_PER_BLOCK = 4;
 
-template <int NA, bool TRANS>
+template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, NA, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    LevBits<DevWave, NA, TRANS, STATIC>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
 template <int NA>
-static hipError_t launch_na(const LevParams &P, bool trans, uint32_t grid, uint32_t wpb, size_t lds, hipStream_t s) {
+static hipError_t launch_na(const LevParams &P, bool trans, bool stat, uint32_t grid, uint32_t wpb, size_t lds, hipStream_t s) {
     dim3 g(grid), b(64 * wpb);
-    if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true>), g, b, lds, s, P);
-    else hipLaunchKernelGGL((lev_bits_kernel<NA, false>), g, b, lds, s, P);
+    if constexpr (NA >= 8) {
+        if (stat) {
+            if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true, true>), g, b, lds, s, P);
+            else hipLaunchKernelGGL((lev_bits_kernel<NA, false, true>), g, b, lds, s, P);
+            return hipGetLastError();
+        }
+    }
+    if (stat) return hipErrorInvalidValue;
+    if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true, false>), g, b, lds, s, P);
+    else hipLaunchKernelGGL((lev_bits_kernel<NA, false, false>), g, b, lds, s, P);
     return hipGetLastError();
 }
 
@@ -35,7 +43,7 @@ hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
     switch (pl.NA) {
-#define TA_CASE(n) case n: return launch_na<n>(P, trans, grid, wpb, lds, s);
+#define TA_CASE(n) case n: return launch_na<n>(P, trans, pl.stat, grid, wpb, lds, s);
         TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)
         TA_CASE(9) TA_CASE(10) TA_CASE(11) TA_CASE(12) TA_CASE(13) TA_CASE(14) TA_CASE(15) TA_CASE(16)
         TA_CASE(18) TA_CASE(20) TA_CASE(22) TA_CASE(24) TA_CASE(26) TA_CASE(28) TA_CASE(30) TA_CASE(32)

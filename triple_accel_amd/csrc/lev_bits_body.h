@@ -22,11 +22,14 @@
 
 namespace ta {
 
-template <class W, int NA, bool TRANS>
+// STATIC: the bytes of `a` under the window stay put for 4 columns (sub-column s reads window bit i from byte i + s and
+// shifts the packed mismatch bits by s instead); the registers move a whole dword every 4th column.  Saves the NA
+// v_alignbyte per column of the sliding form at the price of 3 window bits.
+template <class W, int NA, bool TRANS, bool STATIC = false>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
-    static constexpr int NW = (NA + 7) / 8;            // dwords per bit-vector
-    static constexpr int WB = 4 * NA;                  // window bits (diagonals)
+    static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
+    static constexpr int NW = (WB + 31) / 32;          // dwords per bit-vector (also holds the 4*NA packed mismatch bits)
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
@@ -50,10 +53,10 @@ struct LevBits {
     }
 
     // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
-    template <bool CAP>
+    template <bool CAP, int S = 0>
     static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
         const U32 Bs = W::splat_byte(b_in);
-        U32 PM[NW], D0[NW];
+        U32 PM[NW], D0[NW], NE[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
             U32 ne = W::splat(0);
@@ -71,6 +74,11 @@ struct LevBits {
                 }
                 ne = p == 0 ? (acc >> 7) : (ne | (acc << (8 * p - 7)));
             }
+            NE[q] = ne;
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) {                  // STATIC: window bit i is register byte i + S
+            const U32 ne = (!STATIC || S == 0) ? NE[q] : ((q + 1 < NW) ? W::template alignbit<(S ? S : 1)>(NE[q + 1], NE[q]) : (NE[q] >> S));
             PM[q] = ~ne & wmask(q);
         }
         // D0 = (((PM & VP) + VP) ^ VP) | PM | VN      (Hyyro 2003, eq. for the diagonal zero-difference vector)
@@ -192,11 +200,38 @@ struct LevBits {
             const uint32_t t_hi = (t_lo + 64u < iters) ? t_lo + 64u : iters;
             const U32 ra = a_slot + da - t_lo, rb = b_slot + db - t_lo;   // LDS address = r + tp
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
+            if (STATIC) tp &= ~3u;                             // whole groups (the extra leading iterations slide zeros in)
             for (int part = 0; part < 2; part++) {
                 // the last 16 iterations of a chunk may read into the look-ahead bytes: commit them first (the fetch
                 // was issued at least 48 iterations ago)
                 const uint32_t p_hi = part == 0 ? (t_lo + 48u < t_hi ? t_lo + 48u : t_hi) : t_hi;
                 if (part == 1) { commit_look(); W::lds_wave_sync(); }
+                if (STATIC) {
+                    // groups of 4 iterations (tp a multiple of 4; T0 and the part limits are multiples of 4 except the very end)
+                    const bool cap = W::any(valid & (t_stop < p_hi));
+                    for (; tp < p_hi; tp += 4u) {
+#pragma unroll
+                        for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
+                        const U32 pa = ra + tp;
+                        st.AW[NA - 1] = W::lds_u8(lds, pa) | (W::lds_u8(lds, pa + 1u) << 8) | (W::lds_u8(lds, pa + 2u) << 16) |
+                                        (W::lds_u8(lds, pa + 3u) << 24);
+                        if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
+                        const U32 pb = rb + tp;
+                        const U32 b0 = W::lds_u8(lds, pb), b1 = W::lds_u8(lds, pb + 1u), b2 = W::lds_u8(lds, pb + 2u), b3 = W::lds_u8(lds, pb + 3u);
+                        if (!cap) {
+                            column<false, 0>(st, b0, M, cnt, active);
+                            if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
+                            if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);
+                            if (tp + 3u < p_hi) column<false, 3>(st, b3, M, cnt, active);
+                        } else {
+                            column<true, 0>(st, b0, M, cnt, t_stop > tp);
+                            if (tp + 1u < p_hi) column<true, 1>(st, b1, M, cnt, t_stop > (tp + 1u));
+                            if (tp + 2u < p_hi) column<true, 2>(st, b2, M, cnt, t_stop > (tp + 2u));
+                            if (tp + 3u < p_hi) column<true, 3>(st, b3, M, cnt, t_stop > (tp + 3u));
+                        }
+                    }
+                    continue;
+                }
                 for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
                     advance_a(st, W::lds_u8(lds, ra + tp));
                 if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the part's end

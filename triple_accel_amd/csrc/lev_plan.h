@@ -94,19 +94,28 @@ static const int LEV_BITS_MAX_NA = 32;      // kernels exist for NA = 1..16 and 
 struct LevBitsPlan {
     bool ok;                 // false: costs are not a unit-cost family, or the band is wider than the window
     uint32_t u;              // unit_k of the batch
-    int NA;                  // packed dwords of `a` under the window (window = 4*NA bits)
+    int NA;                  // packed dwords of `a` under the window (window = 4*NA bits, 4*NA - 3 in the static form)
+    bool stat;               // static form: the window registers move a dword every 4th column (lev_bits_body.h)
     uint32_t Tw, ch, lds_per_wave;
 };
 
+// force_static: 0 = planner's choice, 1 = sliding form, 2 = static form
 static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc,
-                                             uint64_t max_len, int force_NA = 0, int force_ch = 0) {
+                                             uint64_t max_len, int force_NA = 0, int force_ch = 0, int force_static = 0) {
     LevBitsPlan p;
     p.ok = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1);   // LEVENSHTEIN_COSTS / RDAMERAU_COSTS (src/levenshtein.rs:79-91)
     p.u = lev_batch_unit_k(k, mc, gc, sg, max_len);
     const uint64_t w = (uint64_t)p.u + 1u + (has_t ? 2u : 0u);     // the transposition test looks one row past each band edge
-    uint64_t na = (w + 3) / 4;
+    uint64_t na = (w + 3) / 4, na_st = (w + 3 + 3) / 4;            // the static form gives up 3 window bits
+    if (na_st < 8) na_st = 8;                                       // static kernels exist for NA >= 8
     if (force_NA > 0 && (uint64_t)force_NA >= na) na = (uint64_t)force_NA;
+    if (force_NA > 0 && (uint64_t)force_NA >= na_st) na_st = (uint64_t)force_NA;
     if (na > 16) na += na & 1;
+    if (na_st > 16) na_st += na_st & 1;
+    // one more dword of compares (5 instructions) buys back NA v_alignbyte per column: worth it from 8 dwords on
+    p.stat = force_static == 2 || (force_static == 0 && na >= 8 && na_st <= (uint64_t)LEV_BITS_MAX_NA);
+    if (p.stat && na_st > (uint64_t)LEV_BITS_MAX_NA) p.stat = false;
+    if (p.stat) na = na_st;
     if (na > (uint64_t)LEV_BITS_MAX_NA) { p.ok = false; na = LEV_BITS_MAX_NA; }
     p.NA = (int)na;
     (void)force_ch;

@@ -100,7 +100,8 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     li.cell_bits = sel.cell_bits;
     // unit-cost families (levenshtein(), rdamerau(), levenshtein_simd_k(), the exp loop) have bit-parallel kernels
     const uint32_t tcost = c->has_transpose ? c->transpose_cost : 0;
-    const LevBitsPlan bp = lev_bits_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, env_int("TA_FORCE_NA"), env_int("TA_FORCE_CH"));
+    const LevBitsPlan bp = lev_bits_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, env_int("TA_FORCE_NA"), env_int("TA_FORCE_CH"),
+                                              env_int("TA_BITS_STATIC"));
     const bool dp_forced = env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L") || env_int("TA_FORCE_AFFINE") ||
                            env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
     LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced);
