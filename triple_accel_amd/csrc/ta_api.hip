@@ -106,6 +106,12 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
                            env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
     LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced);
     const bool unit = c->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || tcost == 1);
+    // a handful of long fixed-length pairs: the tiled row-blocked form uses many wavefronts per pair, whatever the band
+    if (unit && !dp_forced && ch.kernel != LEV_K_BITS && (n_work == 1 || (n_work <= 16 && !subset)) && !a->off && !b->off &&
+        (a->len < b->len ? a->len : b->len) > 2ull * 4096ull && !env_int("TA_WB_NO_TILES")) {
+        ch.kernel = LEV_K_WIDEBITS;
+        ch.rows_per_lane = 64;
+    }
     if (env_int("TA_FORCE_WIDEBITS") && unit && !dp_forced) {
         ch.kernel = LEV_K_WIDEBITS;
         ch.rows_per_lane = env_int("TA_FORCE_WIDEBITS") == 64 ? 64 : 32;
