@@ -14,7 +14,7 @@
 // four flag bytes into a nibble.
 //
 // One pair per lane (64 pairs per wavefront); the window is 4*NA bits wide (NA = packed dwords of `a` bytes
-// under it).  Rows outside [1, a_len] need no masking: above row 0 the virtual values D[r][j] = j + |r| satisfy
+// under it; 4*NA - 3 in the static form below).  Rows outside [1, a_len] need no masking: above row 0 the virtual values D[r][j] = j + |r| satisfy
 // the recurrence with or without spurious matches, and rows below a_len never feed the rows above them.
 // Strings are streamed HBM -> registers -> LDS, 64 bytes per string per refill (see run()).
 #pragma once
@@ -167,7 +167,7 @@ struct LevBits {
         // one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16) (the 16-byte pieces sit on
         // the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk waits in
         // registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is
-        // used up; whole 64-byte lines per fetch keep the HBM traffic at the algorithmic bytes.
+        // used up (32-byte refills re-read every 128-byte L2 line 4 times; measured traffic: DESIGN.md section 5).
         // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
         const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
         Q S[8];
