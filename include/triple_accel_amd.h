@@ -128,7 +128,8 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
                                     uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out);
 /* levenshtein_simd_k_with_opts(a, b, k, true, costs): distance + run-length traceback (library-owned, ta_free).
  * 2-bit argmin codes come from the band-wavefront kernel; the walk is host code.  Bands wider than 4222 diagonals
- * (unit_k > 4220) return TA_ERR_UNSUPPORTED. */
+ * (unit_k > 4220): the unit-cost families use the row-blocked bit-parallel kernel with 3-bit records (up to 8 GB), other
+ * costs return TA_ERR_UNSUPPORTED. */
 int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k,
                          const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits);
 /* levenshtein_exp_with_opts(a, b, true, costs), src/levenshtein.rs:1480-1494 */

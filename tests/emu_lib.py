@@ -33,6 +33,9 @@ def lib():
                                      C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_lev_widebits_huge.restype = C.c_uint32
         L.emu_lev_widebits_huge.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int]
+        L.emu_lev_widebits_trace.restype = C.c_int
+        L.emu_lev_widebits_trace.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -167,3 +170,22 @@ def lev_widebits_huge(a, b, k, trans=False, nwl=1, tile_steps=256, order=0):
     b = bytes(b) + b"\0" * 16
     v = lib().emu_lev_widebits_huge(a, len(a) - 16, b, len(b) - 16, k, int(bool(trans)), nwl, tile_steps, order)
     return None if v == 0xFFFFFFFF else int(v)
+
+
+_EDIT_NAMES = ["Match", "Mismatch", "AGap", "BGap", "Transpose"]
+
+
+def lev_widebits_trace(a, b, k, trans=False, nwl=1):
+    """(distance | None, run-length edits | None) of the TRACE form of the row-blocked kernel + the host walk."""
+    a2 = bytes(a) + b"\0" * 16
+    b2 = bytes(b) + b"\0" * 16
+    cap = len(a) + len(b) + 4
+    out = np.zeros(cap, dtype=[("code", np.uint32), ("pad", np.uint32), ("count", np.uint64)])
+    dist = C.c_uint32()
+    n = C.c_uint64()
+    rc = lib().emu_lev_widebits_trace(a2, len(a), b2, len(b), k, int(bool(trans)), nwl, C.byref(dist), out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise RuntimeError("emu_lev_widebits_trace rc=%d" % rc)
+    if dist.value == 0xFFFFFFFF:
+        return None, None
+    return int(dist.value), [(_EDIT_NAMES[int(out[i]["code"])], int(out[i]["count"])) for i in range(n.value)]

@@ -115,3 +115,26 @@ def test_widebits_huge_pair_as_tiles(trans):
         for tile_steps, order in [(64, 0), (256, 1), (1024, 0), (4096, 1)]:
             assert E.lev_widebits_huge(a, b, k, trans, nwl=1, tile_steps=tile_steps, order=order) == want, (len(a), len(b), k, tile_steps, order)
     assert E.lev_widebits_huge(x, y, 0xFFFFFFFF, trans, nwl=2, tile_steps=512, order=1) == oracle([x], [y], 0xFFFFFFFF, trans)[0]
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_widebits_traceback_equals_the_scalar_traceback(trans):
+    """TRACE form + host walk: the run-length edit script must equal the oracle's (the scalar path's tie order) -- random,
+    mutated, small-alphabet (ties everywhere, transpositions across lane boundaries), swapped roles, several stripes,
+    bounded k (band-limited stripes)."""
+    costs = RDAM if trans else LEV
+    g = Dg.rng(0x7ACE)
+    x = Dg.rand_str(g, 700)
+    y = Dg.mutate(g, x, 60, True)
+    s1 = bytes(g.integers(97, 100, size=300).astype(np.uint8))
+    s2 = bytes(g.integers(97, 100, size=280).astype(np.uint8))
+    xl = Dg.rand_str(g, 4500)
+    yl = Dg.mutate(g, xl, 150, True)
+    cases = [(x, y, 0xFFFFFFFF, 1), (y, x, 0xFFFFFFFF, 1), (s1, s2, 0xFFFFFFFF, 1), (s2, s1, 0xFFFFFFFF, 2), (x, y, 150, 2), (b"", b"abc", 9, 1),
+             (b"abc", b"", 9, 1), (b"ab", b"ba", 9, 1), (x[:33], y[:70], 0xFFFFFFFF, 1), (xl, yl, 0xFFFFFFFF, 1), (xl, yl, 400, 1)]
+    for a, b, k, nwl in cases:
+        want = O.levenshtein_simd_k_with_opts(a, b, k, True, costs)
+        got = E.lev_widebits_trace(a, b, k, trans, nwl=nwl)
+        assert got[0] == want[0], (len(a), len(b), k, nwl)
+        assert got[1] == want[1], (len(a), len(b), k, nwl, got[1][:6], want[1][:6])
+    assert E.lev_widebits_trace(x, y, 20, trans) == (None, None)

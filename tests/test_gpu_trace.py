@@ -53,3 +53,26 @@ def test_trace_longer_strings_and_exp():
         d, tr = T.levenshtein_exp_with_opts(a, b, True, T.LEVENSHTEIN_COSTS)
         wd, wtr = O.levenshtein_exp_with_opts(a, b, True)
         assert (d, [tuple(e) for e in tr]) == (wd, wtr)
+
+
+def test_trace_beyond_the_register_band():
+    """Unit-cost tracebacks whose band needs more than 64 x 66 diagonals take the row-blocked bit-parallel kernel with
+    3-bit records and the host walk: same edit script as the scalar path, for several stripes, swapped roles and the
+    transposition family; weighted costs on such bands stay unsupported."""
+    import triple_accel_amd as T
+    g = Dg.rng(34)
+    for n in (5000, 9000):
+        a = Dg.rand_str(g, n)
+        b = Dg.mutate(g, a, n // 20, True)
+        for costs in [(1, 1, 0, None), (1, 1, 0, 1)]:
+            for x, y in ((a, b), (b, a)):
+                want = O.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, True, costs)
+                assert prod(x, y, 0xFFFFFFFF, costs) == want, (n, costs)
+        d, tr = T.levenshtein_exp_with_opts(a, b, True, T.RDAMERAU_COSTS)
+        wd, wtr = O.levenshtein_exp_with_opts(a, b, True, O.RDAMERAU_COSTS)
+        assert (d, [tuple(e) for e in tr]) == (wd, wtr)
+    s1 = g.integers(97, 100, size=6000, dtype=np.uint8).tobytes()
+    s2 = g.integers(97, 100, size=5500, dtype=np.uint8).tobytes()
+    assert prod(s1, s2, 0xFFFFFFFF, (1, 1, 0, 1)) == O.levenshtein_simd_k_with_opts(s1, s2, 0xFFFFFFFF, True, (1, 1, 0, 1))
+    with pytest.raises(Exception):
+        T.levenshtein_simd_k_with_opts(a, b, 0xFFFFFFFF, True, T.EditCosts(2, 1, 0, None))

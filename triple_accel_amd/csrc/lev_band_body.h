@@ -48,6 +48,7 @@ struct LevParams {
     uint32_t ch;              // bytes per string per streamed chunk
     uint32_t *bnd = nullptr;  // lev_widebits: per wave 6 boundary lines of bnd_line u32 (strings spanning several stripes)
     uint64_t bnd_line = 0;
+    uint64_t trace_cols = 0;  // lev_widebits TRACE: columns per stripe in P.trace (>= b_len + 64)
     uint32_t *trace;          // TRACE kernels: 2-bit argmin codes, word w of (iteration tau, phase, lane) at
                               // ((tau*2 + phase)*64 + lane)*LEV_TRACE_WORDS(D) + w, cell c in bits [2c, 2c+2)
 };

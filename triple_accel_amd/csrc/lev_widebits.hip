@@ -46,6 +46,20 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
     return hipGetLastError();
 }
 
+// ---- trace_on = true for ONE pair: the sweep also stores 3 bits per visited cell (P.trace, P.trace_cols set by the caller)
+template <bool TRANS>
+__global__ __launch_bounds__(64) void lev_widebits_trace_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    LevWideBits<DevWave, 2, TRANS, true>::run(P, 0, 1, lds);
+}
+
+hipError_t lev_widebits_trace_launch(const LevParams &P, bool trans, hipStream_t s) {
+    const uint32_t lds = 21u * 64u * 2u * 4u;
+    if (trans) hipLaunchKernelGGL(lev_widebits_trace_kernel<true>, dim3(1), dim3(64), lds, s, P);
+    else hipLaunchKernelGGL(lev_widebits_trace_kernel<false>, dim3(1), dim3(64), lds, s, P);
+    return hipGetLastError();
+}
+
 // ---- one huge pair: tiles of the stripes' sweeps, one launch per diagonal of the (stripe, tile) grid (lev_widebits_body.h)
 template <int NWL, bool TRANS>
 __global__ __launch_bounds__(64) void lev_widebits_huge_kernel(typename LevWideBits<DevWave, NWL, TRANS>::Huge H, uint32_t d) {

@@ -22,7 +22,9 @@
 
 namespace ta {
 
-template <class W, int NWL, bool TRANS>
+// TRACE (single pair, trace_on = true): every step also stores the lane's Pv, Mv and D0 of its column -- 3 bits per cell --
+// to P.trace; the host walks them back from (n, m) with the scalar tie order (lev_trace_walk.h).
+template <class W, int NWL, bool TRANS, bool TRACE = false>
 struct LevWideBits {
     static_assert(NWL == 1 || NWL == 2, "32 or 64 rows per lane");
     static constexpr uint32_t RB = 32u * NWL;                    // rows per lane
@@ -41,6 +43,7 @@ struct LevWideBits {
         U32 Pv[NWL], Mv[NWL], D0p[NWL], Eqp[NWL];
         U32 sP, sM, sX, sc;      // what the lane below reads next step: top dwords of Ph, Mh, X, and the character
         U32 rP, rM, rX;          // ... as received; lane 0 never receives and keeps the row-0 boundary it was given once
+        U32 D0l[NWL];            // TRACE: D0 of the column just computed
     };
 
     // the two table rows of character c, NOT yet combined: the AND happens one step later, so the LDS reads of step
@@ -89,6 +92,7 @@ struct LevWideBits {
             st.Pv[q] = Mhs | ~(D0[q] | Phs);
             st.Mv[q] = Phs & D0[q];
             if (TRANS) { st.D0p[q] = D0[q]; st.Eqp[q] = Eq[q]; }
+            if (TRACE) st.D0l[q] = D0[q];
         }
         st.sP = Ph[NWL - 1]; st.sM = Mh[NWL - 1]; st.sc = c;
         if (TRANS) st.sX = X[NWL - 1];
@@ -100,6 +104,7 @@ struct LevWideBits {
         const uint32_t *inP, *inM, *inX;   // top boundary written by the stripe above (nullptr: row 0 of the matrix)
         uint32_t plo, phi;           // columns the stripe above covered
         uint32_t *outP, *outM, *outX;      // this stripe's bottom boundary (nullptr: last stripe)
+        uint32_t *trace;             // TRACE: this stripe's records, [column][lane][Pv.. Mv.. D0..] (3*NWL dwords)
     };
 
     // Step s of the skewed sweep: lane t computes column jlo + s - t.  TAIL (last stripe only): lanes t <= s - Cn hold
@@ -152,6 +157,28 @@ struct LevWideBits {
                 st.D0p[q] = nx.D0p[q]; st.Eqp[q] = nx.Eqp[q];
             }
             st.sP = nx.sP; st.sM = nx.sM; st.sX = nx.sX; st.sc = nx.sc;
+#pragma unroll
+            for (int q = 0; q < NWL; q++) st.D0l[q] = nx.D0l[q];
+            if (TRACE) {                                  // (a lane that froze in an earlier step stores nothing)
+                const Bool act = (lane <= s) & ((W::splat(s) - lane) < Z.Cn);
+                const U32 rec = ((W::splat(Z.jlo + s) - lane) * 64u + lane) * (3u * NWL);
+#pragma unroll
+                for (int q = 0; q < NWL; q++) {
+                    W::store_u32(Z.trace, rec + (uint32_t)q, nx.Pv[q], act);
+                    W::store_u32(Z.trace, rec + (uint32_t)(NWL + q), nx.Mv[q], act);
+                    W::store_u32(Z.trace, rec + (uint32_t)(2 * NWL + q), nx.D0l[q], act);
+                }
+            }
+        }
+        if (TRACE && !TAIL) {
+            const Bool act = (lane <= s) & ((W::splat(s) - lane) < Z.Cn);
+            const U32 rec = ((W::splat(Z.jlo + s) - lane) * 64u + lane) * (3u * NWL);
+#pragma unroll
+            for (int q = 0; q < NWL; q++) {
+                W::store_u32(Z.trace, rec + (uint32_t)q, st.Pv[q], act);
+                W::store_u32(Z.trace, rec + (uint32_t)(NWL + q), st.Mv[q], act);
+                W::store_u32(Z.trace, rec + (uint32_t)(2 * NWL + q), st.D0l[q], act);
+            }
         }
         if (OUT && s >= 63u) {                        // lane 63's row is the stripe's last: hand it to the stripe below
             const U32 col = W::splat(Z.jlo + (s - 63u));
@@ -219,6 +246,7 @@ struct LevWideBits {
                     Z.inP = sq ? rd : nullptr; Z.inM = sq ? rd + P.bnd_line : nullptr; Z.inX = sq ? rd + 2u * P.bnd_line : nullptr;
                     Z.outP = last ? nullptr : wr; Z.outM = last ? nullptr : wr + P.bnd_line; Z.outX = last ? nullptr : wr + 2u * P.bnd_line;
                     Z.plo = plo; Z.phi = phi;
+                    Z.trace = TRACE ? P.trace + (uint64_t)sq * P.trace_cols * (64u * 3u * NWL) : nullptr;
                     if (sq) {                                    // D[i0][jlo-1]: down the stripe above at its column plo-1, then right
                         anchor += ROWS;
                         if (Z.jlo > plo) anchor += sum_steps(Z.inP, Z.inM, plo, Z.jlo - 1u, lane);
@@ -418,6 +446,7 @@ struct LevWideBits {
         uint32_t *wr = last ? nullptr : H.lines + (uint64_t)q * 3u * H.line;
         Z.inP = rd; Z.inM = rd ? rd + H.line : nullptr; Z.inX = rd ? rd + 2u * H.line : nullptr;
         Z.outP = wr; Z.outM = wr ? wr + H.line : nullptr; Z.outX = wr ? wr + 2u * H.line : nullptr;
+        Z.trace = nullptr;
 
         build_tables(lds, lane, lane_off, ap, H.n, S.i0);
 

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <vector>
 
+#include "lev_trace_walk.h"
 #include "ta_internal.h"
 
 namespace ta {
@@ -384,6 +385,58 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
     return fetch_u32(od, out);
 }
 
+}  // extern "C"
+
+// trace_on = true beyond the register band (unit costs): row-blocked bit-parallel kernel with 3-bit records + host walk
+static int trace_widebits(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bool swap, uint32_t k, const ta_edit_costs *costs,
+                          uint32_t *out, ta_edit **edits, size_t *n_edits, uint64_t rec_words, uint64_t tcols) {
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    if (rc) return rc;
+    Scratch &ts = tls_scratch(9), &bl = tls_scratch(6);
+    if ((rc = ts.ensure((size_t)rec_words * 4)) || (rc = bl.ensure((size_t)6 * (m + 66) * 4))) return rc;
+    LevParams P;
+    P.a = view_of(&sa); P.b = view_of(&sb);
+    P.subset = nullptr; P.out = od; P.n = 1; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = costs->has_transpose ? 1 : 0;
+    P.u = lev_batch_unit_k(k, 1, 1, 0, m);
+    P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+    P.trace = (uint32_t *)ts.dev; P.trace_cols = tcols;
+    P.bnd = (uint32_t *)bl.dev; P.bnd_line = (uint64_t)m + 66;
+    TA_HIP(lev_widebits_trace_launch(P, costs->has_transpose != 0, 0));
+    uint32_t d = 0;
+    rc = fetch_u32(od, &d);
+    if (rc) return rc;
+    *out = d;
+    if (d == TA_NONE) return TA_OK;
+    std::vector<uint32_t> rec((size_t)rec_words);
+    TA_HIP(hipMemcpy(rec.data(), ts.dev, (size_t)rec_words * 4, hipMemcpyDeviceToHost));
+    WbTrace T{rec.data(), tcols, 2u, (uint32_t)n, (uint32_t)m, P.u};
+    std::vector<ta_edit> res;
+    size_t ci = n, cj = m;
+    const bool ok = wb_trace_walk(T, x, y, d, costs->has_transpose != 0, [&](int code) {
+        uint32_t e;
+        switch (code) {                                                        // relabelling as in ta_levenshtein_trace (:561-603)
+            case 0: ci--; cj--; e = (x[ci] == y[cj]) ? TA_EDIT_MATCH : TA_EDIT_MISMATCH; break;
+            case 1: cj--; e = swap ? TA_EDIT_BGAP : TA_EDIT_AGAP; break;
+            case 2: ci--; e = swap ? TA_EDIT_AGAP : TA_EDIT_BGAP; break;
+            default: ci -= 2; cj -= 2; e = TA_EDIT_TRANSPOSE; break;
+        }
+        if (!res.empty() && res.back().edit == e) res.back().count++;
+        else res.push_back(ta_edit{e, 0u, 1u});
+    });
+    if (!ok) { set_last_error_msg("traceback records are inconsistent"); return TA_ERR_HIP; }
+    *n_edits = res.size();
+    if (!res.empty()) {
+        *edits = (ta_edit *)malloc(res.size() * sizeof(ta_edit));
+        for (size_t t = 0; t < res.size(); t++) (*edits)[t] = res[res.size() - 1 - t];   // :605 reverse
+    }
+    return TA_OK;
+}
+
+extern "C" {
+
 /* levenshtein_simd_k_with_opts(..., trace_on = true): distance + run-length edit script.
  * The band-wavefront kernel stores a 2-bit argmin code per cell (tie order of src/levenshtein.rs:493-532);
  * the walk from (n, m) back to (0, 0) is the host part (:561-606). */
@@ -402,7 +455,17 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
     LevPlan pl = lev_make_plan(sel.max_k, costs->mismatch_cost, gc, sg, m, 16, 0);
     if (!pl.ok) pl = lev_make_plan(sel.max_k, costs->mismatch_cost, gc, sg, m, 66, 0);
-    if (!pl.ok) { set_last_error_msg("traceback band wider than 4222 diagonals is not on the GPU path yet"); return TA_ERR_UNSUPPORTED; }
+    if (!pl.ok) {
+        // band too wide for the register kernel: the unit-cost families take the row-blocked bit-parallel kernel with records
+        const bool unit = costs->mismatch_cost == 1 && gc == 1 && sg == 0 && (!costs->has_transpose || costs->transpose_cost == 1);
+        const uint64_t stripes = (n + 4095) / 4096, tcols = (uint64_t)m + 64;
+        const uint64_t rec_words = stripes * tcols * 64ull * 6ull;
+        if (!unit || m > 0xFFFFFF00ull || rec_words * 4ull > (8ull << 30)) {
+            set_last_error_msg("traceback: band wider than 4222 diagonals with non-unit costs, or more than 8 GB of traceback records");
+            return TA_ERR_UNSUPPORTED;
+        }
+        return trace_widebits(x, n, y, m, swap, k, costs, out, edits, n_edits, rec_words, tcols);
+    }
     ta_strings sa, sb;
     uint32_t *od;
     int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
