@@ -65,8 +65,8 @@ inline std::vector<Edit> take_edits_(ta_edit *e, std::size_t n) {
     ta_free(e);
     return v;
 }
-// :714 -- Some((distance, traceback)) / None; trace_on = true returns the run-length edit script (bands wider than
-// 4222 diagonals with non-unit costs: unsupported_error -- use the scalar routine there)
+// :714 -- Some((distance, traceback)) / None; trace_on = true returns the run-length edit script (more than 8 GB of
+// traceback records: unsupported_error -- use the scalar routine there)
 inline std::optional<std::pair<std::uint32_t, Traceback>> levenshtein_simd_k_with_opts(bytes a, bytes b, std::uint32_t k, bool trace_on, const EditCosts &costs) {
     std::uint32_t o;
     if (trace_on) {

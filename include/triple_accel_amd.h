@@ -40,7 +40,7 @@ typedef enum {
     TA_ERR_BAD_COSTS = 3,    /* EditCosts::new / check_search    src/levenshtein.rs:44-52,67-71 */
     TA_ERR_HIP = 4,          /* HIP runtime failure / no device (no CPU fallback) */
     TA_ERR_ARG = 5,          /* null pointer, size over the documented limit */
-    TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. traceback of a band wider than 4222 diagonals) */
+    TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. a traceback needing more than 8 GB of records) */
     TA_ERR_CAPACITY = 7      /* caller-provided match buffer too small; *n_out holds the need */
 } ta_status;
 
@@ -128,8 +128,8 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
                                     uint32_t k, int trace_on, const ta_edit_costs *costs, uint32_t *out);
 /* levenshtein_simd_k_with_opts(a, b, k, true, costs): distance + run-length traceback (library-owned, ta_free).
  * 2-bit argmin codes come from the band-wavefront kernel; the walk is host code.  Bands wider than 4222 diagonals
- * (unit_k > 4220): the unit-cost families use the row-blocked bit-parallel kernel with 3-bit records (up to 8 GB), other
- * costs return TA_ERR_UNSUPPORTED. */
+ * (unit_k > 4220): the unit-cost families use the row-blocked bit-parallel kernel with 3-bit records, other costs the DP
+ * wide kernel with 2-bit codes; more than 8 GB of records returns TA_ERR_UNSUPPORTED. */
 int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t k,
                          const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits);
 /* levenshtein_exp_with_opts(a, b, true, costs), src/levenshtein.rs:1480-1494 */

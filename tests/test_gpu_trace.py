@@ -74,5 +74,11 @@ def test_trace_beyond_the_register_band():
     s1 = g.integers(97, 100, size=6000, dtype=np.uint8).tobytes()
     s2 = g.integers(97, 100, size=5500, dtype=np.uint8).tobytes()
     assert prod(s1, s2, 0xFFFFFFFF, (1, 1, 0, 1)) == O.levenshtein_simd_k_with_opts(s1, s2, 0xFFFFFFFF, True, (1, 1, 0, 1))
-    with pytest.raises(Exception):
-        T.levenshtein_simd_k_with_opts(a, b, 0xFFFFFFFF, True, T.EditCosts(2, 1, 0, None))
+    # weighted / affine / transposition costs on such bands: the DP wide kernel with 2-bit argmin codes
+    a = Dg.rand_str(g, 4700)
+    b = Dg.mutate(g, a, 120, True)
+    for costs in [(2, 1, 0, None), (1, 1, 1, None), (3, 2, 1, 3), (2, 2, 0, 2)]:
+        for x, y in ((a, b), (b, a)):
+            want = O.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, True, costs)
+            assert prod(x, y, 0xFFFFFFFF, costs) == want, costs
+    assert prod(s1, s2, 0xFFFFFFFF, (2, 2, 0, 2)) == O.levenshtein_simd_k_with_opts(s1, s2, 0xFFFFFFFF, True, (2, 2, 0, 2))

@@ -46,7 +46,9 @@ __device__ __forceinline__ void wide_str(const StrView &s, uint32_t i, const uin
     }
 }
 
-template <bool AFFINE, bool TRANS>
+// TRACE (one pair, trace_on = true): 2-bit argmin codes with the scalar tie order (src/levenshtein.rs:493-532), 32 rows =
+// 2 dwords per lane per column, at P.trace[((stripe * P.trace_cols + j) * 64 + lane) * 2 + word]
+template <bool AFFINE, bool TRANS, bool TRACE = false>
 __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S) {
     const uint32_t t = threadIdx.x;   // lane
     const uint32_t gc = P.gc, sg = P.sg, sgc = P.sg + P.gc, mc = P.mc, tc = P.tc, u = P.u;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
                     uint32_t p2a = up2_prev2;            // dp(row0 - 1, j-2) -> transposition of row r = 0
                     uint32_t p2b = up_dp_prev2;          // dp(row0,     j-2) -> row r = 1
                     uint32_t v = WINF, v_above = WINF;
+                    uint32_t codes[2] = {0u, 0u};
 #pragma unroll
                     for (int r = 0; r < WR; r++) {
                         const uint32_t sub = __builtin_amdgcn_udot4(F4[r >> 2], mc << (8 * (r & 3)), diag, false);   // :471-475
@@ -194,13 +197,17 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
                         const uint32_t ga = GA[r];
                         v_above = v;
                         v = umin_(umin_(sub, ga), gb);                                   // :493-515
+                        uint32_t code = 0;
+                        if (TRACE) code = (gb < umin_(sub, ga)) ? 2u : ((ga < sub) ? 1u : 0u);   // sub, then a_gap (<), then b_gap (<)
                         if (TRANS) {
                             const uint32_t td = p2a;                                     // dp(i-2, j-2)
                             p2a = p2b; p2b = P2[r]; P2[r] = oldH;
                             const bool tz = ((Z4[r >> 2] >> (8 * (r & 3))) & 0xffu) == 0u;
                             const uint32_t tv = td + tc;
+                            if (TRACE) code = (tz && tv <= v) ? 3u : code;               // transposition wins ties (<=)
                             v = (tz && tv < v) ? tv : v;                                 // :517-532
                         }
+                        if (TRACE) codes[r >> 4] |= code << (2 * (r & 15));
                         diag = oldH;
                         H[r] = v;
                         if (AFFINE) {
@@ -211,6 +218,10 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
                             gb = v + gc;
                             GA[r] = gb;
                         }
+                    }
+                    if (TRACE) {
+                        uint32_t *tr = P.trace + (((uint64_t)q * P.trace_cols + j) * 64u + t) * 2u;
+                        tr[0] = codes[0]; tr[1] = codes[1];
                     }
                     send_dp = v; send_gb = gb; send_dp2 = v_above; send_b = bch;
                     if (!last_stripe && t == 63) {       // the stripe's last row -> next stripe's top boundary
@@ -261,6 +272,21 @@ hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32
     else if (affine) hipLaunchKernelGGL((lev_wide_kernel<true, false>), dim3(grid), dim3(64), 0, s, P, S);
     else if (trans) hipLaunchKernelGGL((lev_wide_kernel<false, true>), dim3(grid), dim3(64), 0, s, P, S);
     else hipLaunchKernelGGL((lev_wide_kernel<false, false>), dim3(grid), dim3(64), 0, s, P, S);
+    return hipGetLastError();
+}
+
+// trace_on = true for ONE pair (P.n == 1, P.trace / P.trace_cols set): same sweep, argmin codes stored
+hipError_t lev_wide_trace_launch(const LevParams &P, bool trans, hipStream_t s) {
+    WideScratch S;
+    S.line = (uint64_t)P.lds_per_wave;
+    Scratch &sc = tls_scratch(6);
+    if (sc.ensure((size_t)6 * S.line * sizeof(uint32_t)) != TA_OK) return hipErrorOutOfMemory;
+    S.buf = (uint32_t *)sc.dev;
+    const bool affine = P.sg > 0;
+    if (affine && trans) hipLaunchKernelGGL((lev_wide_kernel<true, true, true>), dim3(1), dim3(64), 0, s, P, S);
+    else if (affine) hipLaunchKernelGGL((lev_wide_kernel<true, false, true>), dim3(1), dim3(64), 0, s, P, S);
+    else if (trans) hipLaunchKernelGGL((lev_wide_kernel<false, true, true>), dim3(1), dim3(64), 0, s, P, S);
+    else hipLaunchKernelGGL((lev_wide_kernel<false, false, true>), dim3(1), dim3(64), 0, s, P, S);
     return hipGetLastError();
 }
 

@@ -435,6 +435,60 @@ static int trace_widebits(const uint8_t *x, size_t n, const uint8_t *y, size_t m
     return TA_OK;
 }
 
+// trace_on = true beyond the register band, any EditCosts: the DP wide kernel with 2-bit argmin codes + the usual walk
+static int trace_wide(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bool swap, uint32_t k, const ta_edit_costs *costs,
+                      uint32_t *out, ta_edit **edits, size_t *n_edits, uint64_t code_words, uint64_t tcols) {
+    ta_strings sa, sb;
+    uint32_t *od;
+    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    if (rc) return rc;
+    Scratch &ts = tls_scratch(9);
+    if ((rc = ts.ensure((size_t)code_words * 4))) return rc;
+    LevParams P;
+    P.a = view_of(&sa); P.b = view_of(&sb);
+    P.subset = nullptr; P.out = od; P.n = 1; P.k = k;
+    P.mc = costs->mismatch_cost; P.gc = costs->gap_cost; P.sg = costs->start_gap_cost;
+    P.tc = costs->has_transpose ? costs->transpose_cost : 0;
+    P.u = lev_batch_unit_k(k, P.mc, P.gc, P.sg, m);
+    P.o = 0; P.L = 0; P.PW = 1; P.Tw = 0; P.ch = 0;
+    P.lds_per_wave = (uint32_t)(m + 2);                                         // boundary line length
+    P.trace = (uint32_t *)ts.dev; P.trace_cols = tcols;
+    TA_HIP(lev_wide_trace_launch(P, costs->has_transpose != 0, 0));
+    uint32_t d = 0;
+    rc = fetch_u32(od, &d);
+    if (rc) return rc;
+    *out = d;
+    if (d == TA_NONE) return TA_OK;
+    std::vector<uint32_t> tr((size_t)code_words);
+    TA_HIP(hipMemcpy(tr.data(), ts.dev, (size_t)code_words * 4, hipMemcpyDeviceToHost));
+    std::vector<ta_edit> res;
+    size_t i = n, j = m;
+    while (i > 0 || j > 0) {                                                    // :561-603
+        uint32_t code;
+        if (i == 0) code = 1;                                                   // row 0 is one a_gap run, column 0 one b_gap run
+        else if (j == 0) code = 2;
+        else {
+            const size_t q = (i - 1) / 2048, r = (i - 1) % 2048, lane = r / 32, rr = r % 32;
+            code = (tr[((q * tcols + j) * 64 + lane) * 2 + (rr >> 4)] >> (2 * (rr & 15))) & 3u;
+        }
+        uint32_t e;
+        switch (code) {
+            case 0: i--; j--; e = (x[i] == y[j]) ? TA_EDIT_MATCH : TA_EDIT_MISMATCH; break;
+            case 1: j--; e = swap ? TA_EDIT_BGAP : TA_EDIT_AGAP; break;
+            case 2: i--; e = swap ? TA_EDIT_AGAP : TA_EDIT_BGAP; break;
+            default: i -= 2; j -= 2; e = TA_EDIT_TRANSPOSE; break;
+        }
+        if (!res.empty() && res.back().edit == e) res.back().count++;
+        else res.push_back(ta_edit{e, 0u, 1u});
+    }
+    *n_edits = res.size();
+    if (!res.empty()) {
+        *edits = (ta_edit *)malloc(res.size() * sizeof(ta_edit));
+        for (size_t t = 0; t < res.size(); t++) (*edits)[t] = res[res.size() - 1 - t];   // :605 reverse
+    }
+    return TA_OK;
+}
+
 extern "C" {
 
 /* levenshtein_simd_k_with_opts(..., trace_on = true): distance + run-length edit script.
@@ -460,11 +514,13 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
         const bool unit = costs->mismatch_cost == 1 && gc == 1 && sg == 0 && (!costs->has_transpose || costs->transpose_cost == 1);
         const uint64_t stripes = (n + 4095) / 4096, tcols = (uint64_t)m + 64;
         const uint64_t rec_words = stripes * tcols * 64ull * 6ull;
-        if (!unit || m > 0xFFFFFF00ull || rec_words * 4ull > (8ull << 30)) {
-            set_last_error_msg("traceback: band wider than 4222 diagonals with non-unit costs, or more than 8 GB of traceback records");
+        const uint64_t code_words = ((n + 2047) / 2048) * tcols * 64ull * 2ull;           // DP wide kernel: 2 bits per cell
+        if (m > 0xFFFFFF00ull || (unit ? rec_words : code_words) * 4ull > (8ull << 30)) {
+            set_last_error_msg("traceback: more than 8 GB of traceback records");
             return TA_ERR_UNSUPPORTED;
         }
-        return trace_widebits(x, n, y, m, swap, k, costs, out, edits, n_edits, rec_words, tcols);
+        if (unit) return trace_widebits(x, n, y, m, swap, k, costs, out, edits, n_edits, rec_words, tcols);
+        return trace_wide(x, n, y, m, swap, k, costs, out, edits, n_edits, code_words, tcols);
     }
     ta_strings sa, sb;
     uint32_t *od;

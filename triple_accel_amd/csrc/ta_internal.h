@@ -45,6 +45,7 @@ hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, uint64_t m
                                uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_widebits_huge_launch(const uint8_t *a, uint32_t a_len, const uint8_t *b, uint32_t b_len, uint32_t u, uint32_t k,
                                     int rows_per_lane, bool trans, uint32_t *out, hipStream_t s, uint32_t *launches_out);
+hipError_t lev_wide_trace_launch(const LevParams &P, bool trans, hipStream_t s);
 hipError_t lev_widebits_trace_launch(const LevParams &P, bool trans, hipStream_t s);
 hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
                            uint32_t *threads_out, uint32_t *dpt_out);
