@@ -128,6 +128,10 @@ void tao_levenshtein_exp_batch(const uint8_t *a_blob, const uint64_t *a_off, con
 void tao_hamming_batch(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
                        size_t n, uint32_t *out, int threads);
 int tao_max_threads(void);
+/* ta_oracle_simd.c: the same contract through an anti-diagonal, auto-vectorised restatement (the shape of the reference's
+ * SIMD core, src/levenshtein.rs:829-1195); start_gap_cost == 0 and k < 15,600 only: returns -1 otherwise, 0 on success. */
+int tao_levenshtein_k_batch_antidiag(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                                     size_t n, uint32_t k, const tao_costs *costs, uint32_t *out, int threads);
 
 void tao_free(void *p);
 

@@ -75,6 +75,9 @@ def lib():
         for name in ("tao_levenshtein_k_batch",):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, u32, cp, C.c_void_p, C.c_int]
             getattr(L, name).restype = None
+        L.tao_levenshtein_k_batch_antidiag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, u32, cp, C.c_void_p,
+                                                       C.c_int]
+        L.tao_levenshtein_k_batch_antidiag.restype = C.c_int
         L.tao_levenshtein_exp_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, cp, C.c_void_p, C.c_int]
         L.tao_levenshtein_exp_batch.restype = None
         L.tao_hamming_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_int]
@@ -256,6 +259,18 @@ def levenshtein_k_batch(a_csr, b_csr, k, costs=LEVENSHTEIN_COSTS, threads=0):
     lib().tao_levenshtein_k_batch(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k, C.byref(cs),
                                   out.ctypes.data, threads or max_threads())
     return out
+
+
+def levenshtein_k_batch_antidiag(a_csr, b_csr, k, costs=LEVENSHTEIN_COSTS, threads=0):
+    """The anti-diagonal auto-vectorised restatement (oracle/ta_oracle_simd.c); None when it does not apply (affine gaps)."""
+    np = _np()
+    (ab, ao), (bb, bo) = a_csr, b_csr
+    n = len(ao) - 1
+    out = np.empty(n, dtype=np.uint32)
+    cs = mk_costs(costs)
+    rc = lib().tao_levenshtein_k_batch_antidiag(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k,
+                                                C.byref(cs), out.ctypes.data, threads or max_threads())
+    return out if rc == 0 else None
 
 
 def levenshtein_exp_batch(a_csr, b_csr, costs=LEVENSHTEIN_COSTS, threads=0):
