@@ -117,7 +117,17 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         ch.kernel = LEV_K_WIDEBITS;
         ch.rows_per_lane = env_int("TA_FORCE_WIDEBITS") == 64 ? 64 : 32;
     }
-    if (ch.kernel == LEV_K_BITS) {
+    // fixed-length batches with a band of 25..45 diagonals: 32 pairs per register, three band cells per lane (lev_sliced.hip);
+    // opt-in -- fewer instructions than the bit-parallel band kernel but bound by the refetch of its string lines
+    uint32_t sl_strips = 0;
+    const bool sliced = ch.kernel == LEV_K_BITS && unit && !trans && !subset && !dp_forced && env_int("TA_FORCE_SLICED") &&
+                        lev_sliced_applies(P.a, P.b, bp.u, &sl_strips);
+    if (sliced) {
+        uint32_t grid = 0, lds = 0, ppw = 0;
+        TA_HIP(lev_sliced_launch(P.a, P.b, n_work, k, bp.u, out_dev, st, &grid, &lds, &ppw));
+        li.kernel = 5; li.diags_per_lane = 3; li.lanes_per_pair = sl_strips; li.pairs_per_wave = ppw;
+        li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
+    } else if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits_launch(P, bp, trans, st, &grid, &lds));

@@ -41,6 +41,9 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s);
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out,
                            uint32_t *lds_out);
+bool lev_sliced_applies(const StrView &a, const StrView &b, uint32_t unit_k, uint32_t *strips_out);
+hipError_t lev_sliced_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t k, uint32_t unit_k, uint32_t *out,
+                             hipStream_t st, uint32_t *grid_out, uint32_t *lds_out, uint32_t *pairs_per_wave);
 hipError_t lev_widebits_launch(const LevParams &P, int rows_per_lane, uint64_t max_len, bool trans, hipStream_t s,
                                uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_widebits_huge_launch(const uint8_t *a, uint32_t a_len, const uint8_t *b, uint32_t b_len, uint32_t u, uint32_t k,
