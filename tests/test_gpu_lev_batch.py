@@ -154,6 +154,36 @@ def test_exp_batch():
         assert np.array_equal(out, want)
 
 
+def test_exp_batch_bag_bound(monkeypatch):
+    """The doubling loop defers a pair until the threshold reaches its bag lower bound (util_kernels.hip): same distances
+    with and without it, for unit and weighted costs, similar and unrelated strings in one batch."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(171)
+    a, b = [], []
+    for n in (70, 200, 500, 900):
+        for i in range(40):
+            x = Dg.rand_str(g, n)
+            y = [Dg.mutate(g, x, 3), Dg.mutate(g, x, n // 8), Dg.rand_str(g, n), Dg.rand_str(g, max(1, n - 40)), x][i % 5]
+            a.append(x); b.append(y)
+    sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+    ca, cb = O.csr_from_list(a), O.csr_from_list(b)
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 0, None), (1, 2, 0, None), (3, 2, 1, 2), (2, 3, 2, None)]:
+        want = O.levenshtein_exp_batch(ca, cb, costs)
+        monkeypatch.delenv("TA_EXP_NO_BOUND", raising=False)
+        got = B.levenshtein_exp_batch(sa, sb, costs).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (costs, np.flatnonzero(got != want)[:8])
+        monkeypatch.setenv("TA_EXP_NO_BOUND", "1")
+        got = B.levenshtein_exp_batch(sa, sb, costs).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), costs
+    # fixed-length batch of unrelated strings: every pair skips the bounded rounds and goes to the unbounded pass at once
+    monkeypatch.delenv("TA_EXP_NO_BOUND", raising=False)
+    x, y = Dg.pairs_random(5, 300, 600)
+    got = B.levenshtein_exp_batch(B.Strings.from_fixed(x), B.Strings.from_fixed(y)).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, O.levenshtein_exp_batch(O.csr_from_fixed(x), O.csr_from_fixed(y)))
+    assert T.last_launch_info()["kernel"] == 4
+
+
 def test_hamming_batch():
     from triple_accel_amd import batch as B
     import triple_accel_amd as T

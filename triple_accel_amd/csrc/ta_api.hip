@@ -301,23 +301,42 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
     if (rc) return rc;
     // subset ping-pong buffers + counter
-    Scratch &s0 = tls_scratch(4), &s1 = tls_scratch(5), &cnt = tls_scratch(3);
+    Scratch &s0 = tls_scratch(4), &s1 = tls_scratch(5), &cnt = tls_scratch(3), &bnd = tls_scratch(10), &wrk = tls_scratch(11);
     if ((rc = s0.ensure(n * 4)) || (rc = s1.ensure(n * 4)) || (rc = cnt.ensure(16))) return rc;
+    // Bag lower bound per pair (util_kernels.hip): a doubling round only takes the unresolved pairs whose bound admits its
+    // threshold -- the others could only return None from it.  Same return values, fewer rounds for dissimilar strings.
+    const bool bounded = n >= 64 && max_len >= 64 && !env_int("TA_EXP_NO_BOUND") && !env_int("TA_EXP_FAITHFUL");
+    if (bounded) {
+        if ((rc = bnd.ensure(n * 4)) || (rc = wrk.ensure(n * 4))) return rc;
+        TA_HIP(hipMemsetAsync(out_dev, 0xFF, n * 4, st));
+        TA_HIP(bag_bound_launch(view_of(a), view_of(b), (uint32_t)n, costs->mismatch_cost, costs->gap_cost, (uint32_t *)bnd.dev, st));
+    }
     uint32_t *sub_in = nullptr, *bufs[2] = {(uint32_t *)s0.dev, (uint32_t *)s1.dev};
-    uint32_t n_work = (uint32_t)n;
+    uint32_t n_left = (uint32_t)n;                          // unresolved pairs (sub_in == nullptr: all of them)
     uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
     int flip = 0;
-    for (int round = 0; round < 40 && n_work > 0; round++) {
-        rc = lev_pass(a, b, n_work, sub_in, k, costs, max_len, out_dev, st);
-        if (rc) return rc;
-        TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
-        TA_HIP(compact_none_launch(out_dev, sub_in, n_work, bufs[flip], (uint32_t *)cnt.dev, st));
-        uint32_t left = 0;
-        TA_HIP(hipMemcpyAsync(&left, cnt.dev, 4, hipMemcpyDeviceToHost, st));
-        TA_HIP(hipStreamSynchronize(st));
-        sub_in = bufs[flip];
-        flip ^= 1;
-        n_work = left;
+    for (int round = 0; round < 40 && n_left > 0; round++) {
+        const uint32_t *work = sub_in;
+        uint32_t n_work = n_left;
+        if (bounded && k != 0xFFFFFFFFu) {
+            TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
+            TA_HIP(compact_bound_launch(out_dev, (const uint32_t *)bnd.dev, k, sub_in, n_left, (uint32_t *)wrk.dev, (uint32_t *)cnt.dev, st));
+            TA_HIP(hipMemcpyAsync(&n_work, cnt.dev, 4, hipMemcpyDeviceToHost, st));
+            TA_HIP(hipStreamSynchronize(st));
+            work = (const uint32_t *)wrk.dev;
+        }
+        if (n_work > 0) {
+            rc = lev_pass(a, b, n_work, work, k, costs, max_len, out_dev, st);
+            if (rc) return rc;
+            TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
+            TA_HIP(compact_none_launch(out_dev, sub_in, n_left, bufs[flip], (uint32_t *)cnt.dev, st));
+            uint32_t left = 0;
+            TA_HIP(hipMemcpyAsync(&left, cnt.dev, 4, hipMemcpyDeviceToHost, st));
+            TA_HIP(hipStreamSynchronize(st));
+            sub_in = bufs[flip];
+            flip ^= 1;
+            n_left = left;
+        }
         k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
         // Once the next bounded pass would cost more than a quarter of the unbounded one (kernel cost model, lev_plan.h),
         // it is cheaper in expectation to finish the unresolved pairs with k = u32::MAX right away (same return values

@@ -95,4 +95,69 @@ hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, u
     return hipGetLastError();
 }
 
+// exp search with a lower bound: next round's work list = unresolved pairs whose bound admits the next threshold
+__global__ void compact_bound_kernel(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
+                                     uint32_t *list_out, uint32_t *count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    uint32_t pair = list_in ? list_in[i] : i;
+    if (out[pair] == 0xFFFFFFFFu && bound[pair] <= k) list_out[atomicAdd(count, 1u)] = pair;
+}
+hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
+                                uint32_t *list_out, uint32_t *count, hipStream_t st) {
+    if (n_in == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_bound_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, bound, k, list_in, n_in, list_out, count);
+    return hipGetLastError();
+}
+
+// Bag (multiset) lower bound of the edit cost of every pair: with ex_a / ex_b the bytes `a` / `b` has in excess of the other
+// (per byte value), any script needs max(ex_a, ex_b) edits that change the bags -- a mismatch fixes one excess on each
+// side, a gap one; a transposition none -- so with s mismatches  cost >= s mismatch + (max(0, ex_a - s) + max(0, ex_b - s)) gap,
+// piecewise linear in s with its minimum at s = 0, min(ex) or max(ex).
+// levenshtein_exp uses it to skip the doubling rounds (src/levenshtein.rs:1445-1454) a pair cannot finish in.
+// One wavefront per pair, one signed counter per byte value in LDS (+1 for a, -1 for b).
+__global__ __launch_bounds__(256) void bag_bound_kernel(StrView a, StrView b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound) {
+    __shared__ int table[4][256];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    int *t = table[w];
+    for (uint32_t pair = blockIdx.x * 4u + w; pair < n; pair += gridDim.x * 4u) {
+        const uint8_t *pa, *pb;
+        uint64_t la, lb;
+        dev_str(a, pair, pa, la);
+        dev_str(b, pair, pb, lb);
+        for (uint32_t i = lane; i < 256u; i += 64u) t[i] = 0;
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        const uint64_t fa = la & ~(uint64_t)3, fb = lb & ~(uint64_t)3;
+        for (uint64_t i = (uint64_t)lane * 4; i < fa; i += 256) {
+            const uint32_t x = *(const u32u *)(pa + i);
+            atomicAdd(&t[x & 255u], 1); atomicAdd(&t[(x >> 8) & 255u], 1); atomicAdd(&t[(x >> 16) & 255u], 1); atomicAdd(&t[x >> 24], 1);
+        }
+        for (uint64_t i = fa + lane; i < la; i += 64) atomicAdd(&t[pa[i]], 1);
+        for (uint64_t i = (uint64_t)lane * 4; i < fb; i += 256) {
+            const uint32_t x = *(const u32u *)(pb + i);
+            atomicAdd(&t[x & 255u], -1); atomicAdd(&t[(x >> 8) & 255u], -1); atomicAdd(&t[(x >> 16) & 255u], -1); atomicAdd(&t[x >> 24], -1);
+        }
+        for (uint64_t i = fb + lane; i < lb; i += 64) atomicAdd(&t[pb[i]], -1);
+        uint32_t ea = 0, eb = 0;
+        for (uint32_t i = lane; i < 256u; i += 64u) {
+            const int v = t[i];
+            if (v > 0) ea += (uint32_t)v; else eb += (uint32_t)(-v);
+        }
+        for (uint32_t m = 32; m >= 1; m >>= 1) { ea += __shfl_xor(ea, m, 64); eb += __shfl_xor(eb, m, 64); }
+        if (lane == 0) {
+            const uint64_t lo = ea < eb ? ea : eb, hi = ea < eb ? eb : ea;
+            const uint64_t c0 = (uint64_t)(ea + (uint64_t)eb) * gc, c1 = lo * mc + (hi - lo) * gc, c2 = hi * mc;
+            const uint64_t c01 = c0 < c1 ? c0 : c1, c = c01 < c2 ? c01 : c2;
+            bound[pair] = c > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)c;
+        }
+    }
+}
+hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + 3u) / 4u;
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(bag_bound_kernel, dim3(blocks), dim3(256), 0, st, a, b, n, mc, gc, bound);
+    return hipGetLastError();
+}
+
 }  // namespace ta
