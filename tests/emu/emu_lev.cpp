@@ -30,6 +30,12 @@ template <int D> static void run_d(const LevParams &P, bool affine, int trans, u
 int g_emu_force_ch = 0;
 extern "C" void emu_lev_set_chunk(int ch) { g_emu_force_ch = ch; }   // 0 = planner's choice, else 16 / 32 / 64
 
+// geometry of the pair-sliced kernel (lev_plan.h): out = {ok, S, dhi, c_ans, e_ans, dabs, steps}
+extern "C" void emu_sliced_plan(uint64_t a_len, uint64_t b_len, uint32_t unit_k, int64_t *out) {
+    const LevSlicedPlan p = lev_sliced_make_plan(a_len, b_len, unit_k);
+    out[0] = p.ok; out[1] = p.S; out[2] = p.dhi; out[3] = p.c_ans; out[4] = p.e_ans; out[5] = p.dabs; out[6] = p.steps;
+}
+
 extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
                             uint32_t n, uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, int has_t, uint32_t tc,
                             uint64_t max_len, int force_D, int force_L, int force_affine, uint32_t *out,

@@ -40,6 +40,8 @@ def lib():
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
                                      C.c_uint64, C.POINTER(C.c_uint64)]
+        L.emu_sliced_plan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.emu_sliced_plan.restype = None
         _lib = L
     return _lib
 
@@ -189,3 +191,11 @@ def lev_widebits_trace(a, b, k, trans=False, nwl=1):
     if dist.value == 0xFFFFFFFF:
         return None, None
     return int(dist.value), [(_EDIT_NAMES[int(out[i]["code"])], int(out[i]["count"])) for i in range(n.value)]
+
+
+def sliced_plan(a_len, b_len, unit_k):
+    """lev_plan.h lev_sliced_make_plan -> dict (ok, S, dhi, c_ans, e_ans, dabs, steps)."""
+    import numpy as np
+    out = np.zeros(7, dtype=np.int64)
+    lib().emu_sliced_plan(a_len, b_len, unit_k, out.ctypes.data)
+    return dict(zip(("ok", "S", "dhi", "c_ans", "e_ans", "dabs", "steps"), (int(v) for v in out)))

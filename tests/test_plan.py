@@ -48,3 +48,30 @@ def test_plan_band_is_half_of_the_reference_band_on_baseline_configs():
     assert pl["u"] == 32 and pl["o"] == 17 and pl["D"] * pl["L"] >= 34 and pl["D"] * pl["L"] < 66
     pl = plan_for(8, 128, (1, 1, 0, 1))
     assert pl["u"] == 8 and pl["o"] == 5 and pl["D"] * pl["L"] >= 10 and pl["D"] * pl["L"] < 18
+
+
+def test_sliced_plan_geometry():
+    """lev_sliced_make_plan: the strips cover the band of 3.1, the answer cell is row a_len of column b_len, S is odd."""
+    seen_ok = 0
+    for a_len in (1, 40, 64, 127, 256, 300, 512, 600):
+        for d in (-40, -10, -3, 0, 4, 11, 45):
+            b_len = a_len + d
+            if b_len < 1:
+                continue
+            for uk in (0, 8, 23, 24, 25, 32, 33, 40, 41, 44, 45, 60):
+                p = E.sliced_plan(a_len, b_len, uk)
+                if abs(d) > uk or b_len > 512:
+                    assert not p["ok"]
+                    continue
+                t = (uk - abs(d)) // 2
+                W = abs(d) + 2 * t + 1
+                assert p["S"] % 2 == 1 and 3 * p["S"] >= W and 3 * (p["S"] - 2) < W
+                assert p["ok"] == (9 <= p["S"] <= 15)
+                assert p["dhi"] == max(0, d) + t and p["dabs"] == abs(d)
+                w_ans = 3 * p["c_ans"] + p["e_ans"]
+                assert 0 <= w_ans < W and p["e_ans"] < 3
+                assert b_len - p["dhi"] + w_ans == a_len                  # row of window cell w_ans at column b_len
+                assert p["steps"] % 64 == 0 and p["steps"] >= 2 * b_len + p["S"]
+                seen_ok += p["ok"]
+    assert seen_ok > 50
+    assert E.sliced_plan(256, 256, 32) == dict(ok=1, S=11, dhi=16, c_ans=5, e_ans=1, dabs=0, steps=576)

@@ -164,4 +164,30 @@ static inline LevChoice lev_choose(uint32_t k, uint32_t mc, uint32_t gc, uint32_
     return c;
 }
 
+// Geometry of the pair-sliced systolic band kernel (lev_sliced.hip) for a fixed-length batch: the band of 3.1 cut into S
+// strips of three window cells (S odd: both entry lanes of a DPP row then hold the same set), 9 <= S <= 15.
+struct LevSlicedPlan {
+    bool ok;
+    uint32_t S;            // strips per group
+    int32_t dhi;           // highest diagonal (j - i) of the band: window cell w of column j is row j - dhi + w
+    uint32_t c_ans, e_ans; // strip and cell of the answer diagonal (window cell dhi - delta)
+    uint32_t dabs;         // |b_len - a_len|
+    uint32_t steps;        // time steps: every strip through b_len columns, rounded to whole 64-step epochs
+};
+inline LevSlicedPlan lev_sliced_make_plan(uint64_t a_len, uint64_t b_len, uint32_t unit_k) {
+    LevSlicedPlan p = {};
+    if (a_len == 0 || b_len == 0 || a_len > 0x7FFFFFF0ull || b_len > 512ull) return p;
+    const uint64_t dabs = a_len > b_len ? a_len - b_len : b_len - a_len;
+    if (dabs > unit_k) return p;
+    const uint32_t t = (unit_k - (uint32_t)dabs) / 2u, W = (uint32_t)dabs + 2u * t + 1u;
+    p.S = ((W + 2u) / 3u) | 1u;
+    p.dabs = (uint32_t)dabs;
+    p.dhi = (int32_t)((b_len > a_len ? (uint32_t)dabs : 0u) + t);
+    const uint32_t w_ans = (uint32_t)((int64_t)p.dhi - ((int64_t)b_len - (int64_t)a_len));
+    p.c_ans = w_ans / 3u; p.e_ans = w_ans % 3u;
+    p.steps = ((2u * (uint32_t)b_len + p.S + 2u) + 63u) / 64u * 64u;
+    p.ok = p.S >= 9u && p.S <= 15u;
+    return p;
+}
+
 }  // namespace ta

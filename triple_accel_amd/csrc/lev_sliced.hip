@@ -323,35 +323,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 }  // namespace
 
-static uint32_t sliced_strips(uint32_t W) {
-    uint32_t S = (W + 2u) / 3u;
-    return S | 1u;                                            // odd: both entry lanes then hold the same set
-}
-
 bool lev_sliced_applies(const StrView &a, const StrView &b, uint32_t unit_k, uint32_t *strips_out) {
     if (a.off || b.off) return false;                         // fixed-length (strided) batches only
-    if (a.len == 0 || b.len == 0 || a.len > 0x7FFFFFF0ull || b.len > 512ull) return false;
-    const uint64_t dabs = a.len > b.len ? a.len - b.len : b.len - a.len;
-    if (dabs > unit_k) return false;
-    const uint32_t t = (unit_k - (uint32_t)dabs) / 2u, W = (uint32_t)dabs + 2u * t + 1u, S = sliced_strips(W);
-    if (strips_out) *strips_out = S;
-    return S >= 9u && S <= 15u;
+    const LevSlicedPlan pl = lev_sliced_make_plan(a.len, b.len, unit_k);
+    if (strips_out) *strips_out = pl.S;
+    return pl.ok;
 }
 
 hipError_t lev_sliced_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t k, uint32_t unit_k, uint32_t *out,
                              hipStream_t st, uint32_t *grid_out, uint32_t *lds_out, uint32_t *pairs_per_wave) {
+    const LevSlicedPlan pl = lev_sliced_make_plan(a.len, b.len, unit_k);
+    if (!pl.ok) return hipErrorInvalidValue;
     SlicedParams P;
     P.a = a.blob; P.b = b.blob; P.a_stride = a.stride; P.b_stride = b.stride;
     P.alen = (uint32_t)a.len; P.blen = (uint32_t)b.len; P.n = n; P.k = k; P.out = out;
     P.a_bytes = (uint64_t)(n - 1u) * a.stride + a.len; P.b_bytes = (uint64_t)(n - 1u) * b.stride + b.len;
-    const int64_t delta = (int64_t)b.len - (int64_t)a.len;
-    P.dabs = (uint32_t)(delta < 0 ? -delta : delta);
-    const uint32_t t = (unit_k - P.dabs) / 2u, W = P.dabs + 2u * t + 1u;
-    P.dhi = (int32_t)((delta > 0 ? delta : 0) + t);
-    P.S = sliced_strips(W);
-    const uint32_t w_ans = (uint32_t)((int64_t)P.dhi - delta);
-    P.c_ans = w_ans / 3u;
-    P.steps = ((2u * P.blen + P.S + 2u) + 63u) / 64u * 64u;
+    P.dabs = pl.dabs; P.dhi = pl.dhi; P.S = pl.S; P.c_ans = pl.c_ans; P.steps = pl.steps;
     const uint32_t lds = 8u * (SL_SET_BYTES + 128u);
     const uint32_t ppw = 256u, grid = (n + ppw - 1u) / ppw;
     if (grid_out) *grid_out = grid;
@@ -363,7 +350,7 @@ hipError_t lev_sliced_launch(const StrView &a, const StrView &b, uint32_t n, uin
         (void)hipFuncSetAttribute((const void *)lev_sliced_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(lev_sliced_kernel<E>, dim3(grid), dim3(64), lds, st, P);                                       \
     }
-    switch (w_ans % 3u) {
+    switch (pl.e_ans) {
         case 0: SL_LAUNCH(0) break;
         case 1: SL_LAUNCH(1) break;
         default: SL_LAUNCH(2) break;
