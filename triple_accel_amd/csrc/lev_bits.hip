@@ -1,5 +1,6 @@
 // lev_bits.hip -- gfx950 instantiations of the bit-parallel band kernel (lev_bits_body.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "lev_bits_body.h"
 #include "lev_plan.h"
@@ -31,14 +32,20 @@ static hipError_t launch_na(const LevParams &P, bool trans, bool stat, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out,
-                           uint32_t *lds_out) {
+hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
+                           uint32_t *grid_out, uint32_t *lds_out) {
     const uint32_t waves = (P.n + 63u) / 64u;
     // 4 waves per block while four rings fit a quarter of the CU's LDS; else one wave per block so that the CU packs
     // as many waves as the LDS holds
     const uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
     const uint32_t grid = (waves + wpb - 1) / wpb;
-    const size_t lds = (size_t)pl.lds_per_wave * wpb;
+    // Strings longer than one 128-byte line: three blocks (12 waves) per CU instead of the four the rings would allow.  The
+    // issue slots are full either way (same run time on cfg2), and a quarter fewer pairs in flight lets the 4 MB L2 keep
+    // more lines until their second half is read (FETCH_SIZE 0.8-1.5 GB against 1.0-1.8 GB, box to box; 516 MB of
+    // strings).  TA_BITS_BLOCK_LDS overrides.
+    size_t lds = (size_t)pl.lds_per_wave * wpb;
+    if (wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
+    if (const char *e = getenv("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
