@@ -281,3 +281,31 @@ def test_a_few_long_pairs_in_a_fixed_length_batch():
         assert kernel_id() == 4
         want = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 0xFFFFFFFF)
         assert np.array_equal(got, want), (n, got, want)
+
+
+def test_small_passes_are_chosen_by_wavefront_latency(monkeypatch):
+    """Up to 1024 pairs the pass lasts as long as its slowest wavefront: a 256-byte pair goes through the row-blocked
+    kernel (one pair per wavefront) although the band kernel (64 pairs per wavefront) is cheaper per pair; the results
+    are the oracle's either way, and TA_NO_LATENCY_RULE=1 restores the throughput choice."""
+    import triple_accel_amd as T
+    g = Dg.rng(0x1A7)
+    for n_pairs in (1, 40, 900):
+        a, b = [], []
+        for i in range(n_pairs):
+            x = Dg.rand_str(g, int(g.integers(200, 300)))
+            a.append(x); b.append(Dg.mutate(g, x, int(g.integers(0, 45)), True) if i % 3 else Dg.rand_str(g, len(x)))
+        for k, costs in [(32, LEV), (32, RDAM), (8, LEV), (0xFFFFFFFF, LEV), (0xFFFFFFFF, RDAM)]:
+            monkeypatch.delenv("TA_NO_LATENCY_RULE", raising=False)
+            got = gpu_k(a, b, k, costs)
+            kid = kernel_id()
+            want = oracle_k(a, b, k, costs)
+            assert np.array_equal(got, want), (n_pairs, k, costs)
+            assert (kid in (3, 4)) if k == 8 else kid == 4, (n_pairs, k, costs, kid)
+            monkeypatch.setenv("TA_NO_LATENCY_RULE", "1")
+            assert np.array_equal(gpu_k(a, b, k, costs), want)
+            assert kernel_id() == (3 if k <= 32 else 1)
+    x = Dg.rand_str(g, 256)
+    y = Dg.mutate(g, x, 10, True)
+    monkeypatch.delenv("TA_NO_LATENCY_RULE", raising=False)
+    assert T.levenshtein(x, y) == O.levenshtein(x, y) and kernel_id() == 4
+    assert T.rdamerau(x, y) == O.rdamerau(x, y) and kernel_id() == 4

@@ -53,7 +53,7 @@ def test_sliced_vs_oracle(monkeypatch, n, la, lb, k, edits):
 
 
 def test_sliced_is_opt_in_and_declines_what_it_cannot_do(monkeypatch):
-    a, b = _batch(5, 500, 256, 256, 30)
+    a, b = _batch(5, 5000, 256, 256, 30)
     monkeypatch.delenv("TA_FORCE_SLICED", raising=False)
     _, info = _run(a, b, 32)
     assert info["kernel"] == 3                                   # default: the bit-parallel band kernel

@@ -136,24 +136,33 @@ struct LevChoice {
     double cost;
 };
 
+// `pairs`: how many pairs the pass holds.  Up to LEV_LATENCY_PAIRS of them (about one wavefront per SIMD on the GPU) the
+// pass lasts as long as its longest wavefront, so the kernels are compared by the instructions ONE wavefront issues, not
+// by the instructions per pair: a kernel that spreads a pair over a whole wavefront then beats one that packs 64 pairs.
+constexpr uint32_t LEV_LATENCY_PAIRS = 1024;
 static inline LevChoice lev_choose(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len,
-                                   bool dp_only) {
+                                   bool dp_only, uint32_t pairs = 0xFFFFFFFFu) {
     const double n = (double)(max_len ? max_len : 1);
+    const bool latency = pairs <= LEV_LATENCY_PAIRS;
     const LevBitsPlan bp = lev_bits_make_plan(k, mc, gc, sg, has_t, tc, max_len);
     const LevPlan pl = lev_make_plan(k, mc, gc, sg, max_len, 0, 0);
     const bool unit = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1);
     LevChoice c;
     if (bp.ok && !dp_only) {                                   // one pair per lane, ~6 instructions per window dword + 25
         c.kernel = LEV_K_BITS; c.rows_per_lane = 0;
-        c.cost = n * (6.0 * bp.NA + 25.0 + (has_t ? 8.0 : 0.0)) / 64.0;
-        return c;
+        c.cost = n * (6.0 * bp.NA + 25.0 + (has_t ? 8.0 : 0.0)) / (latency ? 1.0 : 64.0);
+        if (!latency) return c;
+    } else {
+        c.kernel = 0; c.rows_per_lane = 0; c.cost = 1e300;
     }
     // DP band: (4.5 D + 25) instructions per iteration, shared by the PW pairs of a wave; wide DP kernel: ~6 per cell
-    const double band = pl.ok ? n * (4.5 * pl.D + 25.0 + (has_t ? 1.5 * pl.D : 0.0)) / pl.PW : 1e300;
+    const double band = pl.ok ? n * (4.5 * pl.D + 25.0 + (has_t ? 1.5 * pl.D : 0.0)) / (latency ? 1.0 : pl.PW) : 1e300;
     const double uu = pl.u < n ? (double)pl.u : n;
     const double wide = (2.0 * n * uu - uu * uu) * 6.0 / 64.0 + n * 40.0;
-    c.kernel = band <= wide ? LEV_K_BAND : LEV_K_WIDE; c.rows_per_lane = 0;
-    c.cost = band <= wide ? band : wide;
+    if (c.kernel == 0) {                                       // (the bit-parallel band kernel, where it applies, beats the DP kernels)
+        c.kernel = band <= wide ? LEV_K_BAND : LEV_K_WIDE; c.rows_per_lane = 0;
+        c.cost = band <= wide ? band : wide;
+    }
     if (unit && !dp_only) {                                    // one pair per wave, one column of a 2048/4096-row stripe per ~45 instructions
         const int rpl = max_len > 2048 ? 64 : 32;
         const double rows = 64.0 * rpl, stripes = (double)((max_len + (uint64_t)rows - 1) / (uint64_t)rows);

@@ -105,7 +105,11 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
                                               env_int("TA_BITS_STATIC"));
     const bool dp_forced = env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L") || env_int("TA_FORCE_AFFINE") ||
                            env_int("TA_FORCE_TRANS_SELECT") || env_int("TA_FORCE_WIDE");
-    LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced);
+    // a pass of few pairs is as slow as its slowest wavefront: the chooser then compares wavefronts, not pairs (lev_plan.h);
+    // the switches that pin a kernel layout keep the throughput choice
+    const bool pinned = env_int("TA_NO_LATENCY_RULE") || env_int("TA_FORCE_NA") || env_int("TA_BITS_STATIC") || env_int("TA_FORCE_CH") ||
+                        env_int("TA_FORCE_SLICED");
+    LevChoice ch = lev_choose(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, dp_forced, pinned ? 0xFFFFFFFFu : n_work);
     const bool unit = c->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || tcost == 1);
     // a handful of long fixed-length pairs: the tiled row-blocked form uses many wavefronts per pair, whatever the band
     if (unit && !dp_forced && ch.kernel != LEV_K_BITS && (n_work == 1 || (n_work <= 16 && !subset)) && !a->off && !b->off &&
@@ -315,7 +319,17 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     uint32_t n_left = (uint32_t)n;                          // unresolved pairs (sub_in == nullptr: all of them)
     uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
     int flip = 0;
+    const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
+    const bool dpo = env_int("TA_NO_BITS") != 0, faithful = env_int("TA_EXP_FAITHFUL") != 0;
     for (int round = 0; round < 40 && n_left > 0; round++) {
+        // Once a bounded pass would cost more than a quarter of the unbounded one (kernel cost model, lev_plan.h: per pair for
+        // big passes, per wavefront for small ones), it is cheaper in expectation to finish the unresolved pairs with
+        // k = u32::MAX right away (same return values -- levenshtein_exp returns the distance, whatever k schedule finds it).
+        if (!faithful && k != 0xFFFFFFFFu) {
+            const double c_this = lev_choose(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo, n_left).cost;
+            const double c_full = lev_choose(0xFFFFFFFFu, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo, n_left).cost;
+            if (c_this > 0.25 * c_full) k = 0xFFFFFFFFu;
+        }
         const uint32_t *work = sub_in;
         uint32_t n_work = n_left;
         if (bounded && k != 0xFFFFFFFFu) {
@@ -328,6 +342,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         if (n_work > 0) {
             rc = lev_pass(a, b, n_work, work, k, costs, max_len, out_dev, st);
             if (rc) return rc;
+            if (k == 0xFFFFFFFFu) break;                    // the unbounded pass answers every pair it is given (all that were left)
             TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
             TA_HIP(compact_none_launch(out_dev, sub_in, n_left, bufs[flip], (uint32_t *)cnt.dev, st));
             uint32_t left = 0;
@@ -338,14 +353,6 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
             n_left = left;
         }
         k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
-        // Once the next bounded pass would cost more than a quarter of the unbounded one (kernel cost model, lev_plan.h),
-        // it is cheaper in expectation to finish the unresolved pairs with k = u32::MAX right away (same return values
-        // -- levenshtein_exp returns the distance, whatever k schedule finds it).
-        const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
-        const bool dpo = env_int("TA_NO_BITS") != 0;
-        const double c_next = lev_choose(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo).cost;
-        const double c_full = lev_choose(0xFFFFFFFFu, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo).cost;
-        if (c_next > 0.25 * c_full && !env_int("TA_EXP_FAITHFUL")) k = 0xFFFFFFFFu;
     }
     return TA_OK;
 }
