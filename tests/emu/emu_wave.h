@@ -83,6 +83,24 @@ struct EmuWave {
         }
         return r;
     }
+    static U32 sdot4(const U32 &a, const U32 &b, const U32 &acc) {
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            int32_t t = (int32_t)acc.v[i];
+            for (int k = 0; k < 4; k++) t += (int32_t)(int8_t)(a.v[i] >> (8 * k)) * (int32_t)(int8_t)(b.v[i] >> (8 * k));
+            r.v[i] = (uint32_t)t;
+        }
+        return r;
+    }
+    static U32 ne12(const U32 &x) {
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            uint32_t f = 0;
+            for (int k = 0; k < 4; k++) if (((x.v[i] >> (8 * k)) & 0xffu) != 12u) f |= 0xffu << (8 * k);
+            r.v[i] = f;
+        }
+        return r;
+    }
     static U32 splat_byte(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] & 0xffu) * 0x01010101u; return r; }
     static void addc(const U32 &a, const U32 &b, const Bool &cin, U32 &sum, Bool &cout) {
         for (int i = 0; i < 64; i++) {

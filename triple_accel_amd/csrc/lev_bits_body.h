@@ -10,8 +10,10 @@
 // so a DIAGONAL is a fixed bit position and the distance is read off the answer cell's diagonal:
 //     d = |delta| + sum over columns (1 - D0[bit of that diagonal]),
 // D0 = "the cell equals its diagonal predecessor").  What dominates is no longer the recurrence but building
-// the match vector: 4 byte compares per SWAR group, then v_dot4_u32_u8 with power-of-two weights squeezes the
-// four flag bytes into a nibble.
+// the match vector: the window keeps `a` XOR 0x0C, so after the XOR with the column character a byte is 12 exactly
+// where the two agree; ONE v_perm_b32 with all-ones sources maps byte 12 to 0x00 and every other value to 0xFF (W::ne12),
+// and v_dot4_i32_i8 with the weights -1, -2, ... -128 adds eight such 0 / -1 flags up to their bit mask: 3 instructions
+// per dword of the window.
 //
 // One pair per lane (64 pairs per wavefront); the window is 4*NA bits wide (NA = packed dwords of `a` bytes
 // under it; 4*NA - 3 in the static form below).  Rows outside [1, a_len] need no masking: above row 0 the virtual values D[r][j] = j + |r| satisfy
@@ -41,7 +43,7 @@ struct LevBits {
 
     struct State {
         U32 VP[NW], VN[NW];     // vertical +1 / -1 differences of the previous column, at the current window's rows
-        U32 AW[NA];             // byte i = a[row(i) - 1], row(i) = j - d_hi + i: window bit i <-> byte i
+        U32 AW[NA];             // byte i = a[row(i) - 1] ^ 0x0C, row(i) = j - d_hi + i: window bit i <-> byte i
         U32 PMp[NW], D0p[NW];   // TRANS: previous column's match vector and D0
     };
 
@@ -49,7 +51,7 @@ struct LevBits {
     static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in) {
 #pragma unroll
         for (int k = 0; k < NA - 1; k++) st.AW[k] = W::template alignbyte<1>(st.AW[k + 1], st.AW[k]);
-        st.AW[NA - 1] = W::template alignbyte<1>(a_in, st.AW[NA - 1]);
+        st.AW[NA - 1] = W::template alignbyte<1>(a_in ^ 0x0Cu, st.AW[NA - 1]);
     }
 
     // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
@@ -59,20 +61,21 @@ struct LevBits {
         U32 PM[NW], D0[NW], NE[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
+            // the window bytes carry `a` ^ 0x0C: a byte of x is 12 exactly where a == b, and W::ne12 (one v_perm_b32) turns
+            // that into 0x00 / 0xFF = 0 / -1; signed weights -1, -2, .. -128 add eight flags up to their bit mask.  Byte
+            // groups from the top down, Horner style: the accumulator of a group is the mask so far, shifted up.
             U32 ne = W::splat(0);
+            bool first = true;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+            for (int p = 3; p >= 0; p--) {
                 const int k0 = 8 * q + 2 * p;
-                if (k0 >= NA) break;
-                U32 acc = W::splat(0);
+                if (k0 >= NA) continue;
+                U32 acc = first ? W::splat(0) : (ne << 8);
+                first = false;
 #pragma unroll
-                for (int h = 0; h < 2 && k0 + h < NA; h++) {
-                    const U32 x = st.AW[k0 + h] ^ Bs;
-                    const U32 t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;                 // bit 7 of each byte <- low 7 bits nonzero
-                    const U32 f = W::opaque((t | x) & 0x80808080u);               // 0x80 per mismatching byte
-                    acc = W::dot4(f, W::splat(h ? 0x80402010u : 0x08040201u), acc);   // 128 * (8 mismatch bits)
-                }
-                ne = p == 0 ? (acc >> 7) : (ne | (acc << (8 * p - 7)));
+                for (int h = 0; h < 2 && k0 + h < NA; h++)
+                    acc = W::sdot4(W::ne12(st.AW[k0 + h] ^ Bs), W::splat(h ? 0x80C0E0F0u : 0xF8FCFEFFu), acc);
+                ne = acc;
             }
             NE[q] = ne;
         }
@@ -213,8 +216,8 @@ struct LevBits {
 #pragma unroll
                         for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
                         const U32 pa = ra + tp;
-                        st.AW[NA - 1] = W::lds_u8(lds, pa) | (W::lds_u8(lds, pa + 1u) << 8) | (W::lds_u8(lds, pa + 2u) << 16) |
-                                        (W::lds_u8(lds, pa + 3u) << 24);
+                        st.AW[NA - 1] = (W::lds_u8(lds, pa) | (W::lds_u8(lds, pa + 1u) << 8) | (W::lds_u8(lds, pa + 2u) << 16) |
+                                         (W::lds_u8(lds, pa + 3u) << 24)) ^ 0x0C0C0C0Cu;
                         if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
                         const U32 pb = rb + tp;
                         const U32 b0 = W::lds_u8(lds, pb), b1 = W::lds_u8(lds, pb + 1u), b2 = W::lds_u8(lds, pb + 2u), b3 = W::lds_u8(lds, pb + 3u);

@@ -64,6 +64,12 @@ struct DevWave {
     }
     // acc + sum of the four byte products of a and b -> v_dot4_u32_u8
     static __device__ __forceinline__ U32 dot4(U32 a, U32 b, U32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+    // acc + sum of the four SIGNED byte products -> v_dot4_i32_i8
+    static __device__ __forceinline__ U32 sdot4(U32 a, U32 b, U32 acc) { return (U32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
+    // 0x00 in every byte of x that equals 12, 0xFF in the others -> ONE v_perm_b32: with all-ones sources every byte
+    // selector reads 0xFF (0-7: a source byte, 8-11: a replicated sign bit, >= 13: the constant 0xFF) except 12, the
+    // constant 0x00.  XOR-ing one side of a byte compare with 0x0C turns this into a per-byte != test.
+    static __device__ __forceinline__ U32 ne12(U32 x) { return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, x); }
     // the low byte of x in all four bytes -> v_perm_b32
     static __device__ __forceinline__ U32 splat_byte(U32 x) { return __builtin_amdgcn_perm(x, x, 0x04040404u); }
     // sum = a + b + cin, cout = carry out -> v_add_co_u32 / v_addc_co_u32
