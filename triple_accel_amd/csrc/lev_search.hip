@@ -323,10 +323,12 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uin
             typedef uint32_t u32u __attribute__((aligned(1)));
             nd = *(const u32u *)(P.needle_dev + 4 * w);                     // needle_dev carries 16 bytes of slack
         }
+        // byte test with one v_perm_b32 (wave.h ne12): the needle word carries ^ 0x0C, a window byte then XORs to 12 exactly
+        // where it matches; bytes past the needle's end are forced to 12.  Every mismatching byte adds 8 one-bits.
         const uint32_t m = (w + 1 == nwords) ? tail_mask : 0xFFFFFFFFu;
+        const uint32_t nd12 = nd ^ 0x0C0C0C0Cu, pad = 0x0C0C0C0Cu & ~m;
         auto nz = [&](uint32_t win) -> uint32_t {
-            uint32_t x = (win ^ nd) & m;
-            return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+            return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, ((win ^ nd12) & m) | pad);
         };
         c0 += __builtin_popcount(nz(lo));
         c1 += __builtin_popcount(nz(__builtin_amdgcn_alignbyte(hi, lo, 1)));
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uin
         c3 += __builtin_popcount(nz(__builtin_amdgcn_alignbyte(hi, lo, 3)));
         lo = hi;
     }
-    const uint32_t cnt[4] = {c0, c1, c2, c3};
+    const uint32_t cnt[4] = {c0 >> 3, c1 >> 3, c2 >> 3, c3 >> 3};
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint64_t b = byte0 + r;
