@@ -188,6 +188,19 @@ def main():
         except Exception:
             traffic = None
 
+    # the companion roofline of this integer path: VALU issue (one instruction per SIMD per 4 cycles), from the committed
+    # counter passes of the same command (profiles/r01/bench_cfg2_pmc.json); None when no profile is present
+    valu_issue = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "bench_%s_pmc.json" % wl)
+    if os.path.exists(pmc):
+        try:
+            c = json.load(open(pmc))
+            insts, busy = c["SQ_INSTS_VALU"]["mean_per_launch"], c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+            valu_issue = {"valu_insts_per_launch": insts, "busy_cycles_per_xcd": busy, "simds": 1024,
+                          "frac": insts * 4.0 / (1024.0 * busy), "source": "profiles/r01/bench_%s_pmc.json" % wl}
+        except Exception:
+            valu_issue = None
+
     cpu = None
     if not args.no_cpu and world == 1:        # the CPU leg runs at N = 1 only (rank 0)
         def timed(fn, min_s=4.0, max_reps=64):
@@ -251,6 +264,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "device_ms_per_pass": dev_s * 1e3, "algorithmic_bytes_per_pass": bytes_unit * units,
+                     "valu_issue": valu_issue,
                      "note": "integer VALU-issue-bound path (DESIGN.md section 5); the HBM fraction is reported because north_star asks for it"},
         "cpu_baseline": cpu,
         "kernel": info, "parity_checked_units": parity_n,
