@@ -92,6 +92,7 @@ struct EmuWave {
         }
         return r;
     }
+    static U32 sdot4_first(const U32 &a, const U32 &b) { V32 z; for (int i = 0; i < 64; i++) z.v[i] = 0; return sdot4(a, b, z); }
     static U32 ne12(const U32 &x) {
         V32 r;
         for (int i = 0; i < 64; i++) {

@@ -70,11 +70,10 @@ struct LevBits {
             for (int p = 3; p >= 0; p--) {
                 const int k0 = 8 * q + 2 * p;
                 if (k0 >= NA) continue;
-                U32 acc = first ? W::splat(0) : (ne << 8);
+                U32 acc = first ? W::sdot4_first(W::ne12(st.AW[k0] ^ Bs), W::splat(0xF8FCFEFFu))
+                                : W::sdot4(W::ne12(st.AW[k0] ^ Bs), W::splat(0xF8FCFEFFu), ne << 8);
                 first = false;
-#pragma unroll
-                for (int h = 0; h < 2 && k0 + h < NA; h++)
-                    acc = W::sdot4(W::ne12(st.AW[k0 + h] ^ Bs), W::splat(h ? 0x80C0E0F0u : 0xF8FCFEFFu), acc);
+                if (k0 + 1 < NA) acc = W::sdot4(W::ne12(st.AW[k0 + 1] ^ Bs), W::splat(0x80C0E0F0u), acc);
                 ne = acc;
             }
             NE[q] = ne;

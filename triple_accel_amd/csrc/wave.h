@@ -66,6 +66,9 @@ struct DevWave {
     static __device__ __forceinline__ U32 dot4(U32 a, U32 b, U32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
     // acc + sum of the four SIGNED byte products -> v_dot4_i32_i8
     static __device__ __forceinline__ U32 sdot4(U32 a, U32 b, U32 acc) { return (U32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
+    // the same without an accumulator (clamped form: the three-address encoding, no v_mov of a zero first; the sums here
+    // never come near the clamp)
+    static __device__ __forceinline__ U32 sdot4_first(U32 a, U32 b) { return (U32)__builtin_amdgcn_sdot4((int)a, (int)b, 0, true); }
     // 0x00 in every byte of x that equals 12, 0xFF in the others -> ONE v_perm_b32: with all-ones sources every byte
     // selector reads 0xFF (0-7: a source byte, 8-11: a replicated sign bit, >= 13: the constant 0xFF) except 12, the
     // constant 0x00.  XOR-ing one side of a byte compare with 0x0C turns this into a per-byte != test.
