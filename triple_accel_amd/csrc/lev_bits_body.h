@@ -237,6 +237,14 @@ struct LevBits {
                 for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
                     advance_a(st, W::lds_u8(lds, ra + tp));
                 if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the part's end
+                    for (; tp + 4u <= p_hi; tp += 4u) {        // four columns per address computation
+                        const U32 pa = ra + tp, pb = rb + tp;
+#pragma unroll
+                        for (uint32_t s4 = 0; s4 < 4u; s4++) {
+                            advance_a(st, W::lds_u8(lds, pa + s4));
+                            column<false>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
+                        }
+                    }
                     for (; tp < p_hi; tp++) {
                         const U32 a_in = W::lds_u8(lds, ra + tp), b_in = W::lds_u8(lds, rb + tp);
                         advance_a(st, a_in);
