@@ -129,8 +129,7 @@ def main():
         from triple_accel_amd import dist as TD
 
         def run():
-            hits = B.levenshtein_search_dev(needle, hay, k, costs)                 # All-mode hits (kernel + gather + sort)
-            holder["hits"] = hits
+            hits = B.levenshtein_search_best_dev(needle, hay, k, costs)            # kernels + on-device selection of the best-k hits
             holder["best"] = TD.fold_best(hits, k, True)                           # the sequential Best pass (host)
         desc = "levenshtein_search 32B needle over a %d MiB random haystack shard per GPU, k=16, Best" % mib
         unit_name, dtype = "haystack bytes", "u16+u16 (cost|length packed in a u32 lane)"
@@ -143,8 +142,10 @@ def main():
             run(); torch.cuda.synchronize()
             ns = min(hay_np.size, 4 << 20)
             want = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), k, O.ALL, costs, False)
-            got = [tuple(int(v) for v in r) for r in holder["hits"] if r[1] <= ns]
+            allhits = B.levenshtein_search_dev(needle, hay, k, costs)              # All-mode hits of the whole shard
+            got = [tuple(int(v) for v in r) for r in allhits if r[1] <= ns]
             assert got == [w for w in want if w[1] > 0], "parity gate failed: HIP search != oracle"
+            assert holder["best"] == TD.fold_best(allhits, k, True), "parity gate failed: on-device Best selection != fold over all hits"
             return ns
 
     # ------------------------------------------------------------------ parity gate, warm-up, timed region

@@ -202,6 +202,11 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
                           const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
                           uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
 
+/* Best-mode shortcut for a shard whose All-mode hits sit in HBM (the hits_dev / count of ta_*_search_dev): only the hits
+ * with the smallest k can survive ta_search_fold_best, so the minimum and the selection run on the device and only those
+ * records come back -- library-allocated (ta_free), sorted by end, ready for ta_search_fold_best.  Synchronises. */
+int ta_search_best_hits_dev(const ta_match *hits_dev, uint64_t count, ta_match **out, size_t *n_out, void *stream);
+
 /* Sequential Best post-pass over All-mode hits in increasing `end` order (host memory):
  * running curr_k, overlap fold, final filter (src/levenshtein.rs:1792-1796, 1812-1835;
  * hamming: src/hamming.rs:122-143 with fold = 0).  In place; returns the new count. */

@@ -243,3 +243,34 @@ def test_full_size_cfg5_filter_equals_exact(monkeypatch):
     ora = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), 16, O.ALL, (1, 1, 0, None), False)
     assert [tuple(int(v) for v in r) for r in got if r[1] <= ns] == [w for w in ora if w[1] > 0]
     torch.cuda.synchronize()
+
+
+def test_best_hits_selected_on_the_device():
+    """ta_search_best_hits_dev: the best-k hits picked on the device + the Best fold == the Best fold over all hits ==
+    the oracle's Best, incl. runs of overlapping best hits and a haystack without any hit."""
+    from triple_accel_amd import batch as B, dist as TD
+    g = Dg.rng(0xBE57)
+    for trial in range(12):
+        n = int(g.integers(4, 40))
+        needle = Dg.rand_str(g, n)
+        k = int(g.integers(0, max(1, n // 2) + 1))
+        costs = (1, 1, 0, None) if trial % 3 else (1, 1, 0, 1)
+        hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 200_000, 40, max(1, k))
+        if trial == 5:
+            hay = (needle * 3 + b"zz" + needle + needle[: n // 2] + needle) * 50            # runs of overlapping exact hits
+        if trial == 7:
+            hay, k = bytes(Dg.random_bytes(g, 50_000)), 0                                    # (almost surely) no hit at all
+        t = B.haystack_tensor(hay)
+        allhits = B.levenshtein_search_dev(needle, t, k, costs)
+        best_rows = B.levenshtein_search_best_dev(needle, t, k, costs)
+        if len(allhits):
+            kmin = allhits[:, 2].min()
+            assert (best_rows[:, 2] == kmin).all() and len(best_rows) == int((allhits[:, 2] == kmin).sum())
+            assert (np.diff(best_rows[:, 1]) > 0).all()
+        else:
+            assert len(best_rows) == 0
+        whole = len(needle) * costs[1] + costs[2]
+        head = [(0, 0, whole)] if whole <= k else []
+        got = TD.fold_best(head + [tuple(int(v) for v in r) for r in best_rows], k, True)
+        assert got == TD.fold_best(head + [tuple(int(v) for v in r) for r in allhits], k, True)
+        assert got == O.levenshtein_search_naive_with_opts(needle, hay, k, O.BEST, costs, False), (trial, n, k)

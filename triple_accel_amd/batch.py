@@ -124,6 +124,31 @@ def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchore
     return _hits_to_numpy(hits, int(count.value))
 
 
+def levenshtein_search_best_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, base=0, emit_from=0, cap=None):
+    """The hits of levenshtein_search_dev that can survive the Best fold (those with the smallest k), selected on the
+    device: int64 rows (start, end, k) sorted by end -- feed them to dist.fold_best.  Only these few records leave HBM."""
+    import numpy as np
+    hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
+    assert hay.dtype == torch.uint8 and hay.is_cuda and hay.is_contiguous()
+    needle = bytes(needle)
+    cap = cap or min(length + 2, 1 << 22)
+    hits = _hit_buffer(hay.device, cap)
+    count = _C.c_uint64()
+    cc = _costs(costs)._c()
+    rc = _n.lib().ta_levenshtein_search_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), 0,
+                                            base, emit_from, hits.data_ptr(), cap, _C.byref(count), _stream())
+    _raise(rc)
+    out = _C.POINTER(_n.MatchC)()
+    n_out = _C.c_size_t()
+    rc = _n.lib().ta_search_best_hits_dev(hits.data_ptr(), int(count.value), _C.byref(out), _C.byref(n_out), _stream())
+    _raise(rc)
+    rows = np.empty((n_out.value, 3), dtype=np.int64)
+    for i in range(n_out.value):
+        rows[i] = (out[i].start, out[i].end, out[i].k)
+    _n.lib().ta_free(out)
+    return rows
+
+
 def hamming_search_dev(needle, haystack, k, base=0, cap=None):
     hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
     needle = bytes(needle)

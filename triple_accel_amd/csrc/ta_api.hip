@@ -45,7 +45,7 @@ int Scratch::ensure(size_t bytes) {
 }
 Scratch::~Scratch() { /* device memory is reclaimed at process exit; hipFree during TLS teardown is unsafe */ }
 Scratch &tls_scratch(int which) {
-    static thread_local Scratch s[12];
+    static thread_local Scratch s[13];
     return s[which];
 }
 

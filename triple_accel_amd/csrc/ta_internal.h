@@ -60,6 +60,8 @@ hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, u
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
                                 uint32_t *list_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st);
+hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*device, preset to ~0*/, ta_match *out, uint32_t cap,
+                            uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 hipError_t iota_launch(uint32_t *p, uint32_t n, hipStream_t st);
 
 struct SearchParams {

@@ -176,6 +176,46 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
     return c[0] > cap ? TA_ERR_CAPACITY : TA_OK;
 }
 
+// The hits of a device-resident All-mode result that can survive the Best fold -- those with the smallest k -- sorted by end.
+int ta_search_best_hits_dev(const ta_match *hits_dev, uint64_t count, ta_match **out, size_t *n_out, void *stream) {
+    if (!out || !n_out || (!hits_dev && count)) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (count == 0) return TA_OK;
+    if (!device_ready()) return TA_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t cap = 1u << 16;                                // best hits kept on the first try (rarely more than a handful)
+    Scratch &sel = tls_scratch(12), &cnt = tls_scratch(2);
+    int rc;
+    if ((rc = sel.ensure((size_t)cap * sizeof(ta_match))) || (rc = cnt.ensure(16))) return rc;
+    uint32_t *ctr = (uint32_t *)cnt.dev;                          // [0] count, [1] min k
+    TA_HIP(hipMemsetAsync(ctr, 0, 4, st));
+    TA_HIP(hipMemsetAsync(ctr + 1, 0xFF, 4, st));
+    TA_HIP(hits_best_launch(hits_dev, count, ctr + 1, (ta_match *)sel.dev, cap, ctr, st));
+    uint32_t host[2] = {0, 0};
+    TA_HIP(hipMemcpyAsync(host, ctr, 8, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    std::vector<ta_match> v;
+    if (host[0] <= cap) {
+        v.resize(host[0]);
+        if (host[0]) TA_HIP(hipMemcpyAsync(v.data(), sel.dev, (size_t)host[0] * sizeof(ta_match), hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+    } else {                                                      // a flood of equally good hits: take everything and filter here
+        std::vector<ta_match> all(count);
+        TA_HIP(hipMemcpyAsync(all.data(), hits_dev, (size_t)count * sizeof(ta_match), hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+        for (const ta_match &h : all)
+            if (h.k == host[1]) v.push_back(h);
+    }
+    std::sort(v.begin(), v.end(), [](const ta_match &x, const ta_match &y) { return x.end != y.end ? x.end < y.end : x.start < y.start; });
+    *n_out = v.size();
+    if (!v.empty()) {
+        *out = (ta_match *)malloc(v.size() * sizeof(ta_match));
+        if (!*out) return TA_ERR_ARG;
+        memcpy(*out, v.data(), v.size() * sizeof(ta_match));
+    }
+    return TA_OK;
+}
+
 // src/levenshtein.rs:1792-1796 + :1812-1835 (levenshtein) / src/hamming.rs:122-143 (overlap_fold = 0)
 size_t ta_search_fold_best(ta_match *hits, size_t n, uint32_t k, int overlap_fold) {
     uint32_t curr_k = k;

@@ -160,4 +160,33 @@ hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint
     return hipGetLastError();
 }
 
+// Best-mode reduction of a shard's All-mode hits on the device: the smallest k, then the hits that have it.  (Only those can
+// survive ta_search_fold_best: its final filter keeps k == the running minimum, every hit with the minimum passes the
+// running test, and the overlap rule only ever compares a survivor with the survivor before it.)
+__global__ void hits_min_k_kernel(const ta_match *hits, uint64_t n, uint32_t *min_k) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = i < n ? hits[i].k : 0xFFFFFFFFu;
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint32_t y = __shfl_xor(v, m, 64);
+        v = v < y ? v : y;
+    }
+    if ((threadIdx.x & 63u) == 0 && v != 0xFFFFFFFFu) atomicMin(min_k, v);
+}
+__global__ void hits_select_k_kernel(const ta_match *hits, uint64_t n, const uint32_t *min_k, ta_match *out, uint32_t cap, uint32_t *count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ta_match h = hits[i];
+    if (h.k != *min_k) return;
+    uint32_t at = atomicAdd(count, 1u);
+    if (at < cap) out[at] = h;
+}
+hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*device, preset to ~0*/, ta_match *out, uint32_t cap,
+                            uint32_t *count /*device, pre-zeroed*/, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(hits_min_k_kernel, dim3(blocks), dim3(256), 0, st, hits, n, min_k);
+    hipLaunchKernelGGL(hits_select_k_kernel, dim3(blocks), dim3(256), 0, st, hits, n, min_k, out, cap, count);
+    return hipGetLastError();
+}
+
 }  // namespace ta

@@ -60,9 +60,11 @@ def fold_best(hits, k, overlap_fold=True):
     return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in arr[:m]]
 
 
-def _gpu_local_search(needle, hay_ext, k, costs, base, emit_from):
+def _gpu_local_search(needle, hay_ext, k, costs, base, emit_from, best=False):
     from . import batch as B
     t = B.haystack_tensor(hay_ext) if not isinstance(hay_ext, tuple) else hay_ext
+    if best:                     # only the hits with the shard's smallest k leave the device (see below)
+        return B.levenshtein_search_best_dev(needle, t, k, costs, base, emit_from)
     return B.levenshtein_search_dev(needle, t, k, costs, False, base, emit_from)
 
 
@@ -106,9 +108,17 @@ def levenshtein_search_sharded(needle, shard, k, search_type=SearchType.Best, co
         r -= 1
     ctx = ctx[-halo:] if len(ctx) > halo else ctx
 
-    fn = local_search or _gpu_local_search
     base = int(offs[rank]) - len(ctx)
-    local = np.asarray(fn(needle, ctx + shard, k, costs, base, int(offs[rank])), dtype=np.int64).reshape(-1, 3)
+    best = search_type == SearchType.Best
+    if local_search is None:
+        local = _gpu_local_search(needle, ctx + shard, k, costs, base, int(offs[rank]), best)
+    else:
+        local = local_search(needle, ctx + shard, k, costs, base, int(offs[rank]))
+    local = np.asarray(local, dtype=np.int64).reshape(-1, 3)
+    if best and len(local):
+        # Best keeps the hits with the globally smallest k, and once the running minimum has reached it no other hit is
+        # emitted any more (src/levenshtein.rs:1792-1835): a shard only needs to contribute the hits with ITS smallest k
+        local = local[local[:, 2] == local[:, 2].min()]
 
     # the one exchange step: gather the (tiny) match lists
     flat = torch.from_numpy(np.ascontiguousarray(local).reshape(-1)).to(dev)
