@@ -119,12 +119,18 @@ struct DevWave {
         return (Ptr)(((uint64_t)hi << 32) | lo);
     }
     static __device__ __forceinline__ bool any(Bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+    // wave-wide unsigned maximum in six DPP steps (no LDS round trips): row_shr 1, 2, 4, 8 leave a row's maximum in its
+    // lane 15 (a lane without a source reads 0, the identity), row_bcast:15 / row_bcast:31 carry it on to lane 63
     static __device__ __forceinline__ uint32_t wave_max(U32 x) {
-        for (int m = 32; m >= 1; m >>= 1) {
-            U32 y = shfl(x, lane() ^ (uint32_t)m);
-            x = x > y ? x : y;
-        }
-        return __builtin_amdgcn_readfirstlane(x);
+#define TA_DPP_MAX(ctrl, rows)                                                                        \
+    {                                                                                                 \
+        const U32 y = (U32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, true);              \
+        x = x > y ? x : y;                                                                            \
+    }
+        TA_DPP_MAX(0x111, 0xf) TA_DPP_MAX(0x112, 0xf) TA_DPP_MAX(0x114, 0xf) TA_DPP_MAX(0x118, 0xf)
+        TA_DPP_MAX(0x142, 0xa) TA_DPP_MAX(0x143, 0xc)
+#undef TA_DPP_MAX
+        return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     }
 
     static __device__ __forceinline__ void load_str(const StrView &s, U32 idx, Bool valid, Ptr &p, U32 &len) {
