@@ -33,3 +33,8 @@ ms_s, rows = t(lambda: B._hits_to_numpy(buf, n))
 print("device sort + copy: %.3f ms" % ms_s)
 ms_f, best = t(lambda: TD.fold_best(rows, 16, True))
 print("host fold: %.3f ms -> %d matches" % (ms_f, len(best)))
+ms_b, rows_b = t(lambda: B.levenshtein_search_best_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS))
+print("search_best_dev (C call + on-device selection): %.3f ms, %d rows" % (ms_b, len(rows_b)))
+ms_a, _ = t(lambda: TD.fold_best(B.levenshtein_search_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS), 16, True))
+ms_n, _ = t(lambda: TD.fold_best(B.levenshtein_search_best_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS), 16, True))
+print("whole pass: all hits to the host %.3f ms, best-k hits only %.3f ms" % (ms_a, ms_n))
