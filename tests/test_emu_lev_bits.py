@@ -123,3 +123,27 @@ def test_bits_planner_picks_the_static_form_from_8_dwords():
     assert not plan["static"] and plan["NA"] == 3                             # cfg4: too narrow to pay for itself
     got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 33, False)
     assert plan["static"] and plan["NA"] == 10
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bits_byte_values_around_the_perm_selector_codes(trans):
+    """The byte test is a v_perm_b32 selector lookup (a ^ b ^ 0x0C == 12): alphabets of the selector codes that behave
+    specially (0..13, 0x0C itself, 0x8C, 0xFF) must still compare exactly, sliding and static window forms."""
+    g = np.random.default_rng(0xC0DE)
+    for alpha in ([0x0C, 0x00], [0x00, 0x08, 0x0B, 0x0C, 0x0D], [0x0C, 0x8C, 0xFF, 0x04]):
+        al = np.array(alpha, dtype=np.uint8)
+        a = [al[g.integers(0, len(al), int(g.integers(0, 50)))].tobytes() for _ in range(64)]
+        b = []
+        for x in a:
+            y = bytearray(x)
+            for _ in range(int(g.integers(0, 6))):
+                if y and g.random() < 0.5:
+                    y[int(g.integers(0, len(y)))] = int(al[int(g.integers(0, len(al)))])
+                elif y and g.random() < 0.5:
+                    del y[int(g.integers(0, len(y)))]
+                else:
+                    y.insert(int(g.integers(0, len(y) + 1)), int(al[int(g.integers(0, len(al)))]))
+            b.append(bytes(y))
+        for k, na, static in ((12, 0, 0), (30, 9, 2)):
+            got, plan = E.lev_bits(a, b, k, trans, force_NA=na, static=static)
+            assert got == oracle(a, b, k, trans), (alpha[:4], k, na, static)

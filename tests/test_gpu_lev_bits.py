@@ -309,3 +309,38 @@ def test_small_passes_are_chosen_by_wavefront_latency(monkeypatch):
     monkeypatch.delenv("TA_NO_LATENCY_RULE", raising=False)
     assert T.levenshtein(x, y) == O.levenshtein(x, y) and kernel_id() == 4
     assert T.rdamerau(x, y) == O.rdamerau(x, y) and kernel_id() == 4
+
+
+def test_byte_values_around_the_perm_selector_codes():
+    """The match vector tests bytes with v_perm_b32 selectors (a ^ b ^ 0x0C == 12): alphabets made of the selector codes that
+    behave specially (0..13, the sign-replicating 8..11, 0x0C itself, 0xFF) and the full byte range must still compare
+    exactly, in the sliding and the static window forms, with and without transpositions."""
+    g = Dg.rng(0xC0DE)
+    alphabets = [[0x0C, 0x00], [0x0C, 0x0D], [0x00, 0x08, 0x0B, 0x0C], [0x0C, 0x8C, 0xFF, 0x04], list(range(0, 16)), list(range(256))]
+    for alpha in alphabets:
+        al = np.array(alpha, dtype=np.uint8)
+        a, b = [], []
+        for _ in range(1500):
+            n = int(g.integers(0, 120))
+            x = al[g.integers(0, len(al), n)]
+            if g.random() < 0.7:
+                y = x.copy()
+                for _e in range(int(g.integers(0, 10))):
+                    if len(y) == 0:
+                        break
+                    op, pos = int(g.integers(0, 4)), int(g.integers(0, len(y)))
+                    if op == 0:
+                        y[pos] = al[int(g.integers(0, len(al)))]
+                    elif op == 1:
+                        y = np.insert(y, pos, al[int(g.integers(0, len(al)))])
+                    elif op == 2:
+                        y = np.delete(y, pos)
+                    elif pos + 1 < len(y):
+                        y[pos], y[pos + 1] = y[pos + 1], y[pos]
+            else:
+                y = al[g.integers(0, len(al), int(g.integers(0, 120)))]
+            a.append(x.tobytes()); b.append(y.tobytes())
+        for k, costs in [(3, LEV), (9, RDAM), (30, LEV), (33, RDAM), (60, LEV)]:
+            got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+            assert kernel_id() == 3
+            assert np.array_equal(got, want), (alpha[:4], k, costs, np.flatnonzero(got != want)[:10])
