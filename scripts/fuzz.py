@@ -1,0 +1,111 @@
+"""Randomised parity run on a GPU box: random batches through every distance / search entry point against the CPU oracle.
+usage: python scripts/fuzz.py <minutes> [seed]   (not part of the test suite; prints the first mismatch and exits 1)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import datagen as Dg
+import oracle_lib as O
+import triple_accel_amd as T
+from triple_accel_amd import batch as B
+
+minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+g = np.random.default_rng(seed)
+print("seed", seed, flush=True)
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 0, None), (1, 2, 0, None), (3, 2, 1, 2), (2, 3, 2, None), (1, 1, 1, None), (5, 3, 0, 4), (2, 2, 1, 3), (255, 255, 0, None)]
+
+
+def rand_pairs(n, lo, hi, alpha, sim, edits):
+    a, b = [], []
+    for _ in range(n):
+        la = int(g.integers(lo, hi + 1))
+        x = g.integers(alpha[0], alpha[1], la, dtype=np.uint8).tobytes()
+        if g.random() < sim:
+            y = Dg.mutate(Dg.rng(int(g.integers(1 << 30))), x, int(g.integers(0, edits + 1)), True) if la else x
+        else:
+            y = g.integers(alpha[0], alpha[1], int(g.integers(lo, hi + 1)), dtype=np.uint8).tobytes()
+        a.append(x); b.append(y)
+    return a, b
+
+
+t_end, rounds, kinds = time.time() + 60 * minutes, 0, {}
+while time.time() < t_end:
+    rounds += 1
+    kind = int(g.integers(0, 6))
+    alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
+    costs = COSTS[int(g.integers(0, len(COSTS)))]
+    if not O.costs_valid(costs):
+        continue
+    try:
+        if kind in (0, 1):      # k-bounded batch, ragged or fixed, many geometries
+            n = int(g.choice([1, 7, 64, 500, 1500, 4000]))
+            hi = int(g.choice([8, 40, 130, 300, 700, 2500]))
+            lo = hi if kind == 1 else int(g.integers(0, hi + 1))
+            a, b = rand_pairs(n, lo, hi, alpha, 0.7, int(g.choice([2, 10, 40, 150])))
+            k = int(g.choice([0, 1, 3, 8, 20, 32, 33, 47, 64, 100, 127, 128, 300, 2000, 0xFFFFFFFF]))
+            if kind == 1 and all(len(x) == len(a[0]) for x in a) and all(len(y) == len(b[0]) for y in b) and len(a[0]) and len(b[0]):
+                fa = np.frombuffer(b"".join(a), dtype=np.uint8).reshape(n, -1); fb = np.frombuffer(b"".join(b), dtype=np.uint8).reshape(n, -1)
+                got = B.levenshtein_k_batch(B.Strings.from_fixed(fa), B.Strings.from_fixed(fb), k, costs).cpu().numpy().view(np.uint32)
+            else:
+                got = B.levenshtein_k_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs).cpu().numpy().view(np.uint32)
+            want = O.levenshtein_k_batch(O.csr_from_list(a), O.csr_from_list(b), k, costs)
+            ok = np.array_equal(got, want)
+            what = ("k_batch", n, lo, hi, k, costs, alpha, T.last_launch_info()["kernel"])
+        elif kind == 2:         # exp batch
+            n = int(g.choice([1, 30, 64, 300]))
+            hi = int(g.choice([20, 100, 400, 1200]))
+            a, b = rand_pairs(n, int(g.integers(0, hi + 1)), hi, alpha, 0.6, int(g.choice([3, 30, 200])))
+            got = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), costs).cpu().numpy().view(np.uint32)
+            want = O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), costs)
+            ok = np.array_equal(got, want)
+            what = ("exp_batch", n, hi, costs, alpha)
+        elif kind == 3:         # single calls incl. traceback
+            a, b = rand_pairs(1, 0, int(g.choice([10, 80, 300, 1500])), alpha, 0.8, 30)
+            x, y = a[0], b[0]
+            k = int(g.choice([0, 2, 10, 40, 200, 0xFFFFFFFF]))
+            tr = bool(g.integers(0, 2))
+            got = T.levenshtein_simd_k_with_opts(x, y, k, tr, T.EditCosts(*costs))
+            want = O.levenshtein_simd_k_with_opts(x, y, k, tr, costs)
+            ok = (got is None and want[0] is None) or (got is not None and want[0] is not None and got[0] == want[0] and (not tr or [tuple(e) for e in got[1]] == [tuple(e) for e in want[1]]))
+            what = ("single", len(x), len(y), k, tr, costs)
+        elif kind == 4:         # levenshtein search
+            if not O.costs_valid_search(costs):
+                continue
+            n = int(g.choice([1, 5, 17, 32, 60, 200]))
+            needle = g.integers(max(1, alpha[0]), alpha[1], n, dtype=np.uint8).tobytes()
+            k = int(g.integers(0, max(1, n // 2) + 2))
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, int(g.choice([500, 20000, 300000])), int(g.choice([50, 2000])), max(1, k))
+            st = int(g.integers(0, 2)); anch = bool(g.random() < 0.2)
+            got = [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, k, st, T.EditCosts(*costs), anch)]
+            want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, anch)
+            ok = got == want
+            what = ("search", n, k, st, anch, costs, len(hay))
+        else:                   # hamming + hamming search
+            n = int(g.choice([1, 9, 32, 33, 100, 700]))
+            needle = g.integers(1, 256, n, dtype=np.uint8).tobytes()
+            hay = bytearray(g.integers(1, 256, int(g.choice([n, 1000, 200000])), dtype=np.uint8).tobytes())
+            for pos in range(0, max(1, len(hay) - n), max(n + 3, 5000)):
+                m = bytearray(needle)
+                for _ in range(int(g.integers(0, 4))):
+                    m[int(g.integers(0, n))] = int(g.integers(1, 256))
+                hay[pos:pos + n] = m
+            hay = bytes(hay[: max(len(hay), n)])
+            k = int(g.integers(0, n // 2 + 2)); st = int(g.integers(0, 2))
+            got = [tuple(m) for m in T.hamming_search_simd_with_opts(needle, hay, k, st)]
+            want = O.hamming_search_naive_with_opts(needle, hay, k, st)
+            ok = got == want and T.hamming(needle, hay[:n]) == O.hamming_naive(needle, hay[:n])
+            what = ("hamming_search", n, k, st, len(hay))
+    except Exception as e:
+        print("EXCEPTION", kind, costs, alpha, repr(e)[:300], "last launch", T.last_launch_info(), flush=True)
+        import traceback; traceback.print_exc()
+        try:
+            print("params:", n, hi, lo if kind in (0, 1) else None, k if kind != 2 else None, flush=True)
+        except Exception:
+            pass
+        sys.exit(1)
+    kinds[what[0]] = kinds.get(what[0], 0) + 1
+    if not ok:
+        print("MISMATCH", what, flush=True)
+        sys.exit(1)
+print("fuzz ok:", rounds, "rounds", kinds, flush=True)

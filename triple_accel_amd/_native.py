@@ -72,6 +72,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("triple_accel_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` or `make -C triple_accel_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # PyTorch (device memory, streams) ships its own HIP runtime: let it bring the GPU up before this library makes its first
+    # HIP call -- the other way round torch reports "No HIP GPUs are available" on this stack.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     u8p, sz, u32, i32 = C.c_char_p, C.c_size_t, C.c_uint32, C.c_int
     cp, u32p = C.POINTER(EditCostsC), C.POINTER(C.c_uint32)
