@@ -174,6 +174,9 @@ struct EmuWave {
         for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &q.v[i], 16);
     }
     static U32 lds_u8(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = lds[off.v[i]]; return r; }
+    static U32 lds_read32u(const uint8_t *lds, const U32 &off) { return lds_read32(lds, off); }
+    template <int N>
+    static U32 splat_byte_n(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) * 0x01010101u; return r; }
     static U32 lds_read32(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], lds + off.v[i], 4); return r; }
     static void lds_write32(uint8_t *lds, const U32 &off, const U32 &v) { for (int i = 0; i < 64; i++) memcpy(lds + off.v[i], &v.v[i], 4); }
     static void lds_or32(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) {

@@ -71,3 +71,20 @@ def test_big_batch_tiny_strings():
     got = B.levenshtein_k_batch(sa, sb, 5, (1, 1, 0, 1)).cpu().numpy().view(np.uint32)
     want = O.levenshtein_k_batch((blob_a, off_a), (blob_b, off_b), 5, (1, 1, 0, 1))
     assert np.array_equal(got, want)
+
+
+def test_first_call_before_any_torch_use_in_a_fresh_process():
+    """A fresh interpreter whose FIRST GPU action is a single call of this package (torch untouched until then) must work,
+    and torch must still see the GPU afterwards (the loader brings torch's HIP runtime up first: _native.lib())."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import triple_accel_amd as T; "
+            "assert T.levenshtein(b'kitten', b'sitting') == 3; assert T.device_count() >= 1; "
+            "from triple_accel_amd import batch as B; import numpy as np, torch; "
+            "a = np.full((70, 40), 65, dtype=np.uint8); "
+            "out = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(a), 3).cpu().numpy(); "
+            "assert (out == 0).all() and torch.cuda.is_available(); print('fresh ok')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fresh ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -57,7 +57,8 @@ struct LevBits {
     // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
     template <bool CAP, int S = 0>
     static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
-        const U32 Bs = W::splat_byte(b_in);
+        // STATIC: b_in holds the four column characters of the group, sub-column S takes byte S
+        const U32 Bs = STATIC ? W::template splat_byte_n<S>(b_in) : W::splat_byte(b_in);
         U32 PM[NW], D0[NW], NE[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
@@ -215,11 +216,9 @@ struct LevBits {
 #pragma unroll
                         for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
                         const U32 pa = ra + tp;
-                        st.AW[NA - 1] = (W::lds_u8(lds, pa) | (W::lds_u8(lds, pa + 1u) << 8) | (W::lds_u8(lds, pa + 2u) << 16) |
-                                         (W::lds_u8(lds, pa + 3u) << 24)) ^ 0x0C0C0C0Cu;
+                        st.AW[NA - 1] = W::lds_read32u(lds, pa) ^ 0x0C0C0C0Cu;
                         if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
-                        const U32 pb = rb + tp;
-                        const U32 b0 = W::lds_u8(lds, pb), b1 = W::lds_u8(lds, pb + 1u), b2 = W::lds_u8(lds, pb + 2u), b3 = W::lds_u8(lds, pb + 3u);
+                        const U32 b0 = W::lds_read32u(lds, rb + tp), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
                         if (!cap) {
                             column<false, 0>(st, b0, M, cnt, active);
                             if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);

@@ -188,6 +188,14 @@ struct DevWave {
     static __device__ __forceinline__ U32 lds_u8(const uint8_t *lds, U32 off) { return lds[off]; }
     // lane-private dwords in LDS (4-byte aligned offsets)
     static __device__ __forceinline__ U32 lds_read32(const uint8_t *lds, U32 off) { return *(const uint32_t *)(lds + off); }
+    // a dword at ANY byte offset: one ds_read_b32 (gfx950 DS accesses need no alignment)
+    static __device__ __forceinline__ U32 lds_read32u(const uint8_t *lds, U32 off) {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        return *(const u32u *)(lds + off);
+    }
+    // byte N of x in all four bytes -> v_perm_b32
+    template <int N>
+    static __device__ __forceinline__ U32 splat_byte_n(U32 x) { return __builtin_amdgcn_perm(x, x, 0x04040404u + 0x01010101u * (uint32_t)N); }
     static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
     static __device__ __forceinline__ void lds_or32(uint8_t *lds, U32 off, U32 v, Bool pred) {   // ds_or_b32, no return
         if (pred) (void)__hip_atomic_fetch_or((uint32_t *)(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
