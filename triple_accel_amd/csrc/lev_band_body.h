@@ -95,10 +95,8 @@ struct LevBand {
             for (int w = 0; w < NW; w++) {
                 // b[j-2] and a[i-2] are exactly what the windows held before their last advance: no re-alignment needed
                 Z[w] = (st.AW[w] ^ st.BWp[w]) | (st.AWp[w] ^ st.BW[w]);
-                if (TRANS == 1) {   // 1 per cell whose transposition test FAILS (non-zero byte)
-                    U32 t = (Z[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-                    Z[w] = W::opaque((t | Z[w]) & 0x80808080u) >> 7;
-                }
+                if (TRANS == 1)     // 1 per cell whose transposition test FAILS (non-zero byte; W::ne12: one v_perm_b32 byte test)
+                    Z[w] = W::ne12(Z[w] ^ 0x0C0C0C0Cu) & 0x01010101u;
             }
         }
         // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
@@ -115,10 +113,8 @@ struct LevBand {
         // per byte: 1 where a != b, four cells per VGPR (SWAR); each cell's substitution cost is then ONE
         // v_dot4_u32_u8 with a one-hot byte of mismatch_cost: reg + flag_byte * mc
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            U32 t = (X[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu;      // bit 7 of each byte <- low 7 bits nonzero
-            X[w] = W::opaque((t | X[w]) & 0x80808080u) >> 7;  // 1 per nonzero byte (opaque: keep the and fused with the or)
-        }
+        for (int w = 0; w < NW; w++)                          // 1 per nonzero byte: x ^ 0x0C is 12 exactly where x is 0, and one
+            X[w] = W::ne12(X[w] ^ 0x0C0C0C0Cu) & 0x01010101u;  // v_perm_b32 with all-ones sources maps 12 to 0x00, the rest to 0xFF
         // all substitution candidates first: a v_dot4 result needs 3 wait states before another VALU may read it,
         // so the mins below must not directly follow their own dot4
         U32 subv[Dh];

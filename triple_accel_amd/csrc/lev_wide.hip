@@ -179,9 +179,9 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
                     uint32_t F4[WR / 4], Z4[TRANS ? WR / 4 : 1];
 #pragma unroll
                     for (int w = 0; w < WR / 4; w++) {
-                        uint32_t x = A4[w] ^ B4;
-                        uint32_t y = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-                        F4[w] = ((y | x) >> 7) & 0x01010101u;                          // 1 per mismatching row
+                        // 1 per mismatching row: the XOR plus 0x0C is 12 exactly where the bytes agree, and v_perm_b32 with all-ones
+                        // sources maps byte value 12 to 0x00 and every other one to 0xFF (wave.h, W::ne12)
+                        F4[w] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, A4[w] ^ B4 ^ 0x0C0C0C0Cu) & 0x01010101u;
                         if (TRANS) Z4[w] = (A4[w] ^ (bprev * 0x01010101u)) | (AU4[w] ^ B4);   // 0: a[i]==b[j-1] && a[i-1]==b[j]
                     }
                     uint32_t diag = up_dp_prev;          // dp(row0, j-1)
