@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the library honours its test / tuning switches (TA_FORCE_*, TA_NO_BITS, ...) only when TA_TUNING is set when it is loaded
+os.environ.setdefault("TA_TUNING", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

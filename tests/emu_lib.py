@@ -40,6 +40,8 @@ def lib():
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
                                      C.c_uint64, C.POINTER(C.c_uint64)]
+        L.emu_search_anchored_packed_ok.restype = C.c_int
+        L.emu_search_anchored_packed_ok.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emu_sliced_plan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
         L.emu_sliced_plan.restype = None
         _lib = L

@@ -70,3 +70,31 @@ def test_long_needles_memory_backed_column():
             want = oracle_all(needle, hay, k, costs)
             for tile in (1 << 30, 257):
                 assert E.lev_search_tiled(needle, hay, k, costs, tile=tile) == want, (n, k, tile, costs)
+
+
+def test_anchored_large_k_packed_gate():
+    """Anchored searches with a big k: row 0 costs (i+1)*gc + sg and may pass the packed form's "no gap yet" marker
+    (0x7000).  Wherever the host's gate (srch_anchored_packed_ok) admits the packed form it must equal the oracle; the
+    32+32-bit form must equal it everywhere.  (Round-1 advisor finding: needle "a", 30001 x 'b', k = 30000 under-reported.)"""
+    cases = [(b"a", b"b" * 30001, 30000, (1, 1, 0, None)), (b"a", b"b" * 28000, 27000, (1, 1, 0, None)),
+             (b"ab", b"b" * 200, 25000, (255, 255, 0, None)), (b"abc", b"c" * 150, 30000, (200, 255, 3, None)),
+             (b"ab", b"b" * 120, 20000, (1, 200, 100, 2)), (b"abcd", b"xbcd" + b"q" * 100, 22000, (120, 250, 5, None))]
+    admitted = 0
+    for needle, hay, k, costs in cases:
+        mc, gc, sg, tc = costs
+        want = oracle_all(needle, hay, k, costs, anchored=True)
+        assert E.lev_search_tiled(needle, hay, k, costs, anchored=True, packed=False) == want, (needle, k, costs)
+        for cut in (len(hay), len(hay) // 2, 60, 20):
+            sub = hay[:cut]
+            h = min(len(sub), len(needle) + max(0, k - sg) // gc)
+            if E.lib().emu_search_anchored_packed_ok(h, len(needle), mc, gc, sg):
+                admitted += 1
+                assert E.lev_search_tiled(needle, sub, k, costs, anchored=True, packed=True) == \
+                    oracle_all(needle, sub, k, costs, anchored=True), (needle, cut, k, costs)
+    assert admitted >= 6
+    # the boundary itself: the longest haystack the gate admits for unit costs, and one column more (refused)
+    needle, costs = b"a", (1, 1, 0, None)
+    hmax = max(h for h in range(28000, 29000) if E.lib().emu_search_anchored_packed_ok(h, 1, 1, 1, 0))
+    assert not E.lib().emu_search_anchored_packed_ok(hmax + 1, 1, 1, 1, 0)
+    hay = b"b" * hmax
+    assert E.lev_search_tiled(needle, hay, 30000, costs, anchored=True, packed=True) == oracle_all(needle, hay, 30000, costs, anchored=True)

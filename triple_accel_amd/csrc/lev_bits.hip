@@ -4,6 +4,7 @@
 
 #include "lev_bits_body.h"
 #include "lev_plan.h"
+#include "ta_internal.h"
 
 namespace ta {
 
@@ -45,7 +46,7 @@ hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans
     // strings).  TA_BITS_BLOCK_LDS overrides.
     size_t lds = (size_t)pl.lds_per_wave * wpb;
     if (wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
-    if (const char *e = getenv("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
+    if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;

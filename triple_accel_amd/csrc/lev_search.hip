@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void hamming_search_sa_kernel(SearchParams P) 
 hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s) {
     SearchParams P = P0;
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
-    if (P.needle_len <= 32 && !getenv("TA_HAMMING_SEARCH_SWAR")) {
+    if (P.needle_len <= 32 && !env_str("TA_HAMMING_SEARCH_SWAR")) {
         const uint64_t offsets = P.hay_len - P.needle_len + 1;
         uint64_t tile = (offsets + 262143) / 262144;              // two sets of resident lanes
         if (tile < 8ull * P.needle_len) tile = 8ull * P.needle_len;

@@ -17,6 +17,16 @@
 namespace ta {
 
 constexpr uint32_t SRCH_INF = 0x3FFFFFFFu;
+// "no gap yet" cost of the packed form (lev_search_tile_packed): every real cost must stay below it (the host checks)
+constexpr uint32_t SRCH_PACKED_KINF = 0x7000u;
+// Anchored searches (src/levenshtein.rs:1650-1658, :1710-1719): row 0 costs (i+1)*gc + sg, so every cell is bounded by row 0
+// at the last column plus a whole needle of gaps / mismatches.  The packed form may only run while that bound stays below
+// KINF -- otherwise its continuation KINF + gc would beat a real (larger) candidate.  h = columns the search visits.
+static inline bool srch_anchored_packed_ok(uint64_t h, uint32_t needle_len, uint32_t mc, uint32_t gc, uint32_t sg) {
+    const uint64_t wc = mc > gc ? mc : gc;
+    const uint64_t top = (h + 1) * gc + 2ull * sg + ((uint64_t)needle_len + 1) * wc + gc;
+    return top < SRCH_PACKED_KINF;
+}
 
 struct SearchCosts {
     uint32_t k, mc, gc, sg, tc;
@@ -112,7 +122,7 @@ TA_HD inline void lev_search_tile_packed(const uint8_t *hay, const uint8_t *need
     const uint32_t SGC = (C.sg + C.gc) << 16, GC = C.gc << 16;
     const uint32_t SUB_MIS = (C.mc << 16) - 1u, SUB_EQ = 0xFFFFFFFFu;   // (+mc, length+1) and (+0, length+1)
     const uint32_t TCK = (C.tc << 16) - 2u;                              // (+tc, length+2)
-    constexpr uint32_t KINF = (0x7000u << 16) | 0xFFFFu;
+    constexpr uint32_t KINF = (SRCH_PACKED_KINF << 16) | 0xFFFFu;
 #pragma unroll
     for (int j = 0; j <= N; j++) {
         dp1[j] = (((uint32_t)j * C.gc + (j == 0 ? 0u : C.sg)) << 16) | 0xFFFFu;

@@ -25,7 +25,7 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t per_cu = nwl == 2 ? 14u : 28u;           // 160 KB of LDS per CU / table bytes
     uint32_t resident = (uint32_t)cus * per_cu;
-    if (const char *e = getenv("TA_WB_WAVES_PER_CU")) { int v = atoi(e); if (v > 0) resident = (uint32_t)cus * (uint32_t)v; }
+    if (const char *e = env_str("TA_WB_WAVES_PER_CU")) { int v = atoi(e); if (v > 0) resident = (uint32_t)cus * (uint32_t)v; }
     uint32_t grid = P.n < resident ? P.n : resident;
     P.bnd = nullptr; P.bnd_line = 0;
     if (max_len > 64ull * (uint64_t)rows_per_lane) {
@@ -77,7 +77,7 @@ static hipError_t huge_launch_t(const uint8_t *ap, const uint8_t *bp, uint32_t n
     uint64_t cb = ((uint64_t)m / 16 + 63) & ~(uint64_t)63;         // ~16 tiles per stripe, 1024..8192 steps each
     if (cb < 1024) cb = 1024;
     if (cb > 8192) cb = 8192;
-    if (const char *e = getenv("TA_WB_TILE_STEPS")) { long v = atol(e); if (v >= 64) cb = (uint64_t)v & ~(uint64_t)63; }
+    if (const char *e = env_str("TA_WB_TILE_STEPS")) { long v = atol(e); if (v >= 64) cb = (uint64_t)v & ~(uint64_t)63; }
     H.CB = (uint32_t)cb;
     H.line = (uint64_t)m + 66;
     Scratch &ls = tls_scratch(6), &ss = tls_scratch(8);    // (slots 4 and 5 hold the exp loop's subsets while this runs)

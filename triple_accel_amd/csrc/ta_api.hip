@@ -49,8 +49,13 @@ Scratch &tls_scratch(int which) {
     return s[which];
 }
 
-static inline int env_int(const char *name) {
-    const char *v = getenv(name);
+// Test / tuning switches.  They are honoured only when TA_TUNING was set in the environment when the
+// library was loaded: a production process reads the environment exactly once (here) and never on the call path.
+static const bool g_tuning = getenv("TA_TUNING") != nullptr;
+bool tuning_enabled() { return g_tuning; }
+const char *env_str(const char *name) { return g_tuning ? getenv(name) : nullptr; }
+int env_int(const char *name) {
+    const char *v = env_str(name);
     return v ? atoi(v) : 0;
 }
 

@@ -31,6 +31,11 @@ struct Scratch {
 };
 Scratch &tls_scratch(int which);
 
+// test / tuning switches: nullptr / 0 unless TA_TUNING was set when the library was loaded (no getenv on the call path)
+bool tuning_enabled();
+const char *env_str(const char *name);
+int env_int(const char *name);
+
 // true when a HIP device is usable (lazy, cached)
 bool device_ready();
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "lev_filter_body.h"
+#include "lev_search_body.h"
 #include "ta_internal.h"
 
 namespace ta {
@@ -25,7 +26,7 @@ static bool search_costs_ok(const ta_edit_costs *c) {
 
 // tile size: enough tiles to fill the chip (>= ~128K lanes) while keeping the halo overhead small
 static uint32_t pick_tile(uint64_t hay_len, uint32_t halo) {
-    if (const char *e = getenv("TA_SEARCH_TILE")) { long v = atol(e); if (v > 0) return (uint32_t)v; }
+    if (const char *e = env_str("TA_SEARCH_TILE")) { long v = atol(e); if (v > 0) return (uint32_t)v; }
     uint64_t t = (hay_len + 524287) / 524288;          // ~2 full sets of resident lanes (256 CUs x 32 waves x 64)
     uint64_t lo = (uint64_t)halo * 2;
     if (t < lo) t = lo;
@@ -104,15 +105,17 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         P.col_scratch = (uint32_t *)cs.dev;
     }
     // packed cost/length kernel whenever every cost and length provably fits 16 bits
-    bool packed = needle_len <= 32 && k <= 30000u && (uint64_t)P.tile + P.halo <= 60000u && !getenv("TA_SEARCH_UNPACKED");
-    if (anchored) packed = needle_len <= 32 && k <= 30000u && h <= 60000u && !getenv("TA_SEARCH_UNPACKED");
+    bool packed = needle_len <= 32 && k <= 30000u && (uint64_t)P.tile + P.halo <= 60000u && !env_str("TA_SEARCH_UNPACKED");
+    if (anchored)           // every cost must stay below the packed form's "no gap yet" marker (lev_search_body.h)
+        packed = needle_len <= 32 && k <= 30000u && h <= 60000u && !env_str("TA_SEARCH_UNPACKED") &&
+                 srch_anchored_packed_ok(h, (uint32_t)needle_len, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost);
     // Unit-cost families with a short needle: a bit-parallel scan (lev_filter_body.h) finds the 64-column blocks that hold
     // a cost <= k, and only those go through the exact kernel.  With k >= needle_len every position matches: skip it.
     const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 &&
                       (!costs->has_transpose || costs->transpose_cost == 1);
     bool filtered = false;
     const bool exact_ok = needle_len <= 32 ? packed : true;           // the block-list form exists for the packed and the memory-backed kernel
-    if (unit && !anchored && exact_ok && needle_len <= 256 && k < needle_len && h >= 4096 && !getenv("TA_SEARCH_NOFILTER")) {
+    if (unit && !anchored && exact_ok && needle_len <= 256 && k < needle_len && h >= 4096 && !env_str("TA_SEARCH_NOFILTER")) {
         Scratch &ls = tls_scratch(5), &lc = tls_scratch(4);
         uint64_t cap_list = h / FILTER_BLOCK + 2;
         if (cap_list > (4u << 20)) cap_list = 4u << 20;
@@ -122,7 +125,7 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         uint64_t ft = (h + 131071) / 131072;                          // one set of resident lanes (256 CUs x 8 waves x 64)
         if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
         ft = (ft + FILTER_BLOCK - 1) / FILTER_BLOCK * FILTER_BLOCK;
-        if (const char *e = getenv("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
+        if (const char *e = env_str("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
         F.tile = (uint32_t)(ft > 0x7FFFFFC0ull ? 0x7FFFFFC0ull : ft);
         TA_HIP(lev_filter_launch(F, costs->has_transpose != 0, (uint32_t *)ls.dev, (uint32_t)cap_list, (unsigned int *)lc.dev, st));
         unsigned int n_list = 0;
