@@ -6,15 +6,24 @@ Default workload = BASELINE.json configs[1] (cfg2): levenshtein_simd_k, k = 32, 
 LEVENSHTEIN_COSTS -- the configuration the metric is quoted on.  The other configs are parity-test cases;
 they can be timed with --workload for DESIGN.md but are not the bench line.
 
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank processes its own batch
-(independent units: weak scaling, no data-path collective); rank 0 prints ONE JSON line carrying
-`roofline` (HBM: algorithmic bytes / measured kernel time) and `cpu_baseline` (the CPU oracle on a bounded
-sample, all host cores: the anti-diagonal vectorised restatement for cfg2/cfg4 with the scalar figure beside
-it, the scalar restatement elsewhere).
+Multi-GPU: `python bench.py --gpus N` launches itself as N ranks (one process per GPU, torch.distributed.run, RCCL) when
+it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the
+ranks it is given.  The units are independent, so the data path has no collective:
+  * --scaling weak (default, the `value` of the line): every rank its own batch of the configured size;
+  * --scaling strong: the SAME batch partitioned over the ranks (dist.shard_range); at N > 1 the weak line carries this
+    figure too, as `strong_scaling`, measured in the same run;
+  * cfg5: the ranks' resident shards are ONE haystack (dist.levenshtein_search_sharded: halo tails all-gathered on the
+    device, shard searched in place, match lists gathered -- the path's one real exchange step).
+Rank 0 prints ONE JSON line carrying `roofline` (HBM: algorithmic bytes / measured kernel time, plus the VALU-issue
+roofline of this integer path against both the guide's 2-cycle ceiling and the opcode-mix ceiling) and `cpu_baseline`
+(the CPU oracle on a bounded sample: the hand-written AVX2 u8 anti-diagonal restatement for cfg2/cfg4 with the other
+restatements and a thread-scaling line beside it, the scalar restatement elsewhere).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +34,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+PROFILE_ROUND = "r02"
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -35,23 +45,77 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
     ap.add_argument("--dist", default="random", choices=["random", "mutated"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: become N ranks (one per GPU) under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")                 # the ranks do no host-parallel work (cpu_baseline runs at N = 1 only)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def host_cpu_facts():
+    """What the host really offers the CPU baseline: nproc, affinity, cgroup quota, OpenMP environment."""
+    facts = {"nproc": os.cpu_count()}
+    try:
+        facts["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        facts["affinity"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                quota = None if q < 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    facts["cgroup_cpus"] = quota
+    facts["omp"] = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "GOMP_CPU_AFFINITY")}
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        facts["model"] = model[0] if model else None
+    except Exception:
+        facts["model"] = None
+    return facts
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import datagen as Dg
     import oracle_lib as O
     import triple_accel_amd as T
     from triple_accel_amd import batch as B
+    from triple_accel_amd import dist as TD
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
-    local = local % torch.cuda.device_count()          # (lets a 1-GPU box dry-run the multi-rank control flow)
+    ndev = torch.cuda.device_count()
+    # RCCL needs one GPU per rank; on a box with fewer GPUs than ranks (a 1-GPU dry run of the multi-rank control flow) the
+    # ranks share devices and the tiny control-plane collectives go over gloo
+    backend = os.environ.get("TA_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+    local = local % ndev
     torch.cuda.set_device(local)
     dist = None
-    backend = os.environ.get("TA_BENCH_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; "gloo" only for dry runs
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -61,150 +125,218 @@ def main():
 
     wl = args.workload
     evaluated_unit = None
-    seed = 0x7A00 + int(wl[3:]) + 1000 * rank
     cores = O.max_threads()
     LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+    strong = args.scaling == "strong"
 
     # ------------------------------------------------------------------ workload set-up
+    # make(seed, lo, hi) -> (run, units, parity, extra): one rank's share of a batch
     if wl in ("cfg2", "cfg4", "cfg3", "cfg1"):
-        n, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
-                          "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM)}[wl]
-        n = args.pairs or n
-        if args.dist == "random":
-            a, b = Dg.pairs_random(seed, n, L)
-        else:
-            g = Dg.rng(seed)
-            a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
-            b = a.copy()
-            kk = k or 64
-            pos = g.integers(0, L, size=(n, max(1, kk // 2)))
-            b[np.arange(n)[:, None], pos] = 32
-        sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
-        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        n_cfg, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
+                              "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM)}[wl]
+        n_cfg = args.pairs or n_cfg
         bytes_unit = 2 * L + 4
         if wl == "cfg1":
             cells_unit = L
-            run = lambda: B.hamming_batch(sa, sb, out=out)
-            oracle = lambda lo, hi, th: O.hamming_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), threads=th)
             desc, unit_name, dtype = "hamming() on 10K random 1KiB pairs (GPU batch kernel)", "byte pairs", "u8"
-            cpu_sample = n
         elif wl == "cfg3":
             cells_unit = L * L                                     # the answer's work: the full matrix
-            run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
-            oracle = lambda lo, hi, th: O.levenshtein_exp_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), costs, threads=th)
             desc, unit_name, dtype = "levenshtein_exp full distance on 100K random 4KiB pairs", "pairs", "u32"
-            cpu_sample = max(cores, 64)
         else:
             cells_unit = O.band_cells(L, L, k, costs)              # cells the scalar banded path visits
-            run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out)
-            oracle = lambda lo, hi, th: O.levenshtein_k_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), k, costs, threads=th)
             desc = {"cfg2": "levenshtein_simd_k k=32, 1M random 256B pairs, u8 cells",
                     "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)"}[wl]
-            unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select), arithmetic in 32-bit VGPR lanes
-            cpu_sample = min(n, 20000 * max(1, cores // 2))
+            unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select); the kernel computes on 1-bit cells in u32 lanes
             # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
-            #  -- about half of the credited reference band; reported for transparency, never credited
+            #  -- about half of the credited reference band; reported beside the credited figure
             uk = min((min(k, L * max(costs[0], costs[1])) - costs[2]) // costs[1], 2 * L)
             evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
-        units = n
 
-        def parity():
-            run(); torch.cuda.synchronize()
-            ns = min(n, 4000 if wl != "cfg3" else 48)
-            got = out[:ns].cpu().numpy().view(np.uint32)
-            assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
-            return ns
+        def gen(seed, n):
+            if args.dist == "random":
+                return Dg.pairs_random(seed, n, L)
+            g = Dg.rng(seed)
+            a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
+            b = a.copy()
+            pos = g.integers(0, L, size=(n, max(1, (k or 64) // 2)))
+            b[np.arange(n)[:, None], pos] = 32
+            return a, b
+
+        def make(share_of_common_batch):
+            """One rank's pairs: its own batch (weak) or its contiguous share of the common one (strong)."""
+            if share_of_common_batch:
+                a, b = gen(0x7A00 + int(wl[3:]), n_cfg)
+                lo, hi = TD.shard_range(n_cfg, rank, world)
+                a, b = a[lo:hi], b[lo:hi]
+            else:
+                a, b = gen(0x7A00 + int(wl[3:]) + 1000 * rank, n_cfg)
+            n = a.shape[0]
+            sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+            out = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
+            if wl == "cfg1":
+                run = lambda: B.hamming_batch(sa, sb, out=out)
+                oracle = lambda lo, hi, th: O.hamming_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), threads=th)
+            elif wl == "cfg3":
+                run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
+                oracle = lambda lo, hi, th: O.levenshtein_exp_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), costs, threads=th)
+            else:
+                run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out)
+                oracle = lambda lo, hi, th: O.levenshtein_k_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), k, costs, threads=th)
+            if n == 0:
+                run = lambda: None
+
+            def parity():
+                run(); torch.cuda.synchronize()
+                ns = min(n, 4000 if wl != "cfg3" else 48)
+                got = out[:ns].cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
+                return ns
+            return run, n, parity, {"a": a, "b": b, "oracle": oracle}
     else:   # cfg5: levenshtein_search, 32 B needle over a 1 GiB random shard per GPU
         mib = args.pairs or 1024
-        g = Dg.rng(seed)
         needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()     # same needle on every rank
-        hay_np = Dg.random_bytes(g, mib << 20)
-        for pos in range(1 << 16, hay_np.size - 100, 1 << 20):     # ~1 planted mutated copy per MiB
-            mm = np.frombuffer(Dg.mutate(g, needle, 10), dtype=np.uint8)
-            hay_np[pos:pos + mm.size] = mm
-        hay = B.haystack_tensor(hay_np)
         k, costs = 16, LEV
-        cells_unit, bytes_unit, units = 32, 1, hay_np.size         # per haystack byte: 32 cells, 1 byte read
-        holder = {}
-        from triple_accel_amd import dist as TD
-
-        def run():
-            hits = B.levenshtein_search_best_dev(needle, hay, k, costs)            # kernels + on-device selection of the best-k hits
-            holder["best"] = TD.fold_best(hits, k, True)                           # the sequential Best pass (host)
+        cells_unit, bytes_unit = 32, 1                              # per haystack byte: 32 cells, 1 byte read
         desc = "levenshtein_search 32B needle over a %d MiB random haystack shard per GPU, k=16, Best" % mib
         unit_name, dtype = "haystack bytes", "u16+u16 (cost|length packed in a u32 lane)"
-        cpu_sample = 8 << 20
 
-        def oracle_search(lo, hi, th):
-            return O.levenshtein_search_naive_with_opts(needle, hay_np[lo:hi].tobytes(), k, O.BEST, costs, False)
+        def make(share_of_common_batch):
+            size = mib << 20
+            if share_of_common_batch:                               # strong: one `mib` haystack cut into `world` shards
+                lo, hi = TD.shard_range(size, rank, world)
+                size = hi - lo
+            g = Dg.rng(0x7A05 + 1000 * rank)
+            hay_np = Dg.random_bytes(g, size)
+            for pos in range(1 << 16, hay_np.size - 100, 1 << 20):     # ~1 planted mutated copy per MiB
+                mm = np.frombuffer(Dg.mutate(g, needle, 10), dtype=np.uint8)
+                hay_np[pos:pos + mm.size] = mm
+            hay = B.haystack_tensor(hay_np)                         # resident in HBM from here on
+            holder = {}
+            if world == 1:
+                def run():
+                    hits = B.levenshtein_search_best_dev(needle, hay, k, costs)        # kernels + on-device selection of the best-k hits
+                    holder["best"] = TD.fold_best(hits, k, True)                       # the sequential Best pass (host)
+            else:
+                def run():                                          # the ranks' shards are one haystack: halo exchange + gather
+                    holder["best"] = TD.levenshtein_search_sharded(needle, hay, k, T.SearchType.Best, T.EditCosts(*costs))
 
-        def parity():
-            run(); torch.cuda.synchronize()
-            ns = min(hay_np.size, 4 << 20)
-            want = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), k, O.ALL, costs, False)
-            allhits = B.levenshtein_search_dev(needle, hay, k, costs)              # All-mode hits of the whole shard
-            got = [tuple(int(v) for v in r) for r in allhits if r[1] <= ns]
-            assert got == [w for w in want if w[1] > 0], "parity gate failed: HIP search != oracle"
-            assert holder["best"] == TD.fold_best(allhits, k, True), "parity gate failed: on-device Best selection != fold over all hits"
-            return ns
+            def parity():
+                run(); torch.cuda.synchronize()
+                ns = min(hay_np.size, 4 << 20)
+                want = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), k, O.ALL, costs, False)
+                allhits = B.levenshtein_search_dev(needle, hay, k, costs)              # All-mode hits of this rank's shard
+                got = [tuple(int(v) for v in r) for r in allhits if r[1] <= ns]
+                assert got == [w for w in want if w[1] > 0], "parity gate failed: HIP search != oracle"
+                if world == 1:
+                    assert holder["best"] == TD.fold_best(allhits, k, True), "parity gate failed: on-device Best selection != fold over all hits"
+                else:          # every rank must hold the same answer (the sharded search itself is compared with the monolithic
+                    # oracle across shard cuts in tests/test_gpu_dist.py and tests/test_dist_cpu.py)
+                    mine = torch.tensor([hash(tuple(tuple(int(v) for v in m) for m in holder["best"])) & 0x7FFFFFFF], dtype=torch.int64)
+                    mine = mine.cuda() if backend == "nccl" else mine
+                    allv = [torch.zeros_like(mine) for _ in range(world)]
+                    dist.all_gather(allv, mine)
+                    assert len({int(v[0].item()) for v in allv}) == 1, "sharded search: ranks disagree"
+                return ns
+            return run, hay_np.size, parity, {"hay_np": hay_np}
 
-    # ------------------------------------------------------------------ parity gate, warm-up, timed region
-    parity_n = parity()
-    info = T.last_launch_info()
-
+    # ------------------------------------------------------------------ timing helpers
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        run()
-        ev[i + 1].record()                                # same stream as the kernel launches
-    barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_region(run, steps, warmup):
+        """W untimed warm-ups, then EXACTLY `steps` passes between barrier + synchronize; max over ranks.
+        -> (wall seconds, mean device ms per pass from HIP events on the launch stream)"""
+        for _ in range(warmup):
+            run()
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            run()
+            ev[i + 1].record()                                # same stream as the kernel launches
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dev_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]))
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, dev_ms
+
+    def total_units(units):
+        if world == 1:
+            return units
+        tt = torch.tensor([units], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt)
+        return int(tt.item())
+
+    # ------------------------------------------------------------------ parity gate, warm-up, timed region
+    run, units, parity, extra = make(strong and world > 1)
+    parity_n = parity()
+    info = T.last_launch_info()
+    elapsed, dev_ms = timed_region(run, args.steps, args.warmup)
+    all_units = total_units(units)
+
+    strong_fig = None
+    if world > 1 and not strong:        # the second figure of a multi-rank weak run: the same batch partitioned over the ranks
+        del run, parity, extra
+        torch.cuda.empty_cache()
+        run_s, units_s, parity_s, _ = make(True)
+        parity_s()
+        el_s, dev_s_ms = timed_region(run_s, args.steps, args.warmup)
+        tot_s = total_units(units_s)
+        if rank == 0:
+            strong_fig = {"value": cells_unit * tot_s * args.steps / el_s / 1e9, "unit": "GCUPS", "ms_per_step": el_s / args.steps * 1e3,
+                          "units_total": tot_s, "units_this_rank": units_s, "device_ms_per_pass": dev_s_ms}
+        extra = {}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    value = cells_unit * units * args.steps * world / elapsed / 1e9
-    dev_s = float(np.mean(step_ms)) / 1e3                 # device time of one pass (HIP events on the launch stream)
+    value = cells_unit * all_units * args.steps / elapsed / 1e9
+    dev_s = dev_ms / 1e3                                   # device time of one pass (HIP events on the launch stream)
     achieved = bytes_unit * units / dev_s / 1e9
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get(wl, {}).get("bytes_per_launch")
-        except Exception:
-            traffic = None
 
-    # the companion roofline of this integer path: VALU issue (one instruction per SIMD per 4 cycles), from the committed
-    # counter passes of the same command (profiles/r01/bench_cfg2_pmc.json); None when no profile is present
-    valu_issue = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "bench_%s_pmc.json" % wl)
-    if os.path.exists(pmc):
+    # committed counter passes of the same command (profiles/<round>/): HBM-side traffic and the VALU-issue roofline
+    def load_json(*parts):
+        p = os.path.join(ROOT, "profiles", *parts)
         try:
-            c = json.load(open(pmc))
-            insts, busy = c["SQ_INSTS_VALU"]["mean_per_launch"], c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+            return json.load(open(p))
+        except Exception:
+            return None
+    traffic = None
+    tj = load_json(PROFILE_ROUND, "hbm_traffic.json") or load_json("hbm_traffic.json")
+    if tj:
+        traffic = tj.get(wl, {}).get("bytes_per_launch")
+    valu_issue = None
+    pmc = load_json(PROFILE_ROUND, "bench_%s_pmc.json" % wl)
+    if pmc:
+        try:
+            insts, busy = pmc["SQ_INSTS_VALU"]["mean_per_launch"], pmc["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+            cyc_per_inst = 1024.0 * busy / insts
             valu_issue = {"valu_insts_per_launch": insts, "busy_cycles_per_xcd": busy, "simds": 1024,
-                          "frac": insts * 4.0 / (1024.0 * busy), "source": "profiles/r01/bench_%s_pmc.json" % wl}
+                          "cycles_per_valu_inst_per_simd": cyc_per_inst,
+                          # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 -> the hard ceiling
+                          "frac_of_2cycle_ceiling": 2.0 / cyc_per_inst,
+                          "source": "profiles/%s/bench_%s_pmc.json" % (PROFILE_ROUND, wl)}
+            mix = load_json(PROFILE_ROUND, "isa_mix.json")
+            if mix and wl in mix:                          # opcode histogram of the inner loop x measured per-class issue cost
+                m = mix[wl]
+                valu_issue["mix_cycles_per_valu_inst"] = m["modelled_cycles_per_valu_inst"]
+                valu_issue["frac_of_mix_ceiling"] = m["modelled_cycles_per_valu_inst"] / cyc_per_inst
+                valu_issue["mix_source"] = "profiles/%s/isa_mix.json (%s)" % (PROFILE_ROUND, m.get("kernel", ""))
         except Exception:
             valu_issue = None
 
     cpu = None
     if not args.no_cpu and world == 1:        # the CPU leg runs at N = 1 only (rank 0)
-        def timed(fn, min_s=4.0, max_reps=64):
+        facts = host_cpu_facts()
+
+        def timed(fn, min_s=3.0, max_reps=64):
             """fn() repeatedly until min_s has passed -> (seconds per call, calls)"""
             fn()                                                        # page in, spin the OpenMP team up
             t, reps = time.perf_counter(), 0
@@ -214,54 +346,92 @@ def main():
                 if dt >= min_s or reps >= max_reps:
                     return dt / reps, reps
         if wl == "cfg5":
+            hay_np = extra["hay_np"]
+            cpu_sample = min(8 << 20, hay_np.size)
             t1 = time.perf_counter()
-            oracle_search(0, cpu_sample, cores)
+            O.levenshtein_search_naive_with_opts(needle, hay_np[:cpu_sample].tobytes(), k, O.BEST, costs, False)
             dt = time.perf_counter() - t1
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread (the scalar search is one serial scan), oracle/ta_oracle.c "
-                             "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt)}
+                             "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt), "host": facts}
         elif wl in ("cfg2", "cfg4"):
-            # inputs staged once (CSR blobs), outside the timed loops; three figures: the scalar restatement on all host
-            # threads, the anti-diagonal compiler-vectorised restatement (oracle/ta_oracle_simd.c: u16 cells, AVX2 when the
-            # host has it -- the shape of the reference's own SIMD core) on all host threads and on one thread.  `value` is
-            # the best all-thread figure.
-            ns = min(n, 1_000_000)
+            # Inputs staged once (CSR blobs), outside the timed loops.  Three restatements: the hand-written AVX2 one with
+            # saturating u8 cells (oracle/ta_oracle_avx2.c: 64 / 32 u8 lanes per anti-diagonal for cfg2 / cfg4 -- the reference's
+            # own Avx2x32x8 / Avx1x32x8 classes), the compiler-vectorised u16 anti-diagonal one (ta_oracle_simd.c) and the scalar
+            # one (ta_oracle.c).  `value` is the best all-thread figure; `cores` the EFFECTIVE parallelism it reached
+            # (all-thread rate / one-thread rate), with the thread-scaling line that shows where it saturates.
+            a, b = extra["a"], extra["b"]
+            ns = min(units, 1_000_000)
             ca, cb = O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns])
             n1 = min(ns, 20_000)
             c1a, c1b = O.csr_from_fixed(a[:n1]), O.csr_from_fixed(b[:n1])
             ref = O.levenshtein_k_batch(c1a, c1b, k, costs, threads=cores)
+            variants = [("scalar u32 (oracle/ta_oracle.c)", O.levenshtein_k_batch)]
             got = O.levenshtein_k_batch_antidiag(c1a, c1b, k, costs, threads=cores)
-            assert got is not None and np.array_equal(got, ref), "the two CPU restatements differ"
-            s_sc, r_sc = timed(lambda: O.levenshtein_k_batch(ca, cb, k, costs, threads=cores))
-            s_ad, r_ad = timed(lambda: O.levenshtein_k_batch_antidiag(ca, cb, k, costs, threads=cores))
-            s_a1, r_a1 = timed(lambda: O.levenshtein_k_batch_antidiag(c1a, c1b, k, costs, threads=1), min_s=2.0)
-            s_s1, r_s1 = timed(lambda: O.levenshtein_k_batch(c1a, c1b, k, costs, threads=1), min_s=2.0, max_reps=4)
-            gcups = lambda units, sec: cells_unit * units / sec / 1e9
-            v_sc, v_ad = gcups(ns, s_sc), gcups(ns, s_ad)
-            cpu = {"value": max(v_sc, v_ad), "unit": "GCUPS", "cores": cores, "kind": "port",
-                   "sample": "%d pairs of the same batch staged once, %d OpenMP threads, repeated for >= 4 s per variant "
-                             "(%d / %d passes): anti-diagonal compiler-vectorised restatement (oracle/ta_oracle_simd.c) %.1f GCUPS, "
-                             "scalar restatement (oracle/ta_oracle.c) %.1f GCUPS; one thread on %d pairs: %.2f / %.2f GCUPS"
-                             % (ns, cores, r_ad, r_sc, v_ad, v_sc, n1, gcups(n1, s_a1), gcups(n1, s_s1)),
-                   "antidiag_value": v_ad, "scalar_value": v_sc,
-                   "antidiag_one_thread": gcups(n1, s_a1), "scalar_one_thread": gcups(n1, s_s1)}
+            assert got is not None and np.array_equal(got, ref), "the CPU restatements differ (u16 anti-diagonal)"
+            variants.append(("anti-diagonal u16, compiler-vectorised (oracle/ta_oracle_simd.c)", O.levenshtein_k_batch_antidiag))
+            have_u8 = O.have_avx2()
+            if have_u8:
+                got, hist = O.levenshtein_k_batch_ladder(c1a, c1b, k, costs, threads=cores, hist=True)
+                assert np.array_equal(got, ref), "the CPU restatements differ (AVX2 u8 anti-diagonal)"
+                lanes = [0, 32, 64, 128, 256, -1][int(np.argmax(hist))]
+                variants.append(("anti-diagonal AVX2, %d saturating u8 lanes (oracle/ta_oracle_avx2.c)" % lanes, O.levenshtein_k_batch_ladder))
+            gcups = lambda nu, sec: cells_unit * nu / sec / 1e9
+            res = {}
+            for name, fn in variants:
+                s_all, _ = timed(lambda: fn(ca, cb, k, costs, threads=cores), min_s=2.5)
+                s_one, _ = timed(lambda: fn(c1a, c1b, k, costs, threads=1), min_s=1.0, max_reps=4)
+                res[name] = (gcups(ns, s_all), gcups(n1, s_one))
+            best = max(res, key=lambda nm: res[nm][0])
+            fn_best = dict(variants)[best]
+            scaling_line = []
+            th = 1
+            while th < cores:
+                s_t, _ = timed(lambda: fn_best(ca, cb, k, costs, threads=th), min_s=0.8, max_reps=3)
+                scaling_line.append((th, round(gcups(ns, s_t), 2)))
+                th *= 2
+            scaling_line.append((cores, round(res[best][0], 2)))
+            eff = res[best][0] / res[best][1]
+            cpu = {"value": res[best][0], "unit": "GCUPS", "cores": round(eff, 1), "kind": "port",
+                   "sample": "%d pairs of the same batch staged once; best variant: %s, %.1f GCUPS on %d OpenMP threads = %.1fx its "
+                             "one-thread rate of %.2f GCUPS (effective cores; the host offers nproc %s, affinity %s, cgroup quota %s); "
+                             "each variant repeated for >= 2.5 s"
+                             % (ns, best, res[best][0], cores, eff, res[best][1], facts["nproc"], facts["affinity"], facts["cgroup_cpus"]),
+                   "threads_used": cores, "host": facts,
+                   "variants_gcups_all_threads_and_one_thread": {nm: [round(v[0], 2), round(v[1], 3)] for nm, v in res.items()},
+                   "thread_scaling_gcups": scaling_line}
         else:
+            oracle = extra["oracle"]
+            cpu_sample = units if wl == "cfg1" else max(cores, 64)
             t1 = time.perf_counter()
             oracle(0, cpu_sample, cores)
             dt = time.perf_counter() - t1
-            cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
-                   "sample": "first %d %s of the same batch, %d OpenMP threads, oracle/ta_oracle.c (restated scalar path), %.1f s"
-                             % (cpu_sample, unit_name, cores, dt)}
+            t2 = time.perf_counter()
+            n_one = max(1, cpu_sample // max(cores, 1)) if wl == "cfg3" else cpu_sample
+            oracle(0, n_one, 1)
+            dt1 = time.perf_counter() - t2
+            v_all, v_one = cells_unit * cpu_sample / dt / 1e9, cells_unit * n_one / dt1 / 1e9
+            cpu = {"value": v_all, "unit": "GCUPS", "cores": round(v_all / v_one, 1), "kind": "port",
+                   "sample": "first %d %s of the same batch, %d OpenMP threads, oracle/ta_oracle.c (restated scalar path), %.1f s; one "
+                             "thread: %.3f GCUPS (cores = all-thread / one-thread rate)" % (cpu_sample, unit_name, cores, dt, v_one),
+                   "threads_used": cores, "host": facts}
 
     if info.get("kernel") == 3:
         dtype = "u32 bit-vectors, 1 bit per band cell (reference width class u%d)" % info.get("cell_bits", 8)
+    evaluated_value = value * evaluated_unit / cells_unit if evaluated_unit else None
     line = {
         "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
         "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "unit": unit_name,
-                   "credited_cells_per_unit": cells_unit, "evaluated_band_cells_per_unit": evaluated_unit, "parallelism": "independent units sharded x%d, no collective" % world},
+        "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "units_total": all_units,
+                   "unit": unit_name, "credited_cells_per_unit": cells_unit, "evaluated_band_cells_per_unit": evaluated_unit,
+                   "parallelism": "independent units sharded x%d (%s), %s" % (
+                       world, args.scaling, "no collective" if wl != "cfg5" or world == 1 else
+                       "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
+                   "backend": backend if world > 1 else None},
+        "value_evaluated_cells": evaluated_value,
+        "strong_scaling": strong_fig,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "device_ms_per_pass": dev_s * 1e3, "algorithmic_bytes_per_pass": bytes_unit * units,

@@ -133,6 +133,14 @@ int tao_max_threads(void);
 int tao_levenshtein_k_batch_antidiag(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
                                      size_t n, uint32_t k, const tao_costs *costs, uint32_t *out, int threads);
 
+/* ta_oracle_avx2.c: hand-written AVX2 anti-diagonal restatement with saturating u8 cells (the reference's Avx{1,2,4,8}x32x8
+ * classes, src/levenshtein.rs:766-786) and the width ladder 8 -> 16 -> 32 around it (16-bit: ta_oracle_simd.c, 32-bit: the
+ * scalar restatement).  start_gap_cost == 0 only; -1 when the host has no AVX2 or the costs are affine.  lanes_hist: 6
+ * counters (no DP needed / 32 / 64 / 128 / 256 u8 lanes / wider cells) or NULL. */
+int tao_have_avx2(void);
+int tao_levenshtein_k_batch_ladder(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
+                                   size_t n, uint32_t k, const tao_costs *costs, uint32_t *out, int threads, uint64_t *lanes_hist);
+
 void tao_free(void *p);
 
 #ifdef __cplusplus

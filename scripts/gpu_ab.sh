@@ -1,16 +1,17 @@
 #!/bin/bash
-# A/B on ONE box: bench the library built from HEAD~N (gpurun_out-independent copy under /tmp) against the working tree's.
-# usage: gpu_ab.sh <old .so path relative to the repo> ; prints device ms per pass for cfg2 / cfg4, alternating three times
+# A/B of library builds on ONE box (boxes differ by +- 3 %): device ms per pass for cfg2 / cfg4, alternating REPS times.
+# usage: gpu_ab.sh [REPS=3] <a.so> <b.so> ...   (paths relative to the repo; the working tree's library is restored at the end)
 cd $GRAFT_REPO_ROOT
-OLD=$1
-cp triple_accel_amd/libtriple_accel_amd.so /tmp/new.so
-for rep in 1 2 3; do
-  for v in old new; do
-    if [ $v = old ]; then cp $OLD triple_accel_amd/libtriple_accel_amd.so; else cp /tmp/new.so triple_accel_amd/libtriple_accel_amd.so; fi
-    for wl in cfg2 cfg4; do
-      t=$(python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['roofline']['device_ms_per_pass'],4))")
-      echo "$v $wl $t"
+REPS=3
+if [[ $1 =~ ^[0-9]+$ ]]; then REPS=$1; shift; fi
+cp triple_accel_amd/libtriple_accel_amd.so /tmp/ta_keep.so
+for rep in $(seq $REPS); do
+  for so in "$@"; do
+    cp $so triple_accel_amd/libtriple_accel_amd.so
+    for wl in ${AB_WORKLOADS:-cfg2 cfg4}; do
+      t=$(python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['roofline']['device_ms_per_pass'],4), round(d['ms_per_step'],4))")
+      echo "$(basename $so) $wl $t"
     done
   done
 done
-cp /tmp/new.so triple_accel_amd/libtriple_accel_amd.so
+cp /tmp/ta_keep.so triple_accel_amd/libtriple_accel_amd.so

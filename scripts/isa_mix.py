@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Opcode histogram and issue-cycle model of a kernel's inner loop, from hipcc's own assembly.
+
+    python scripts/isa_mix.py [--json out.json] [--dump-dir DIR]
+
+For each BASELINE configuration's dominant kernel: compile its translation unit to gfx950 assembly (-S), take the
+basic block that carries the inner loop (the one with the most VALU instructions inside the kernel's deepest loop),
+count its instructions by opcode, and price every VALU opcode with the issue cost MEASURED on MI355X by
+scripts/ubench_valu*.hip (profiles/r01/ubench_valu_issue_rates*.txt, cycles per wave-instruction per SIMD at >= 2
+waves/SIMD):
+    full-rate class  2.3  v_add/sub/and/or/xor/mov/not/lshrrev (plain VOP1/VOP2 integer ops)
+    v_bitop3_b32     2.8
+    half-rate class  4.2  everything else measured: v_perm, v_dot4*, v_alignbit/byte, v_lshlrev, v_bfe, v_bcnt, v_min/max,
+                          v_cmp, v_cndmask (sgpr mask), v_add_co/v_addc_co, v_and_or, v_lshl_or/add, DPP/SDWA forms, v_pk_*16
+The modelled cycles per iteration = sum(count x class cost) is the MIX-SPECIFIC issue ceiling of that loop; the guide's
+hard ceiling is 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, SIMD-32).  bench.py reports the measured
+cycles per VALU instruction (SQ_INSTS_VALU, GRBM_GUI_ACTIVE) against both.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+from collections import Counter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "triple_accel_amd", "csrc")
+
+FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_not_b32", "v_lshrrev_b32",
+        "v_add_f32", "v_mul_f32", "v_min_u16", "v_add_u16", "v_xnor_b32", "v_accvgpr_write_b32", "v_accvgpr_read_b32", "v_nop"}
+SPECIAL = {"v_bitop3_b32": 2.8, "v_fma_f32": 2.9, "ds_bpermute_b32": 24.0}
+HALF = 4.2
+
+# (config, translation unit, mangled-name regex of the dominant kernel, columns / steps one iteration of the block advances)
+KERNELS = [
+    ("cfg2", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi9ELb0ELb1E\w*", "4 columns of 64 pairs (33-diagonal band, static window)"),
+    ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
+    ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi64ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
+    ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernel\w*", "haystack bytes per lane (bit-parallel filter scan)"),
+]
+
+
+def cost(op):
+    base = re.sub(r"_(e32|e64)$", "", op)
+    if base.endswith("_dpp") or base.endswith("_sdwa"):
+        return HALF, "half"
+    if base in SPECIAL:
+        return SPECIAL[base], "bitop3" if base == "v_bitop3_b32" else base
+    if base in FULL:
+        return 2.3, "full"
+    if base.startswith("v_"):
+        return HALF, "half"
+    return 0.0, "other"            # SALU / LDS / VMEM / waitcnt issue on other ports
+
+
+def kernel_body(asm, name_re):
+    m = re.search(r"^(%s):" % name_re, asm, re.M)
+    if not m:
+        return None, None
+    i = m.start()
+    j = asm.index(".Lfunc_end", i)
+    return m.group(1), asm[i:j]
+
+
+def blocks_of(body):
+    parts = re.split(r"\n(\.LBB\d+_\d+):", body)
+    out = []
+    for k in range(1, len(parts), 2):
+        ins = []
+        for l in parts[k + 1].split("\n"):
+            if not l.startswith("\t"):
+                continue
+            t = l.split()
+            if not t or t[0].startswith((";", ".")):
+                continue
+            ins.append(t[0])
+        depth = 0
+        md = re.findall(r"Depth=(\d+)", parts[k + 1][:400])
+        if md:
+            depth = max(int(x) for x in md)
+        out.append((parts[k], ins, depth, parts[k + 1]))
+    return out
+
+
+def hot_block(body):
+    bl = blocks_of(body)
+    return max(bl, key=lambda b: sum(1 for x in b[1] if x.startswith("v_")))
+
+
+def analyse(label, ins):
+    c = Counter(re.sub(r"_(e32|e64)$", "", x) for x in ins)
+    classes = Counter()
+    cycles = 0.0
+    nvalu = 0
+    for op, n in c.items():
+        w, cl = cost(op)
+        if op.startswith("v_") or op == "ds_bpermute_b32":
+            classes[cl] += n
+            cycles += w * n
+            if op.startswith("v_"):
+                nvalu += n
+    return {"block": label, "instructions": len(ins), "valu": nvalu, "by_class": dict(classes),
+            "s_nop": c.get("s_nop", 0), "lds": sum(n for op, n in c.items() if op.startswith("ds_")),
+            "vmem": sum(n for op, n in c.items() if op.startswith(("global_", "buffer_", "flat_"))),
+            "salu": sum(n for op, n in c.items() if op.startswith("s_") and op != "s_nop"),
+            "modelled_issue_cycles": round(cycles, 1),
+            "modelled_cycles_per_valu_inst": round(cycles / max(nvalu, 1), 3),
+            "histogram": dict(c.most_common())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json")
+    ap.add_argument("--dump-dir", help="write each kernel's hot block (assembly text) here")
+    args = ap.parse_args()
+    asm_cache = {}
+    result = {}
+    for cfg, tu, name_re, what in KERNELS:
+        if tu not in asm_cache:
+            out = "/tmp/isa_mix_%s.s" % tu.replace(".hip", "")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                                   "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", os.path.join(CSRC, tu), "-o", out],
+                                  cwd=CSRC)
+            asm_cache[tu] = open(out).read()
+        name, body = kernel_body(asm_cache[tu], name_re)
+        if body is None:
+            print("%s: kernel %s not found in %s" % (cfg, name_re, tu), file=sys.stderr)
+            continue
+        lab, ins, depth, text = hot_block(body)
+        r = analyse(lab, ins)
+        r["kernel"] = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        r["iteration"] = what
+        r["vgprs"] = int((re.findall(r"; NumVgprs: (\d+)", asm_cache[tu][asm_cache[tu].index(name + ":"):]) or ["0"])[0])
+        result[cfg] = r
+        print("%s  %s  block %s: %d instr, %d VALU (%s), %d s_nop, %d LDS, %d VMEM -> %.0f modelled issue cycles, %.2f per VALU instr"
+              % (cfg, r["kernel"][:60], lab, r["instructions"], r["valu"],
+                 ", ".join("%s %d" % kv for kv in sorted(r["by_class"].items())), r["s_nop"], r["lds"], r["vmem"],
+                 r["modelled_issue_cycles"], r["modelled_cycles_per_valu_inst"]))
+        print("      " + ", ".join("%d %s" % (n, op) for op, n in list(r["histogram"].items())[:14]))
+        if args.dump_dir:
+            os.makedirs(args.dump_dir, exist_ok=True)
+            with open(os.path.join(args.dump_dir, "inner_loop_%s.s" % cfg), "w") as f:
+                f.write("; %s\n; hot block %s of %s (hipcc -O3 --offload-arch=gfx950 -S)\n%s:%s\n" % (r["kernel"], lab, tu, lab, text))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(result, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

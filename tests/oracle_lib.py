@@ -78,6 +78,10 @@ def lib():
         L.tao_levenshtein_k_batch_antidiag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, u32, cp, C.c_void_p,
                                                        C.c_int]
         L.tao_levenshtein_k_batch_antidiag.restype = C.c_int
+        L.tao_levenshtein_k_batch_ladder.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, u32, cp, C.c_void_p,
+                                                     C.c_int, C.c_void_p]
+        L.tao_levenshtein_k_batch_ladder.restype = C.c_int
+        L.tao_have_avx2.argtypes = []; L.tao_have_avx2.restype = C.c_int
         L.tao_levenshtein_exp_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, cp, C.c_void_p, C.c_int]
         L.tao_levenshtein_exp_batch.restype = None
         L.tao_hamming_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_int]
@@ -271,6 +275,27 @@ def levenshtein_k_batch_antidiag(a_csr, b_csr, k, costs=LEVENSHTEIN_COSTS, threa
     rc = lib().tao_levenshtein_k_batch_antidiag(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k,
                                                 C.byref(cs), out.ctypes.data, threads or max_threads())
     return out if rc == 0 else None
+
+
+def have_avx2():
+    return bool(lib().tao_have_avx2())
+
+
+def levenshtein_k_batch_ladder(a_csr, b_csr, k, costs=LEVENSHTEIN_COSTS, threads=0, hist=False):
+    """The hand-written AVX2 u8 anti-diagonal restatement with the width ladder 8 -> 16 -> 32 around it
+    (oracle/ta_oracle_avx2.c); None when it does not apply (no AVX2 on the host, affine gaps).  hist=True also returns the
+    six class counters (no DP / 32 / 64 / 128 / 256 u8 lanes / wider cells)."""
+    np = _np()
+    (ab, ao), (bb, bo) = a_csr, b_csr
+    n = len(ao) - 1
+    out = np.empty(n, dtype=np.uint32)
+    h = np.zeros(6, dtype=np.uint64)
+    cs = mk_costs(costs)
+    rc = lib().tao_levenshtein_k_batch_ladder(ab.ctypes.data, ao.ctypes.data, bb.ctypes.data, bo.ctypes.data, n, k,
+                                              C.byref(cs), out.ctypes.data, threads or max_threads(), h.ctypes.data)
+    if rc != 0:
+        return (None, None) if hist else None
+    return (out, [int(x) for x in h]) if hist else out
 
 
 def levenshtein_exp_batch(a_csr, b_csr, costs=LEVENSHTEIN_COSTS, threads=0):

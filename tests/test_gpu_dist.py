@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, needle, hay, k, costs, cuts, q):
+def _worker(rank, world, port, needle, hay, k, costs, cuts, resident, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,6 +26,13 @@ def _worker(rank, world, port, needle, hay, k, costs, cuts, q):
         from triple_accel_amd import dist as D
         torch.cuda.set_device(0)
         shard = hay[cuts[rank]:cuts[rank + 1]]
+        if resident:                                       # the shard lives in HBM; the sharded search must not copy or re-upload it
+            from triple_accel_amd import batch as B
+            shard = B.haystack_tensor(shard)
+
+            def _no_upload(*a, **kw):
+                raise AssertionError("a resident shard was re-uploaded")
+            B.haystack_tensor = _no_upload
         res = {}
         for st in (T.SearchType.All, T.SearchType.Best):
             ms = D.levenshtein_search_sharded(needle, shard, k, st, T.EditCosts(*costs))     # default local search: the HIP kernels
@@ -35,8 +42,8 @@ def _worker(rank, world, port, needle, hay, k, costs, cuts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("costs", [(1, 1, 0, None), (2, 1, 1, None)])
-def test_two_rank_sharded_search_with_hip_kernels(costs):
+@pytest.mark.parametrize("costs,resident", [((1, 1, 0, None), False), ((1, 1, 0, None), True), ((2, 1, 1, None), True)])
+def test_two_rank_sharded_search_with_hip_kernels(costs, resident):
     import datagen as Dg
     import oracle_lib as O
     g = Dg.rng(321)
@@ -47,8 +54,8 @@ def test_two_rank_sharded_search_with_hip_kernels(costs):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + costs[0]
-    ps = [ctx.Process(target=_worker, args=(r, world, port, needle, hay, k, costs, cuts, q)) for r in range(world)]
+    port = 29650 + costs[0] + 10 * int(resident)
+    ps = [ctx.Process(target=_worker, args=(r, world, port, needle, hay, k, costs, cuts, resident, q)) for r in range(world)]
     for p in ps:
         p.start()
     out = dict(q.get(timeout=300) for _ in range(world))

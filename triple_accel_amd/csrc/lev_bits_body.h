@@ -27,7 +27,13 @@ namespace ta {
 // STATIC: the bytes of `a` under the window stay put for 4 columns (sub-column s reads window bit i from byte i + s and
 // shifts the packed mismatch bits by s instead); the registers move a whole dword every 4th column.  Saves the NA
 // v_alignbyte per column of the sliding form at the price of 3 window bits.
-template <class W, int NA, bool TRANS, bool STATIC = false>
+// PACK: how the eight-bit masks of the byte groups are put together -- 0: Horner chain through the v_dot4 accumulator (mask so far
+// << 8, then the next group's two v_dot4 on top of it); 1: every group on its own (two v_dot4), joined by v_lshl_or_b32 -- the same
+// instruction count, but the groups no longer wait for each other.
+#ifndef TA_BITS_PACK
+#define TA_BITS_PACK 0
+#endif
+template <class W, int NA, bool TRANS, bool STATIC = false, int PACK = TA_BITS_PACK>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
@@ -67,6 +73,20 @@ struct LevBits {
             // groups from the top down, Horner style: the accumulator of a group is the mask so far, shifted up.
             U32 ne = W::splat(0);
             bool first = true;
+            if (PACK == 1) {
+                // groups from the top down so that the join is (top << 8 | next) ... each v_lshl_or_b32 takes one finished group
+#pragma unroll
+                for (int p = 3; p >= 0; p--) {
+                    const int k0 = 8 * q + 2 * p;
+                    if (k0 >= NA) continue;
+                    U32 g = W::sdot4_first(W::ne12(st.AW[k0] ^ Bs), W::splat(0xF8FCFEFFu));
+                    if (k0 + 1 < NA) g = W::sdot4(W::ne12(st.AW[k0 + 1] ^ Bs), W::splat(0x80C0E0F0u), g);
+                    ne = first ? g : W::lshl_or(ne, 8, g);
+                    first = false;
+                }
+                NE[q] = ne;
+                continue;
+            }
 #pragma unroll
             for (int p = 3; p >= 0; p--) {
                 const int k0 = 8 * q + 2 * p;
@@ -219,7 +239,14 @@ struct LevBits {
                         st.AW[NA - 1] = W::lds_read32u(lds, pa) ^ 0x0C0C0C0Cu;
                         if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
                         const U32 b0 = W::lds_read32u(lds, rb + tp), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
-                        if (!cap) {
+                        if (!cap && tp + 4u <= p_hi) {
+                            // the common case is straight-line code: the four sub-columns' match vectors do not depend on
+                            // each other, so their v_perm / v_dot4 chains interleave with the serial core of the one before
+                            column<false, 0>(st, b0, M, cnt, active);
+                            column<false, 1>(st, b1, M, cnt, active);
+                            column<false, 2>(st, b2, M, cnt, active);
+                            column<false, 3>(st, b3, M, cnt, active);
+                        } else if (!cap) {                     // the last, partial group of the longest pair
                             column<false, 0>(st, b0, M, cnt, active);
                             if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
                             if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);

@@ -2,10 +2,11 @@
 
 The hot path shards without any data-path collective:
   * pair batches: contiguous N/G pairs per rank; results stay on the rank (or are all-gathered on request);
-  * levenshtein_search over one big haystack: contiguous shards with a left halo of needle_len + unit_k + 2
-    bytes taken from the previous rank(s); every rank emits All-mode hits for its own end positions only; the
-    ONE exchange step is the final match-list gather (counts, then padded records), after which the
-    order-dependent Best fold runs identically on every rank.
+  * levenshtein_search over one big haystack: contiguous shards RESIDENT in HBM (never copied or re-uploaded); every
+    rank publishes its last needle_len + unit_k + 2 bytes (one all-gather of that many bytes, on the device under RCCL)
+    and searches [left context | its first halo bytes] as a tiny head buffer plus its shard in place; every rank emits
+    All-mode hits for its own end positions only; the ONE exchange step of the data path is the final match-list gather
+    (counts, then padded records), after which the order-dependent Best fold runs identically on every rank.
 """
 import ctypes as _C
 
@@ -60,61 +61,113 @@ def fold_best(hits, k, overlap_fold=True):
     return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in arr[:m]]
 
 
-def _gpu_local_search(needle, hay_ext, k, costs, base, emit_from, best=False):
+def _gpu_local_search(needle, hay, k, costs, base, emit_from, best=False):
+    """hay: (CUDA uint8 tensor with read slack, length) -- already resident, nothing is uploaded here."""
     from . import batch as B
-    t = B.haystack_tensor(hay_ext) if not isinstance(hay_ext, tuple) else hay_ext
     if best:                     # only the hits with the shard's smallest k leave the device (see below)
-        return B.levenshtein_search_best_dev(needle, t, k, costs, base, emit_from)
-    return B.levenshtein_search_dev(needle, t, k, costs, False, base, emit_from)
+        return B.levenshtein_search_best_dev(needle, hay, k, costs, base, emit_from)
+    return B.levenshtein_search_dev(needle, hay, k, costs, False, base, emit_from)
+
+
+def _as_device_shard(shard):
+    """(tensor, length) for a device-resident shard (a uint8 CUDA tensor with >= 16 bytes of read slack after `length`, or
+    that pair itself); None for host bytes."""
+    if isinstance(shard, tuple) and len(shard) == 2 and isinstance(shard[0], torch.Tensor):
+        return shard[0], int(shard[1])
+    if isinstance(shard, torch.Tensor):
+        from .batch import SLACK
+        return shard, shard.numel() - SLACK
+    return None
 
 
 def levenshtein_search_sharded(needle, shard, k, search_type=SearchType.Best, costs=LEVENSHTEIN_COSTS, group=None,
                                local_search=None):
-    """levenshtein_search_simd_with_opts (unanchored) over the concatenation of every rank's `shard` (bytes).
+    """levenshtein_search_simd_with_opts (unanchored) over the concatenation of every rank's `shard`.
 
+    `shard` is host bytes, or -- the form the 1 GiB-per-GPU configuration uses -- a haystack already RESIDENT in HBM:
+    a uint8 CUDA tensor with >= 16 bytes of read slack, or `(tensor, length)` (batch.haystack_tensor).  A resident shard
+    is never copied or re-uploaded: the only bytes that move are the `needle_len + unit_k + 2`-byte tails every rank
+    publishes (one all-gather, on the device under RCCL) and the final match lists.  Each rank runs two searches:
+      * the HEAD: [left context from the previous rank(s) | the first `halo` bytes of its shard] -- a buffer of at most
+        2 * halo bytes assembled on the device -- which owns the end positions inside those first `halo` bytes;
+      * the BODY: the shard itself, in place, which owns every later end position (its own first `halo` bytes are the
+        left context those need; a DP started fresh `halo` bytes early is exact for every cost <= k).
     Returns the same list of Match on every rank.  `local_search(needle, bytes, k, costs, base, emit_from)` ->
-    int64 rows (start, end, k) defaults to the HIP kernel; tests inject a CPU stand-in to exercise the
-    partition / halo / gather logic under gloo."""
+    int64 rows (start, end, k) replaces the HIP kernels (tests inject a CPU stand-in to exercise the partition / halo /
+    gather logic under gloo; host-bytes shards only)."""
     needle = bytes(needle)
-    shard = bytes(shard)
     costs = _costs(costs)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = _device_for_group(group)
     if len(needle) == 0:
         return []
+    dshard = _as_device_shard(shard)
+    if dshard is None:
+        shard = bytes(shard)
+        if local_search is None:                          # host bytes + HIP kernels: upload once, then the resident path
+            from . import batch as B
+            dshard = B.haystack_tensor(shard)
+    elif local_search is not None:
+        raise ValueError("local_search stand-ins take host bytes")
+    slen = dshard[1] if dshard is not None else len(shard)
     unit_k = max(0, k - costs.start_gap_cost) // costs.gap_cost
     halo = len(needle) + unit_k + 2
 
     # shard lengths -> global offsets
-    ln = torch.tensor([len(shard)], dtype=torch.int64, device=dev)
+    ln = torch.tensor([slen], dtype=torch.int64, device=dev)
     lens = [torch.zeros_like(ln) for _ in range(world)]
     dist.all_gather(lens, ln, group=group)
     lens = [int(x.item()) for x in lens]
     offs = np.concatenate([[0], np.cumsum(lens)])
-    # every rank publishes its last `halo` bytes; a rank's left context is the tail of what precedes it
-    tail = np.zeros(halo, dtype=np.uint8)
-    tl = min(halo, len(shard))
-    if tl:
-        tail[halo - tl:] = np.frombuffer(shard[-tl:], dtype=np.uint8)
-    tail_t = torch.from_numpy(tail).to(dev)
+    # every rank publishes its last `halo` bytes (right-aligned); a rank's left context is the tail of what precedes it
+    tl = min(halo, slen)
+    if dshard is not None:
+        tail_t = torch.zeros(halo, dtype=torch.uint8, device=dshard[0].device)
+        if tl:
+            tail_t[halo - tl:] = dshard[0][slen - tl:slen]
+        tail_t = tail_t.to(dev)                           # stays on the device under RCCL; `halo` bytes to the host under gloo
+    else:
+        tail = np.zeros(halo, dtype=np.uint8)
+        if tl:
+            tail[halo - tl:] = np.frombuffer(shard[-tl:], dtype=np.uint8)
+        tail_t = torch.from_numpy(tail).to(dev)
     tails = [torch.zeros_like(tail_t) for _ in range(world)]
     dist.all_gather(tails, tail_t, group=group)
-    ctx = b""
-    r = rank - 1
-    while r >= 0 and len(ctx) < halo:
+    pieces, have, r = [], 0, rank - 1
+    while r >= 0 and have < halo:
         tr = min(halo, lens[r])
-        piece = tails[r].cpu().numpy().tobytes()[halo - tr:] if tr else b""
-        ctx = piece + ctx
+        if tr:
+            pieces.insert(0, tails[r][halo - tr:])
+            have += tr
         r -= 1
-    ctx = ctx[-halo:] if len(ctx) > halo else ctx
+    ctx_t = torch.cat(pieces)[-halo:] if pieces else torch.zeros(0, dtype=torch.uint8, device=dev)
+    nctx = int(ctx_t.numel())
 
-    base = int(offs[rank]) - len(ctx)
+    off = int(offs[rank])
+    h1 = min(halo, slen)                                  # end positions (off, off + h1] belong to the head search
     best = search_type == SearchType.Best
-    if local_search is None:
-        local = _gpu_local_search(needle, ctx + shard, k, costs, base, int(offs[rank]), best)
+    if dshard is not None:
+        from .batch import SLACK
+        sdev = dshard[0].device
+        head = torch.zeros(nctx + h1 + SLACK, dtype=torch.uint8, device=sdev)
+        if nctx:
+            head[:nctx] = ctx_t.to(sdev)
+        if h1:
+            head[nctx:nctx + h1] = dshard[0][:h1]
+        parts = []
+        if h1:
+            parts.append(_gpu_local_search(needle, (head, nctx + h1), k, costs, off - nctx, off, best))
+        if slen > h1:
+            parts.append(_gpu_local_search(needle, dshard, k, costs, off, off + h1, best))
     else:
-        local = local_search(needle, ctx + shard, k, costs, base, int(offs[rank]))
-    local = np.asarray(local, dtype=np.int64).reshape(-1, 3)
+        ctx = ctx_t.cpu().numpy().tobytes()
+        parts = []
+        if h1:
+            parts.append(local_search(needle, ctx + shard[:h1], k, costs, off - nctx, off))
+        if slen > h1:
+            parts.append(local_search(needle, shard, k, costs, off, off + h1))
+    parts = [np.asarray(x, dtype=np.int64).reshape(-1, 3) for x in parts]
+    local = np.concatenate(parts) if parts else np.empty((0, 3), dtype=np.int64)
     if best and len(local):
         # Best keeps the hits with the globally smallest k, and once the running minimum has reached it no other hit is
         # emitted any more (src/levenshtein.rs:1792-1835): a shard only needs to contribute the hits with ITS smallest k
