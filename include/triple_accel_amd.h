@@ -164,6 +164,16 @@ int ta_hamming_search(const uint8_t *needle, size_t needle_len, const uint8_t *h
                       ta_match **out, size_t *n_out);
 void ta_free(void *p);
 
+/* Threading.  Every entry point may be called from any number of threads at once.  The single-call host functions
+ * (ta_hamming .. ta_levenshtein_exp, the *_search host forms, the tracebacks) run on a stream the library keeps per calling
+ * thread (non-blocking: concurrent callers never serialise on the null stream) and stage short pairs through a pinned,
+ * device-mapped buffer of that thread -- one kernel launch and one stream synchronisation per call.  The batch / *_dev
+ * functions run on the stream the caller passes; a thread that switches streams between two such calls is ordered by an
+ * event the library records at the end of each call (the thread-local scratch of the first call may still be in use).
+ * ta_thread_release() frees what the calling thread holds inside the library (device scratch, its stream, the pinned
+ * buffer); optional -- without it they live until process exit. */
+void ta_thread_release(void);
+
 /* ---- batch API on device-resident data (new surface; N = 1 equals the single-call form) -- */
 
 /* String i of a batch is blob[off[i] .. off[i+1]) (CSR, n+1 offsets, device memory), or, when

@@ -4,7 +4,7 @@
     python scripts/isa_mix.py [--json out.json] [--dump-dir DIR]
 
 For each BASELINE configuration's dominant kernel: compile its translation unit to gfx950 assembly (-S), take the
-basic block that carries the inner loop (the one with the most VALU instructions inside the kernel's deepest loop),
+innermost loop with the most VALU instructions (all its basic blocks, minus the ragged-tail variants),
 count its instructions by opcode, and price every VALU opcode with the issue cost MEASURED on MI355X by
 scripts/ubench_valu*.hip (profiles/r01/ubench_valu_issue_rates*.txt, cycles per wave-instruction per SIMD at >= 2
 waves/SIMD):
@@ -36,7 +36,7 @@ HALF = 4.2
 KERNELS = [
     ("cfg2", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi9ELb0ELb1E\w*", "4 columns of 64 pairs (33-diagonal band, static window)"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
-    ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi64ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
+    ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
     ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernel\w*", "haystack bytes per lane (bit-parallel filter scan)"),
 ]
 
@@ -64,6 +64,7 @@ def kernel_body(asm, name_re):
 
 
 def blocks_of(body):
+    body = re.sub(r"\n; %bb\.(\d+):", lambda m: "\n.LBB0_%s:" % m.group(1), body)     # fall-through blocks carry no label of their own
     parts = re.split(r"\n(\.LBB\d+_\d+):", body)
     out = []
     for k in range(1, len(parts), 2):
@@ -83,9 +84,33 @@ def blocks_of(body):
     return out
 
 
-def hot_block(body):
+def hot_loop(body):
+    """The innermost loop with the most VALU work: all blocks LLVM annotates with the same deepest `Header=`, plus that header.
+    Blocks of the loop that carry the per-column liveness select of the ragged tail (a v_cndmask_b32 fed by a v_cmp -- only the
+    last chunk of a batch takes them) are left out, so the histogram is the path a full chunk runs."""
     bl = blocks_of(body)
-    return max(bl, key=lambda b: sum(1 for x in b[1] if x.startswith("v_")))
+    groups = {}
+    for lab, ins, depth, text in bl:
+        m = re.search(r"Header=(BB\d+_\d+) Depth=(\d+)", text[:600])
+        hdr = None
+        if "This Inner Loop Header" in text[:600]:
+            hdr = lab.lstrip(".L")
+        elif m:
+            hdr = m.group(1)
+        if hdr:
+            groups.setdefault(hdr, []).append((lab, ins, text))
+    def valu(g):
+        return sum(1 for _, ins, _ in g for x in ins if x.startswith("v_"))
+    hdr = max(groups, key=lambda h: valu(groups[h]))
+    used, skipped, all_ins, texts = [], [], [], []
+    for lab, ins, text in groups[hdr]:
+        if len(groups[hdr]) > 1 and any(x.startswith("v_cndmask") for x in ins) and any(x.startswith("v_cmp") for x in ins):
+            skipped.append(lab)
+            continue
+        used.append(lab)
+        all_ins += ins
+        texts.append("%s:%s" % (lab, text))
+    return "+".join(used), all_ins, skipped, "\n".join(texts)
 
 
 def analyse(label, ins):
@@ -127,8 +152,9 @@ def main():
         if body is None:
             print("%s: kernel %s not found in %s" % (cfg, name_re, tu), file=sys.stderr)
             continue
-        lab, ins, depth, text = hot_block(body)
+        lab, ins, skipped, text = hot_loop(body)
         r = analyse(lab, ins)
+        r["blocks_left_out_ragged_tail"] = skipped
         r["kernel"] = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
         r["iteration"] = what
         r["vgprs"] = int((re.findall(r"; NumVgprs: (\d+)", asm_cache[tu][asm_cache[tu].index(name + ":"):]) or ["0"])[0])
@@ -141,7 +167,7 @@ def main():
         if args.dump_dir:
             os.makedirs(args.dump_dir, exist_ok=True)
             with open(os.path.join(args.dump_dir, "inner_loop_%s.s" % cfg), "w") as f:
-                f.write("; %s\n; hot block %s of %s (hipcc -O3 --offload-arch=gfx950 -S)\n%s:%s\n" % (r["kernel"], lab, tu, lab, text))
+                f.write("; %s\n; inner loop (blocks %s) of %s (hipcc -O3 --offload-arch=gfx950 -S)\n%s\n" % (r["kernel"], lab, tu, text))
     if args.json:
         with open(args.json, "w") as f:
             json.dump(result, f, indent=1)

@@ -31,15 +31,29 @@ template <int NA> static void run_bits(const LevParams &P, bool trans, bool stat
     free(lds);
 }
 
+// a_off / b_off == nullptr: fixed-length (strided) batch of a_len / b_len bytes per string -- the coalesced fetch form;
+// subset (may be nullptr): pair indices, as the levenshtein_exp rounds pass them
+extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, uint64_t a_len, const uint8_t *b_blob,
+                                const uint64_t *b_off, uint64_t b_len, const uint32_t *subset,
+                                uint32_t n, uint32_t k, int has_t, uint64_t max_len, int force_NA, int force_static, uint32_t *out,
+                                uint32_t *plan_out /* NA, u, Tw, static */);
+
 extern "C" int emu_lev_bits(const uint8_t *a_blob, const uint64_t *a_off, const uint8_t *b_blob, const uint64_t *b_off,
                             uint32_t n, uint32_t k, int has_t, uint64_t max_len, int force_NA, int force_static, uint32_t *out,
                             uint32_t *plan_out /* NA, u, Tw, static */) {
+    return emu_lev_bits_any(a_blob, a_off, 0, b_blob, b_off, 0, nullptr, n, k, has_t, max_len, force_NA, force_static, out, plan_out);
+}
+
+extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, uint64_t a_len, const uint8_t *b_blob,
+                                const uint64_t *b_off, uint64_t b_len, const uint32_t *subset,
+                                uint32_t n, uint32_t k, int has_t, uint64_t max_len, int force_NA, int force_static, uint32_t *out,
+                                uint32_t *plan_out /* NA, u, Tw, static */) {
     LevBitsPlan pl = lev_bits_make_plan(k, 1, 1, 0, has_t != 0, 1, max_len, force_NA, g_emu_force_ch, force_static);
     if (!pl.ok) return 1;
     LevParams P;
-    P.a = StrView{a_blob, a_off, 0, 0};
-    P.b = StrView{b_blob, b_off, 0, 0};
-    P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
+    P.a = StrView{a_blob, a_off, a_off ? 0 : a_len, a_off ? 0 : a_len};
+    P.b = StrView{b_blob, b_off, b_off ? 0 : b_len, b_off ? 0 : b_len};
+    P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
     if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.stat; }

@@ -147,3 +147,58 @@ def test_bits_byte_values_around_the_perm_selector_codes(trans):
         for k, na, static in ((12, 0, 0), (30, 9, 2)):
             got, plan = E.lev_bits(a, b, k, trans, force_NA=na, static=static)
             assert got == oracle(a, b, k, trans), (alpha[:4], k, na, static)
+
+
+# ---- fixed-length (strided) batches take the COALESCED fetch form: four lanes per pair bring 64 consecutive bytes
+def _fixed_batch(seed, n, la, lb, k, alpha=26, swaps=False):
+    g = Dg.rng(seed)
+    a = g.integers(97, 97 + alpha, size=(n, la), dtype=np.uint8)
+    b = np.empty((n, lb), dtype=np.uint8)
+    for i in range(n):
+        if g.random() < 0.75:
+            m = Dg.mutate(g, a[i].tobytes(), int(g.integers(0, k + 3)), swaps)
+            m = (m + g.integers(97, 97 + alpha, size=lb, dtype=np.uint8).tobytes())[:lb]
+        else:
+            m = g.integers(97, 97 + alpha, size=lb, dtype=np.uint8).tobytes()
+        b[i] = np.frombuffer(m, dtype=np.uint8)
+    return a, b
+
+
+@pytest.mark.parametrize("la,lb,k,trans", [(256, 256, 32, False), (128, 128, 8, True), (100, 93, 12, False), (61, 70, 20, True),
+                                           (300, 300, 60, False), (17, 17, 3, False), (200, 215, 127, False), (1, 1, 1, False),
+                                           (64, 64, 0, False), (130, 129, 33, True)])
+def test_emu_bits_fixed_length_coalesced(la, lb, k, trans):
+    """n = 150: two full wavefronts and one with 22 live lanes (helper lanes serve live pairs while their own pair is absent)."""
+    a, b = _fixed_batch(la * 7 + lb + k, 150, la, lb, k, swaps=trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(150)]
+    for static in (1, 2):
+        if static == 2 and k >= 124:
+            continue
+        got, plan = E.lev_bits_fixed(a, b, k, trans, static=static)
+        assert got == want, (la, lb, k, trans, static, plan)
+    assert any(w is not None for w in want) or k == 0
+
+
+def test_emu_bits_fixed_length_subset():
+    """The levenshtein_exp rounds hand the kernel a subset list: helper lanes must follow the OWNER's pair index."""
+    a, b = _fixed_batch(5, 200, 96, 96, 10)
+    g = Dg.rng(9)
+    subset = np.sort(g.choice(200, size=77, replace=False)).astype(np.uint32)
+    got, _ = E.lev_bits_fixed(a, b, 10, False, subset=subset)
+    for i in range(200):
+        if i in set(int(x) for x in subset):
+            assert got[i] == O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 10, False, (1, 1, 0, None))[0], i
+        else:
+            assert got[i] == "untouched", i
+
+
+def test_emu_bits_fixed_length_nul_and_high_bytes():
+    g = Dg.rng(12)
+    a = g.integers(0, 256, size=(70, 80), dtype=np.uint8)
+    b = a.copy()
+    b[:, ::7] = g.integers(0, 256, size=b[:, ::7].shape, dtype=np.uint8)
+    a[:, 3] = 0; b[:, 5] = 12; a[:, 9] = 12
+    got, _ = E.lev_bits_fixed(a, b, 30, False)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 30, False, (1, 1, 0, None))[0] for i in range(70)]
+    assert got == want

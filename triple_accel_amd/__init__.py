@@ -86,7 +86,20 @@ def _u32(fn, *args):
 
 
 def _b(x):
-    return bytes(x)
+    """bytes-like only: `bytes(5)` would silently turn an int into five NUL bytes."""
+    if isinstance(x, bytes):
+        return x
+    if isinstance(x, (bytearray, memoryview)) or type(x).__name__ == "ndarray":
+        return bytes(x)
+    raise TypeError("expected a bytes-like string, got %s" % type(x).__name__)
+
+
+def _k(k):
+    """k is a u32 in the reference; ctypes would truncate anything else silently."""
+    k = int(k)
+    if not 0 <= k <= 0xFFFFFFFF:
+        raise OverflowError("k must fit a u32, got %d" % k)
+    return k
 
 
 # ---------------------------------------------------------------- hamming (src/hamming.rs)
@@ -111,7 +124,7 @@ def _matches(fn, *args):
 def hamming_search_simd_with_opts(needle, haystack, k, search_type):
     """src/hamming.rs:454"""
     needle, haystack = _b(needle), _b(haystack)
-    return _matches(_n.lib().ta_hamming_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
+    return _matches(_n.lib().ta_hamming_search_simd_with_opts, needle, len(needle), haystack, len(haystack), _k(k),
                     search_type)
 
 
@@ -145,16 +158,16 @@ def levenshtein_simd_k_with_opts(a, b, k, trace_on, costs):
     """src/levenshtein.rs:714 -> None | (distance, None | [Edit])."""
     a, b = _b(a), _b(b)
     if trace_on:
-        d, edits = _trace(_n.lib().ta_levenshtein_trace, a, len(a), b, len(b), k, _C.byref(_costs(costs)._c()))
+        d, edits = _trace(_n.lib().ta_levenshtein_trace, a, len(a), b, len(b), _k(k), _C.byref(_costs(costs)._c()))
         return None if d is None else (d, edits)
-    d = _u32(_n.lib().ta_levenshtein_simd_k_with_opts, a, len(a), b, len(b), k, 0, _C.byref(_costs(costs)._c()))
+    d = _u32(_n.lib().ta_levenshtein_simd_k_with_opts, a, len(a), b, len(b), _k(k), 0, _C.byref(_costs(costs)._c()))
     return None if d is None else (d, None)
 
 
 def levenshtein_simd_k(a, b, k):
     """src/levenshtein.rs:677"""
     a, b = _b(a), _b(b)
-    return _u32(_n.lib().ta_levenshtein_simd_k, a, len(a), b, len(b), k)
+    return _u32(_n.lib().ta_levenshtein_simd_k, a, len(a), b, len(b), _k(k))
 
 
 def _dist(name):
@@ -182,7 +195,7 @@ def levenshtein_exp_with_opts(a, b, trace_on, costs):
 def levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored):
     """src/levenshtein.rs:1911"""
     needle, haystack = _b(needle), _b(haystack)
-    return _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
+    return _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), _k(k),
                     search_type, _C.byref(_costs(costs)._c()), int(bool(anchored)))
 
 
@@ -198,7 +211,7 @@ levenshtein_search = levenshtein_search_simd   # src/levenshtein.rs:2508
 def levenshtein_select(a_len, b_len, k, costs=LEVENSHTEIN_COSTS):
     """The dispatcher arithmetic (src/levenshtein.rs:731-791): (max_k, unit_k, cell_bits, ref_lanes)."""
     s = _n.LevSelectC()
-    _raise(_n.lib().ta_levenshtein_select(a_len, b_len, k, _C.byref(_costs(costs)._c()), _C.byref(s)))
+    _raise(_n.lib().ta_levenshtein_select(a_len, b_len, _k(k), _C.byref(_costs(costs)._c()), _C.byref(s)))
     return (s.max_k, s.unit_k, s.cell_bits, s.ref_lanes)
 
 

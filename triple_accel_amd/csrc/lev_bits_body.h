@@ -27,13 +27,7 @@ namespace ta {
 // STATIC: the bytes of `a` under the window stay put for 4 columns (sub-column s reads window bit i from byte i + s and
 // shifts the packed mismatch bits by s instead); the registers move a whole dword every 4th column.  Saves the NA
 // v_alignbyte per column of the sliding form at the price of 3 window bits.
-// PACK: how the eight-bit masks of the byte groups are put together -- 0: Horner chain through the v_dot4 accumulator (mask so far
-// << 8, then the next group's two v_dot4 on top of it); 1: every group on its own (two v_dot4), joined by v_lshl_or_b32 -- the same
-// instruction count, but the groups no longer wait for each other.
-#ifndef TA_BITS_PACK
-#define TA_BITS_PACK 0
-#endif
-template <class W, int NA, bool TRANS, bool STATIC = false, int PACK = TA_BITS_PACK>
+template <class W, int NA, bool TRANS, bool STATIC = false>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
@@ -73,20 +67,6 @@ struct LevBits {
             // groups from the top down, Horner style: the accumulator of a group is the mask so far, shifted up.
             U32 ne = W::splat(0);
             bool first = true;
-            if (PACK == 1) {
-                // groups from the top down so that the join is (top << 8 | next) ... each v_lshl_or_b32 takes one finished group
-#pragma unroll
-                for (int p = 3; p >= 0; p--) {
-                    const int k0 = 8 * q + 2 * p;
-                    if (k0 >= NA) continue;
-                    U32 g = W::sdot4_first(W::ne12(st.AW[k0] ^ Bs), W::splat(0xF8FCFEFFu));
-                    if (k0 + 1 < NA) g = W::sdot4(W::ne12(st.AW[k0 + 1] ^ Bs), W::splat(0x80C0E0F0u), g);
-                    ne = first ? g : W::lshl_or(ne, 8, g);
-                    first = false;
-                }
-                NE[q] = ne;
-                continue;
-            }
 #pragma unroll
             for (int p = 3; p >= 0; p--) {
                 const int k0 = 8 * q + 2 * p;
@@ -194,7 +174,47 @@ struct LevBits {
         // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
         const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
         Q S[8];
+        // COALESCED form (fixed-length batches, with or without a subset list): the wavefront fetches cooperatively.  In load
+        // p (0..3) lane l brings piece c = l & 3 (16 bytes) of pair-slot g = 16 p + (l >> 2): four consecutive lanes read 64
+        // consecutive bytes of one string, so a global_load_dwordx4 touches 16 runs of 64 bytes instead of 64 scattered 16-byte
+        // pieces, and commits them to THAT pair's LDS slot (the compute side still reads its own pair's slot, lane = pair).
+        // The lengths are the batch's, hence the band geometry (nlo, ea, eb) is the same number in every lane.
+        // CSR batches keep the per-lane form below: every lane fetches its own pair's pieces.
+        const bool coop = !P.a.off && !P.b.off;
+        const U32 pc = lane & 3u;                                  // piece of the chunk this lane carries
+        Ptr ah[4], bh[4];
+        Bool vh[4];
+        U32 ea_u = ea, eb_u = eb, alen_u = alen, blen_u = blen;
+        if (coop) {
+            alen_u = W::splat((uint32_t)P.a.len); blen_u = W::splat((uint32_t)P.b.len);
+            const U32 diff_u = W::sel(blen_u >= alen_u, blen_u - alen_u, alen_u - blen_u);
+            const Bool in_u = diff_u <= P.u;
+            const U32 tb_u = W::sel(in_u, (W::splat(P.u) - diff_u) >> 1, W::splat(0));
+            const U32 nlo_u = W::sel(in_u, tb_u + W::sel(blen_u >= alen_u, W::splat(0), diff_u) + (TRANS ? 1u : 0u), W::splat(0));
+            const U32 ca_u = W::splat(T0) - nlo_u;
+            ea_u = ca_u + ((W::splat(16u) - (ca_u & 15u)) & 15u);
+            eb_u = W::splat(T0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const U32 g = (lane >> 2) + 16u * (uint32_t)p;
+                ah[p] = W::shfl_ptr(aptr, g);
+                bh[p] = W::shfl_ptr(bptr, g);
+                vh[p] = W::shfl(W::sel(valid, W::splat(1), W::splat(0)), g) != 0u;
+            }
+        }
+        const U32 a_dst = (lane >> 2) * BITS_SLOT_A + pc * 16u, b_dst = (lane >> 2) * BITS_SLOT_B + pc * 16u + 64u * BITS_SLOT_A;
         auto fetch = [&](uint32_t kc) {
+            if (coop) {
+                const U32 y0 = W::splat(kc * 64u) + pc * 16u;
+                const Bool ina = (ea_u <= y0) & ((y0 - ea_u) < alen_u), inb = (eb_u <= y0) & ((y0 - eb_u) < blen_u);
+                const U32 offa = W::sel(ina, y0 - ea_u, W::splat(0)), offb = W::sel(inb, y0 - eb_u, W::splat(0));
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    S[p] = W::gload16(W::ptr_add(ah[p], offa), vh[p] & ina);
+                    S[4 + p] = W::gload16(W::ptr_add(bh[p], offb), vh[p] & inb);
+                }
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const uint32_t y0 = kc * 64u + 16u * (uint32_t)p;
@@ -207,11 +227,24 @@ struct LevBits {
         auto commit_main = [&]() {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                W::lds_store16(lds, a_slot + 16u * p, S[p], active);
-                W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
+                if (coop) {
+                    W::lds_store16(lds, a_dst + 16u * BITS_SLOT_A * (uint32_t)p, S[p], active);
+                    W::lds_store16(lds, b_dst + 16u * BITS_SLOT_B * (uint32_t)p, S[4 + p], active);
+                } else {
+                    W::lds_store16(lds, a_slot + 16u * p, S[p], active);
+                    W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
+                }
             }
         };
-        auto commit_look = [&]() { W::lds_store16(lds, a_slot + 64u, S[0], active); };
+        // the look-ahead bytes are the NEXT chunk's first piece: S[0] in the per-lane form, the registers of the lanes with pc == 0
+        auto commit_look = [&]() {
+            if (coop) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) W::lds_store16(lds, a_dst + 16u * BITS_SLOT_A * (uint32_t)p + 64u, S[p], pc == 0u);
+            } else {
+                W::lds_store16(lds, a_slot + 64u, S[0], active);
+            }
+        };
         const uint32_t kc0 = tp0 / 64u;
         fetch(kc0);
         commit_main();
@@ -239,14 +272,7 @@ struct LevBits {
                         st.AW[NA - 1] = W::lds_read32u(lds, pa) ^ 0x0C0C0C0Cu;
                         if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
                         const U32 b0 = W::lds_read32u(lds, rb + tp), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
-                        if (!cap && tp + 4u <= p_hi) {
-                            // the common case is straight-line code: the four sub-columns' match vectors do not depend on
-                            // each other, so their v_perm / v_dot4 chains interleave with the serial core of the one before
-                            column<false, 0>(st, b0, M, cnt, active);
-                            column<false, 1>(st, b1, M, cnt, active);
-                            column<false, 2>(st, b2, M, cnt, active);
-                            column<false, 3>(st, b3, M, cnt, active);
-                        } else if (!cap) {                     // the last, partial group of the longest pair
+                        if (!cap) {
                             column<false, 0>(st, b0, M, cnt, active);
                             if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
                             if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);

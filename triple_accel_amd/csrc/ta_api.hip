@@ -43,10 +43,49 @@ int Scratch::ensure(size_t bytes) {
     cap = want;
     return TA_OK;
 }
-Scratch::~Scratch() { /* device memory is reclaimed at process exit; hipFree during TLS teardown is unsafe */ }
+void Scratch::release() {
+    if (dev) (void)hipFree(dev);
+    dev = nullptr; cap = 0;
+}
+Scratch::~Scratch() { /* at thread exit the HIP runtime may already be gone (process teardown): ta_thread_release() is the explicit way */ }
 Scratch &tls_scratch(int which) {
-    static thread_local Scratch s[13];
+    static thread_local Scratch s[TA_SCRATCH_SLOTS];
     return s[which];
+}
+
+int CallCtx::ensure() {
+    if (st && pin) return TA_OK;
+    if (!st) TA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (!pin) {
+        void *h = nullptr, *d = nullptr;
+        TA_HIP(hipHostMalloc(&h, PIN_BYTES, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) d = h;
+        pin = (uint8_t *)h; pin_dev = (uint8_t *)d;
+    }
+    return TA_OK;
+}
+void CallCtx::release() {
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+    if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_dev = nullptr; }
+}
+CallCtx &call_ctx() {
+    static thread_local CallCtx c;
+    return c;
+}
+
+struct LastUse { hipStream_t st = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+static LastUse &last_use() {
+    static thread_local LastUse u;
+    return u;
+}
+StreamGuard::StreamGuard(hipStream_t s) : st(s) {
+    LastUse &u = last_use();
+    if (u.pending && u.st != s && u.ev) (void)hipStreamWaitEvent(s, u.ev, 0);
+}
+StreamGuard::~StreamGuard() {
+    LastUse &u = last_use();
+    if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) { u.ev = nullptr; return; }
+    if (hipEventRecord(u.ev, st) == hipSuccess) { u.st = st; u.pending = true; }
 }
 
 // Test / tuning switches.  They are honoured only when TA_TUNING was set in the environment when the
@@ -282,6 +321,15 @@ int ta_last_launch_info(ta_launch_info *out) {
 
 void ta_free(void *p) { free(p); }
 
+/* Frees what the calling thread holds inside the library: its device scratch, its stream and its pinned staging buffer.
+ * Optional -- a thread that exits without it leaves them to process exit (nothing is freed from a thread-exit hook: the HIP
+ * runtime may already be gone by then). */
+void ta_thread_release(void) {
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < TA_SCRATCH_SLOTS; i++) tls_scratch(i).release();
+    call_ctx().release();
+}
+
 /* ---------------------------------------------------------------- batch API */
 
 int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k,
@@ -292,6 +340,7 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     if (!device_ready()) return TA_ERR_HIP;
     if (n == 0) return TA_OK;
     hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
     uint64_t max_len = 0;
     rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
     if (rc) return rc;
@@ -306,6 +355,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     if (!device_ready()) return TA_ERR_HIP;
     if (n == 0) return TA_OK;
     hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
     uint64_t max_len = 0;
     rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
     if (rc) return rc;
@@ -367,47 +417,73 @@ int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_
     if (rc) return rc;
     if (!device_ready()) return TA_ERR_HIP;
     if (n == 0) return TA_OK;
+    StreamGuard guard((hipStream_t)stream);
     TA_HIP(hamming_batch_launch(view_of(a), view_of(b), (uint32_t)n, out_dev, (hipStream_t)stream));
     return TA_OK;
 }
 
 /* ---------------------------------------------------------------- single-call host API */
 
-// stage one (a, b) pair into thread-local device scratch: [a | slack | b | slack | out]
-static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
-                      ta_strings *sa, ta_strings *sb, uint32_t **out_dev) {
+// One (a, b) pair of a single call.  Short pairs go into the thread's pinned, device-mapped buffer: the kernel reads the
+// strings in place and writes its answer next to them (`*out_host` then reads it after one stream synchronisation).  Long
+// pairs are copied to thread-local device scratch on the thread's stream.  Either way the call runs on the thread's own
+// non-blocking stream `*st`.
+struct Staged {
+    ta_strings sa, sb;
+    uint32_t *out_dev;             // where the kernel writes
+    volatile uint32_t *out_host;   // host view of out_dev (pinned case) or nullptr
+    hipStream_t st;
+};
+static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, Staged *S) {
     if ((!a && a_len) || (!b && b_len)) return TA_ERR_ARG;
     if (a_len > 0xFFFFFFF0ull || b_len > 0xFFFFFFF0ull) return TA_ERR_ARG;
     if (!device_ready()) return TA_ERR_HIP;
-    const size_t a_pad = (a_len + TA_BLOB_SLACK + 255) & ~(size_t)255, b_pad = (b_len + TA_BLOB_SLACK + 255) & ~(size_t)255;
-    Scratch &sc = tls_scratch(0);
-    int rc = sc.ensure(a_pad + b_pad + 256);
+    CallCtx &cx = call_ctx();
+    int rc = cx.ensure();
     if (rc) return rc;
+    S->st = cx.st;
+    const size_t a_pad = (a_len + TA_BLOB_SLACK + 255) & ~(size_t)255, b_pad = (b_len + TA_BLOB_SLACK + 255) & ~(size_t)255;
+    if (a_pad + b_pad <= CallCtx::RESULT_OFF) {
+        if (a_len) memcpy(cx.pin, a, a_len);
+        if (b_len) memcpy(cx.pin + a_pad, b, b_len);
+        S->sa = ta_strings{cx.pin_dev, nullptr, 0, a_len, a_len};
+        S->sb = ta_strings{cx.pin_dev + a_pad, nullptr, 0, b_len, b_len};
+        S->out_dev = (uint32_t *)(cx.pin_dev + CallCtx::RESULT_OFF);
+        S->out_host = (volatile uint32_t *)(cx.pin + CallCtx::RESULT_OFF);
+        return TA_OK;
+    }
+    Scratch &sc = tls_scratch(0);
+    if ((rc = sc.ensure(a_pad + b_pad + 256))) return rc;
     uint8_t *base = (uint8_t *)sc.dev;
-    if (a_len) TA_HIP(hipMemcpyAsync(base, a, a_len, hipMemcpyHostToDevice, 0));
-    if (b_len) TA_HIP(hipMemcpyAsync(base + a_pad, b, b_len, hipMemcpyHostToDevice, 0));
-    *sa = ta_strings{base, nullptr, 0, a_len, a_len};
-    *sb = ta_strings{base + a_pad, nullptr, 0, b_len, b_len};
-    *out_dev = (uint32_t *)(base + a_pad + b_pad);
+    if (a_len) TA_HIP(hipMemcpyAsync(base, a, a_len, hipMemcpyHostToDevice, cx.st));
+    if (b_len) TA_HIP(hipMemcpyAsync(base + a_pad, b, b_len, hipMemcpyHostToDevice, cx.st));
+    S->sa = ta_strings{base, nullptr, 0, a_len, a_len};
+    S->sb = ta_strings{base + a_pad, nullptr, 0, b_len, b_len};
+    S->out_dev = (uint32_t *)(base + a_pad + b_pad);
+    S->out_host = nullptr;
     return TA_OK;
 }
 
-static int fetch_u32(uint32_t *dev, uint32_t *out) {
-    TA_HIP(hipMemcpyAsync(out, dev, 4, hipMemcpyDeviceToHost, 0));
-    TA_HIP(hipStreamSynchronize(0));
+static int fetch_u32(const Staged &S, uint32_t *out) {
+    if (S.out_host) {
+        TA_HIP(hipStreamSynchronize(S.st));
+        *out = *S.out_host;
+        return TA_OK;
+    }
+    TA_HIP(hipMemcpyAsync(out, S.out_dev, 4, hipMemcpyDeviceToHost, S.st));
+    TA_HIP(hipStreamSynchronize(S.st));
     return TA_OK;
 }
 
 int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
     if (!out) return TA_ERR_ARG;
     if (a_len != b_len) return TA_ERR_LEN_MISMATCH;          // src/hamming.rs:318
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(a, a_len, b, b_len, &S);
     if (rc) return rc;
-    rc = ta_hamming_batch(&sa, &sb, 1, od, 0);
+    rc = ta_hamming_batch(&S.sa, &S.sb, 1, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(od, out);
+    return fetch_u32(S, out);
 }
 
 int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
@@ -417,13 +493,12 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
     if (trace_on) return TA_ERR_UNSUPPORTED;
     if (!device_ready()) return TA_ERR_HIP;
     if (a_len == 0 && b_len == 0) { *out = 0; return TA_OK; }   // src/levenshtein.rs:721-727
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(a, a_len, b, b_len, &S);
     if (rc) return rc;
-    rc = ta_levenshtein_k_batch(&sa, &sb, 1, k, costs, od, 0);
+    rc = ta_levenshtein_k_batch(&S.sa, &S.sb, 1, k, costs, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(od, out);
+    return fetch_u32(S, out);
 }
 
 }  // extern "C"
@@ -431,10 +506,12 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
 // trace_on = true beyond the register band (unit costs): row-blocked bit-parallel kernel with 3-bit records + host walk
 static int trace_widebits(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bool swap, uint32_t k, const ta_edit_costs *costs,
                           uint32_t *out, ta_edit **edits, size_t *n_edits, uint64_t rec_words, uint64_t tcols) {
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(x, n, y, m, &S);
     if (rc) return rc;
+    ta_strings &sa = S.sa, &sb = S.sb;
+    uint32_t *od = S.out_dev;
+    hipStream_t tst = S.st;
     Scratch &ts = tls_scratch(9), &bl = tls_scratch(6);
     if ((rc = ts.ensure((size_t)rec_words * 4)) || (rc = bl.ensure((size_t)6 * (m + 66) * 4))) return rc;
     LevParams P;
@@ -445,9 +522,9 @@ static int trace_widebits(const uint8_t *x, size_t n, const uint8_t *y, size_t m
     P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
     P.trace = (uint32_t *)ts.dev; P.trace_cols = tcols;
     P.bnd = (uint32_t *)bl.dev; P.bnd_line = (uint64_t)m + 66;
-    TA_HIP(lev_widebits_trace_launch(P, costs->has_transpose != 0, 0));
+    TA_HIP(lev_widebits_trace_launch(P, costs->has_transpose != 0, tst));
     uint32_t d = 0;
-    rc = fetch_u32(od, &d);
+    rc = fetch_u32(S, &d);
     if (rc) return rc;
     *out = d;
     if (d == TA_NONE) return TA_OK;
@@ -479,10 +556,12 @@ static int trace_widebits(const uint8_t *x, size_t n, const uint8_t *y, size_t m
 // trace_on = true beyond the register band, any EditCosts: the DP wide kernel with 2-bit argmin codes + the usual walk
 static int trace_wide(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bool swap, uint32_t k, const ta_edit_costs *costs,
                       uint32_t *out, ta_edit **edits, size_t *n_edits, uint64_t code_words, uint64_t tcols) {
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(x, n, y, m, &S);
     if (rc) return rc;
+    ta_strings &sa = S.sa, &sb = S.sb;
+    uint32_t *od = S.out_dev;
+    hipStream_t tst = S.st;
     Scratch &ts = tls_scratch(9);
     if ((rc = ts.ensure((size_t)code_words * 4))) return rc;
     LevParams P;
@@ -494,9 +573,9 @@ static int trace_wide(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bo
     P.o = 0; P.L = 0; P.PW = 1; P.Tw = 0; P.ch = 0;
     P.lds_per_wave = (uint32_t)(m + 2);                                         // boundary line length
     P.trace = (uint32_t *)ts.dev; P.trace_cols = tcols;
-    TA_HIP(lev_wide_trace_launch(P, costs->has_transpose != 0, 0));
+    TA_HIP(lev_wide_trace_launch(P, costs->has_transpose != 0, tst));
     uint32_t d = 0;
-    rc = fetch_u32(od, &d);
+    rc = fetch_u32(S, &d);
     if (rc) return rc;
     *out = d;
     if (d == TA_NONE) return TA_OK;
@@ -563,10 +642,12 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
         if (unit) return trace_widebits(x, n, y, m, swap, k, costs, out, edits, n_edits, rec_words, tcols);
         return trace_wide(x, n, y, m, swap, k, costs, out, edits, n_edits, code_words, tcols);
     }
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(x, n, y, m, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(x, n, y, m, &S);
     if (rc) return rc;
+    ta_strings &sa = S.sa, &sb = S.sb;
+    uint32_t *od = S.out_dev;
+    hipStream_t tst = S.st;
     const uint32_t tw = (uint32_t)lev_trace_words(pl.D);
     const size_t taus = (n + m + 1) / 2 + 1;
     const size_t trace_words = taus * 2 * 64 * tw;
@@ -578,9 +659,9 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     P.mc = costs->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = costs->has_transpose ? costs->transpose_cost : 0;
     P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
     P.trace = (uint32_t *)ts.dev;
-    TA_HIP(lev_band_trace_launch(P, pl, sg > 0, costs->has_transpose != 0, 0));
+    TA_HIP(lev_band_trace_launch(P, pl, sg > 0, costs->has_transpose != 0, tst));
     uint32_t d = 0;
-    rc = fetch_u32(od, &d);
+    rc = fetch_u32(S, &d);
     if (rc) return rc;
     *out = d;
     if (d == TA_NONE) return TA_OK;
@@ -642,13 +723,12 @@ int ta_levenshtein_exp_with_opts(const uint8_t *a, size_t a_len, const uint8_t *
     if (trace_on) return TA_ERR_UNSUPPORTED;
     if (!device_ready()) return TA_ERR_HIP;
     if (a_len == 0 && b_len == 0) { *out = 0; return TA_OK; }
-    ta_strings sa, sb;
-    uint32_t *od;
-    int rc = stage_pair(a, a_len, b, b_len, &sa, &sb, &od);
+    Staged S;
+    int rc = stage_pair(a, a_len, b, b_len, &S);
     if (rc) return rc;
-    rc = ta_levenshtein_exp_batch(&sa, &sb, 1, costs, od, 0);
+    rc = ta_levenshtein_exp_batch(&S.sa, &S.sb, 1, costs, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(od, out);
+    return fetch_u32(S, out);
 }
 int ta_levenshtein_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
     ta_edit_costs c = ta_levenshtein_costs();

@@ -22,14 +22,39 @@ void set_last_error_msg(const char *msg);
         }                                                   \
     } while (0)
 
-// Thread-local grow-only device scratch (single-call host API staging).
+// Thread-local grow-only device scratch.
 struct Scratch {
     void *dev = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes);   // TA_OK / TA_ERR_HIP
+    void release();
     ~Scratch();
 };
+constexpr int TA_SCRATCH_SLOTS = 13;
 Scratch &tls_scratch(int which);
+
+// Per-thread context of the single-call host API: its own non-blocking stream (concurrent callers never meet on the null
+// stream) and a pinned, device-mapped staging buffer -- a short pair is memcpy'd there, the kernel reads it in place and
+// writes the answer back into it: one launch and one stream synchronisation per call, no staging copies.
+struct CallCtx {
+    static constexpr size_t PIN_BYTES = 64 * 1024, RESULT_OFF = PIN_BYTES - 64;
+    hipStream_t st = nullptr;
+    uint8_t *pin = nullptr;       // host address
+    uint8_t *pin_dev = nullptr;   // the same bytes as the device addresses them
+    int ensure();                 // TA_OK / TA_ERR_HIP
+    void release();
+};
+CallCtx &call_ctx();
+
+// The batch / *_dev entry points run on the CALLER's stream but keep state in thread-local scratch that their kernels may
+// still be using when the call returns.  A later call from the same thread on a DIFFERENT stream first makes that stream
+// wait (device-side, hipStreamWaitEvent) for the event recorded at the end of the previous call; calls that stay on one
+// stream -- the normal case -- are ordered by the stream itself and cost nothing extra.
+struct StreamGuard {
+    hipStream_t st;
+    explicit StreamGuard(hipStream_t s);
+    ~StreamGuard();
+};
 
 // test / tuning switches: nullptr / 0 unless TA_TUNING was set when the library was loaded (no getenv on the call path)
 bool tuning_enabled();

@@ -69,6 +69,7 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     if (needle_len > 0xFFFFu) { set_last_error_msg("needle longer than 65535 bytes"); return TA_ERR_ARG; }
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
     Scratch &cnt = tls_scratch(2);
     int rc = cnt.ensure(16);
     if (rc) return rc;
@@ -158,6 +159,7 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
     hipStream_t st = (hipStream_t)stream;
     *count_host = 0;
     if (needle_len == 0 || needle_len > haystack_len) return TA_OK;                     // src/hamming.rs:455-461
+    StreamGuard guard(st);
     Scratch &cnt = tls_scratch(2);
     int rc = cnt.ensure(16);
     if (rc) return rc;
@@ -186,6 +188,7 @@ int ta_search_best_hits_dev(const ta_match *hits_dev, uint64_t count, ta_match *
     if (count == 0) return TA_OK;
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
     const uint32_t cap = 1u << 16;                                // best hits kept on the first try (rarely more than a handful)
     Scratch &sel = tls_scratch(12), &cnt = tls_scratch(2);
     int rc;
@@ -248,22 +251,34 @@ static int give(std::vector<ta_match> &v, ta_match **out, size_t *n_out) {
     return TA_OK;
 }
 
-// stage a haystack into device scratch (with read slack) and collect the All-mode hits, sorted by end
+// stage a haystack into device scratch (with read slack) and collect the All-mode hits, sorted by end; everything runs on
+// the calling thread's own stream.  The hit buffer starts at min(haystack_len + 2, 4M) records; a denser result (All mode
+// over a big haystack, k >= needle_len) reports its true count, and the pass is repeated once with room for exactly that.
 template <class Launch>
 static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::vector<ta_match> &hits, Launch launch) {
     if (!device_ready()) return TA_ERR_HIP;
-    Scratch &hs = tls_scratch(0), &ob = tls_scratch(1);
-    int rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64);
+    CallCtx &cx = call_ctx();
+    int rc = cx.ensure();
     if (rc) return rc;
+    Scratch &hs = tls_scratch(0), &ob = tls_scratch(1);
+    if ((rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64))) return rc;
     size_t cap = haystack_len + 2;
-    if (cap > (1u << 26)) cap = (1u << 26);
+    if (cap > (1u << 22)) cap = (1u << 22);
     if ((rc = ob.ensure(cap * sizeof(ta_match)))) return rc;
-    if (haystack_len) TA_HIP(hipMemcpyAsync(hs.dev, haystack, haystack_len, hipMemcpyHostToDevice, 0));
+    if (haystack_len) TA_HIP(hipMemcpyAsync(hs.dev, haystack, haystack_len, hipMemcpyHostToDevice, cx.st));
     uint64_t count = 0;
-    rc = launch((const uint8_t *)hs.dev, (ta_match *)ob.dev, cap, &count);
+    rc = launch((const uint8_t *)hs.dev, (ta_match *)ob.dev, cap, &count, cx.st);
+    if (rc == TA_ERR_CAPACITY && count > cap && count <= (uint64_t)haystack_len + 2) {
+        cap = (size_t)count;
+        if ((rc = ob.ensure(cap * sizeof(ta_match)))) return rc;
+        rc = launch((const uint8_t *)hs.dev, (ta_match *)ob.dev, cap, &count, cx.st);
+    }
     if (rc) return rc;
     hits.resize(count);
-    if (count) TA_HIP(hipMemcpy(hits.data(), ob.dev, count * sizeof(ta_match), hipMemcpyDeviceToHost));
+    if (count) {
+        TA_HIP(hipMemcpyAsync(hits.data(), ob.dev, count * sizeof(ta_match), hipMemcpyDeviceToHost, cx.st));
+        TA_HIP(hipStreamSynchronize(cx.st));
+    }
     std::sort(hits.begin(), hits.end(), [](const ta_match &x, const ta_match &y) {
         return x.end != y.end ? x.end < y.end : x.start < y.start;
     });
@@ -295,9 +310,9 @@ int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_le
     }
     if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;   // :1965
     std::vector<ta_match> hits;
-    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt) {
+    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         if (haystack_len == 0) { *cnt = 0; return (int)TA_OK; }
-        return ta_levenshtein_search_dev(needle, needle_len, hd, haystack_len, k, costs, anchored, 0, 0, od, cap, cnt, 0);
+        return ta_levenshtein_search_dev(needle, needle_len, hd, haystack_len, k, costs, anchored, 0, 0, od, cap, cnt, st);
     });
     if (rc) return rc;
     // the match that ends before the first haystack byte (:1693-1706, SIMD :2394-2399)
@@ -324,8 +339,8 @@ int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
     if (needle_len > haystack_len) return TA_OK;                                // src/hamming.rs:455-457
     if (needle_len == 0) return TA_OK;                                          // :459-461
     std::vector<ta_match> hits;
-    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt) {
-        return ta_hamming_search_dev(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, 0);
+    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
+        return ta_hamming_search_dev(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, st);
     });
     if (rc) return rc;
     if (search_type == TA_SEARCH_BEST) hits.resize(ta_search_fold_best(hits.data(), hits.size(), k, 0));

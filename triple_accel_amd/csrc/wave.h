@@ -91,8 +91,6 @@ struct DevWave {
     // statements (a v_dot4 result consumed by an asm VALU instruction two slots later read a stale value on gfx950).
     // (a << s) + b -> v_lshl_add_u32
     static __device__ __forceinline__ U32 lshl_add(U32 a, uint32_t s, U32 b) { return (a << s) + b; }
-    // (a << s) | b -> v_lshl_or_b32
-    static __device__ __forceinline__ U32 lshl_or(U32 a, uint32_t s, U32 b) { return (a << s) | b; }
     // per-lane shift amounts (< 32)
     static __device__ __forceinline__ U32 shlv(U32 x, U32 s) { return x << s; }
     static __device__ __forceinline__ U32 shrv(U32 x, U32 s) { return x >> s; }
