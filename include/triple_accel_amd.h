@@ -162,6 +162,13 @@ int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
                                      uint32_t k, int search_type, ta_match **out, size_t *n_out);
 int ta_hamming_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
                       ta_match **out, size_t *n_out);
+/* hamming_search_naive_with_opts, src/hamming.rs:96-146 (and hamming_search_naive :70 with k = ceil(n/2), Best): the scalar
+ * routine's contract -- no NUL-byte panic, an empty needle matches with k = 0 at every offset 0..=haystack_len. */
+int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
+                                      const uint8_t *haystack, size_t haystack_len,
+                                      uint32_t k, int search_type, ta_match **out, size_t *n_out);
+/* Limits of the host search forms: needles up to 65,535 bytes (TA_ERR_ARG beyond); the result list is bounded only by memory
+ * (a pass that overflows its first hit buffer is repeated once with room for the count it reported). */
 void ta_free(void *p);
 
 /* Threading.  Every entry point may be called from any number of threads at once.  The single-call host functions

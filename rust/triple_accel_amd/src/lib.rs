@@ -4,7 +4,14 @@
 //! Callers keep `use triple_accel::*;` unchanged.  Differences, all documented in INTEGRATION.md:
 //! * search functions return an eager iterator (the GPU scans the whole haystack at once);
 //! * there is no CPU fallback below this layer: without a usable GPU the calls panic with the HIP status;
-//! * tracebacks of bands wider than 4,224 diagonals are not on the GPU path (`levenshtein_*_with_opts` panics there).
+//! * tracebacks needing more than 8 GB of device records (about 140K x 140K bytes) are refused (`levenshtein_*_with_opts`
+//!   panics there with the library's status);
+//! * every function implements the reference's SCALAR rules.  On an AVX2/SSE4.1 host the reference's own
+//!   `levenshtein_simd_k_with_opts` / `levenshtein_search_simd_with_opts` take its SIMD cores instead, whose transposition
+//!   is an unconditional blend (src/levenshtein.rs:2384-2388) where the scalar path tests `<=` (:517-525), and whose
+//!   tracebacks / match starts can differ from the scalar ones on ties.  Where the two disagree this crate returns the
+//!   scalar answer under both names (INTEGRATION.md section 5 lists the cases);
+//! * the generic `T: PartialEq` entry points map their items onto bytes: more than 256 distinct items panic.
 use std::os::raw::{c_int, c_void};
 
 #[derive(Debug, PartialEq)]
@@ -41,6 +48,8 @@ mod ffi {
                                                     out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_hamming_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                 search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
+        pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
+                                                 search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
     }
     /// status codes -> the reference's panics (src/hamming.rs:318, src/lib.rs:240, src/levenshtein.rs:44-52,69)
@@ -79,6 +88,24 @@ pub mod hamming {
     /// same result contract as `hamming` (src/hamming.rs:317, :354): one GPU kernel serves them all
     pub fn hamming_simd_parallel(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
     pub fn hamming_simd_movemask(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+    /// src/hamming.rs:36 (same assert, same count)
+    pub fn hamming_naive(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+    /// src/hamming.rs:176, :249 -- the word-wise CPU routines need `alloc_str` buffers there; here any slice will do
+    pub fn hamming_words_64(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+    pub fn hamming_words_128(a: &[u8], b: &[u8]) -> u32 { hamming(a, b) }
+
+    /// src/hamming.rs:96 -- the scalar routine's contract: no NUL-byte panic, an empty needle matches at every offset
+    pub fn hamming_search_naive_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType)
+        -> Box<dyn Iterator<Item = Match> + 'a> {
+        let (mut p, mut n) = (std::ptr::null_mut::<TaMatch>(), 0usize);
+        check(unsafe { ta_hamming_search_naive_with_opts(needle.as_ptr(), needle.len(), haystack.as_ptr(), haystack.len(), k,
+                                                         (search_type == SearchType::Best) as c_int, &mut p, &mut n) });
+        Box::new(unsafe { take_matches(p, n) }.into_iter())
+    }
+    /// src/hamming.rs:70
+    pub fn hamming_search_naive<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        hamming_search_naive_with_opts(needle, haystack, ((needle.len() as u32) >> 1) + ((needle.len() as u32) & 1), SearchType::Best)
+    }
 
     /// src/hamming.rs:454
     pub fn hamming_search_simd_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType)
@@ -178,6 +205,79 @@ pub mod levenshtein {
     pub fn levenshtein_search<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
         levenshtein_search_simd(needle, haystack)
     }
+
+    // ---- the scalar entry points: the kernels implement the scalar rules, so these are the same calls under the other names
+
+    /// items of any `T: PartialEq` -> bytes over one code table shared by both strings (at most 256 distinct items)
+    fn symbols<'x, T: PartialEq>(a: &'x [T], b: &'x [T]) -> (Vec<u8>, Vec<u8>) {
+        fn code<'x, T: PartialEq>(table: &mut Vec<&'x T>, x: &'x T) -> u8 {
+            match table.iter().position(|d| **d == *x) {
+                Some(i) => i as u8,
+                None => {
+                    assert!(table.len() < 256, "triple_accel_amd: more than 256 distinct symbols cannot be mapped onto the byte kernels");
+                    table.push(x);
+                    (table.len() - 1) as u8
+                }
+            }
+        }
+        let mut table: Vec<&'x T> = Vec::with_capacity(256);
+        let ta: Vec<u8> = a.iter().map(|x| code(&mut table, x)).collect();
+        let tb: Vec<u8> = b.iter().map(|x| code(&mut table, x)).collect();
+        (ta, tb)
+    }
+    /// src/levenshtein.rs:148
+    pub fn levenshtein_naive_with_opts<T: PartialEq>(a: &[T], b: &[T], trace_on: bool, costs: EditCosts) -> (u32, Option<Vec<Edit>>) {
+        let (ta, tb) = symbols(a, b);
+        levenshtein_simd_k_with_opts(&ta, &tb, u32::MAX, trace_on, costs).unwrap()
+    }
+    /// src/levenshtein.rs:105
+    pub fn levenshtein_naive<T: PartialEq>(a: &[T], b: &[T]) -> u32 { levenshtein_naive_with_opts(a, b, false, LEVENSHTEIN_COSTS).0 }
+    /// src/levenshtein.rs:123 (the reference's spelling)
+    pub fn levenstein_naive_str(a: &str, b: &str) -> u32 {
+        let (a, b): (Vec<char>, Vec<char>) = (a.chars().collect(), b.chars().collect());
+        levenshtein_naive(&a, &b)
+    }
+    /// src/levenshtein.rs:376
+    pub fn levenshtein_naive_k_with_opts<T: PartialEq>(a: &[T], b: &[T], k: u32, trace_on: bool, costs: EditCosts)
+        -> Option<(u32, Option<Vec<Edit>>)> {
+        let (ta, tb) = symbols(a, b);
+        levenshtein_simd_k_with_opts(&ta, &tb, k, trace_on, costs)
+    }
+    /// src/levenshtein.rs:342
+    pub fn levenshtein_naive_k(a: &[u8], b: &[u8], k: u32) -> Option<u32> { levenshtein_simd_k(a, b, k) }
+    /// src/levenshtein.rs:609-651: ASCII strings as they are, anything else through a table of at most 256 distinct chars
+    pub fn levenshtein_simd_k_str(a: &str, b: &str, k: u32) -> Option<u32> {
+        if a.is_ascii() && b.is_ascii() {
+            return levenshtein_simd_k(a.as_bytes(), b.as_bytes(), k);
+        }
+        let mut chars: Vec<char> = Vec::with_capacity(256);
+        let mut translate = |s: &str| -> Option<Vec<u8>> {
+            s.chars().map(|c| match chars.iter().position(|&d| c == d) {
+                Some(i) => Some(i as u8),
+                None => { let idx = chars.len(); if idx < 256 { chars.push(c); Some(idx as u8) } else { None } }
+            }).collect()
+        };
+        let ta = translate(a)?;
+        let tb = translate(b)?;
+        levenshtein_simd_k(&ta, &tb, k)
+    }
+    /// src/levenshtein.rs:1589
+    pub fn levenshtein_search_naive_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType,
+                                                   costs: EditCosts, anchored: bool) -> Box<dyn Iterator<Item = Match> + 'a> {
+        levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored)
+    }
+    /// src/levenshtein.rs:1549
+    pub fn levenshtein_search_naive<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
+        levenshtein_search_simd(needle, haystack)
+    }
+}
+
+/// src/lib.rs:197 (the reference pads and aligns for its u128 Hamming routines; the bytes are what matters here)
+pub fn alloc_str(len: usize) -> Vec<u8> { vec![0u8; len] }
+/// src/lib.rs:229
+pub fn fill_str(dest: &mut [u8], src: &[u8]) {
+    assert!(dest.len() >= src.len());
+    dest[..src.len()].copy_from_slice(src);
 }
 
 // src/lib.rs:126-127

@@ -1,0 +1,33 @@
+"""How much of the band kernel's time is memory?  The same launch (1M pairs, 256 B, k = 32) with every pair reading the SAME
+256 bytes (stride 0: all hits in L1/L2, no HBM traffic) against the real batch; and the real batch at several occupancies."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import datagen as Dg
+import triple_accel_amd as T
+from triple_accel_amd import batch as B
+
+n, L, k = 1_000_000, 256, 32
+a, b = Dg.pairs_random(0x7A02, n, L)
+sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+out = torch.empty(n, dtype=torch.int32, device="cuda")
+
+def dev_ms(fa, fb, reps=50):
+    for _ in range(5): B.levenshtein_k_batch(fa, fb, k, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): B.levenshtein_k_batch(fa, fb, k, out=out)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+s0a = B.Strings(sa.blob, None, stride=0, length=L, n=n)
+s0b = B.Strings(sb.blob, None, stride=0, length=L, n=n)
+print("real batch           %.4f ms" % dev_ms(sa, sb), T.last_launch_info())
+print("stride 0 (no HBM)    %.4f ms" % dev_ms(s0a, s0b))
+for env in sys.argv[1:]:
+    kv = dict(x.split("=") for x in env.split(",")) if env else {}
+    os.environ.update(kv)
+    print("%-40s %.4f ms  lds %d grid %d" % (env, dev_ms(sa, sb), T.last_launch_info()["lds_bytes"], T.last_launch_info()["grid"]))
+    for key in kv: os.environ.pop(key)

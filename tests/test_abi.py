@@ -68,3 +68,46 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "ta_oracle" not in text and "oracle_lib" not in text and "libta_emu" not in text, f
+
+
+def _c_arity(header, name):
+    m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, re.S)
+    assert m, name
+    args = m.group(1).strip()
+    return 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+
+
+def test_rust_shim_extern_block_matches_the_header():
+    """Every `extern "C"` item of rust/triple_accel_amd/src/lib.rs is declared in include/triple_accel_amd.h with the same
+    number of parameters (there is no rustc here to do the check)."""
+    header = open(os.path.join(ROOT, "include", "triple_accel_amd.h")).read()
+    rs = open(os.path.join(ROOT, "rust", "triple_accel_amd", "src", "lib.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n    }")]
+    fns = re.findall(r"pub fn (ta_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->\s*[A-Za-z_0-9:]+)?\s*;", block, re.S)
+    assert len(fns) >= 10
+    for name, args in fns:
+        n_rs = len([a for a in args.split(",") if a.strip()])
+        assert n_rs == _c_arity(header, name), (name, n_rs, _c_arity(header, name))
+
+
+def test_every_reference_pub_fn_has_a_mirror():
+    """The drop-in claim, name by name: the reference's public functions (the list below was read off
+    /root/reference/src/{lib,levenshtein,hamming}.rs `pub fn` lines) exist in the Python mirror and in
+    the Rust shim's text."""
+    import triple_accel_amd as T
+    names = ["alloc_str", "fill_str",
+             "levenshtein_naive", "levenstein_naive_str", "levenshtein_naive_with_opts", "levenshtein_naive_k",
+             "levenshtein_naive_k_with_opts", "levenshtein_simd_k_str", "levenshtein_simd_k", "levenshtein_simd_k_with_opts",
+             "levenshtein", "rdamerau", "levenshtein_exp", "levenshtein_exp_with_opts", "rdamerau_exp",
+             "levenshtein_search_naive", "levenshtein_search_naive_with_opts", "levenshtein_search_simd",
+             "levenshtein_search_simd_with_opts", "levenshtein_search",
+             "hamming_naive", "hamming_search_naive", "hamming_search_naive_with_opts", "hamming_words_64", "hamming_words_128",
+             "hamming_simd_parallel", "hamming_simd_movemask", "hamming", "hamming_search_simd", "hamming_search_simd_with_opts",
+             "hamming_search"]
+    rs = open(os.path.join(ROOT, "rust", "triple_accel_amd", "src", "lib.rs")).read()
+    for n in names:
+        assert hasattr(T, n), n
+        assert re.search(r"pub fn %s\b" % n, rs), n
+    for t in ("Match", "Edit", "EditType", "SearchType", "EditCosts", "LEVENSHTEIN_COSTS", "RDAMERAU_COSTS"):
+        assert hasattr(T, t) and re.search(r"pub (struct|enum|const) %s\b" % t, rs), t

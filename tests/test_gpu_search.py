@@ -274,3 +274,40 @@ def test_best_hits_selected_on_the_device():
         got = TD.fold_best(head + [tuple(int(v) for v in r) for r in best_rows], k, True)
         assert got == TD.fold_best(head + [tuple(int(v) for v in r) for r in allhits], k, True)
         assert got == O.levenshtein_search_naive_with_opts(needle, hay, k, O.BEST, costs, False), (trial, n, k)
+
+
+def test_hamming_search_naive_contract():
+    """hamming_search_naive_with_opts (src/hamming.rs:96-146): NUL bytes in the haystack are legal, an empty needle matches
+    with k = 0 at every offset -- unlike the SIMD-contract entry, which panics / returns nothing there."""
+    import triple_accel_amd as T
+    g = Dg.rng(19)
+    hay = bytearray(g.integers(0, 4, size=4000, dtype=np.uint8).tobytes())      # plenty of NUL bytes
+    for n in (1, 2, 5, 33, 40):
+        needle = bytes(hay[700:700 + n])
+        for k in (0, 1, n // 2):
+            for st in (O.ALL, O.BEST):
+                want = O.hamming_search_naive_with_opts(needle, bytes(hay), k, st)
+                assert [tuple(m) for m in T.hamming_search_naive_with_opts(needle, bytes(hay), k, st)] == want, (n, k, st)
+    for st in (O.ALL, O.BEST):
+        assert [tuple(m) for m in T.hamming_search_naive_with_opts(b"", b"abc", 2, st)] == O.hamming_search_naive_with_opts(b"", b"abc", 2, st)
+    assert [tuple(m) for m in T.hamming_search_naive(b"abc", b"  abd")] == [(2, 5, 1)]      # the doc-test of src/hamming.rs:66
+    assert list(T.hamming_search_naive(b"abcd", b"abc")) == []
+
+
+def test_scalar_names_are_the_same_engine():
+    """The reference's scalar entry points under their own names: generic items (chars, ints) ride a code table."""
+    import triple_accel_amd as T
+    assert T.levenshtein_naive(b"abc", b"ab") == 1 and T.levenstein_naive_str("abc", "ab") == 1
+    assert T.levenstein_naive_str("naïve café", "naive cafe") == 2
+    assert T.levenshtein_naive([10, 2000, 30, 70000], [10, 30, 70000, 5]) == 2
+    d, tr = T.levenshtein_naive_with_opts(b"abc", b"ab", True, T.LEVENSHTEIN_COSTS)
+    assert d == 1 and [tuple(e) for e in tr] == [("Match", 2), ("BGap", 1)]               # doc-test of src/levenshtein.rs:143
+    assert T.levenshtein_naive_k(b"abc", b"ab", 1) == 1 and T.levenshtein_naive_k(b"abc", b"", 1) is None
+    assert T.levenshtein_naive_k_with_opts("abcd", "abdc", 1, False, T.RDAMERAU_COSTS) == (1, None)
+    assert [tuple(m) for m in T.levenshtein_search_naive(b"abc", b"  abd")] == [tuple(m) for m in T.levenshtein_search(b"abc", b"  abd")]
+    with pytest.raises(NotImplementedError):
+        T.levenshtein_naive(list(range(300)), list(range(300)))
+    with pytest.raises(TypeError):
+        T.levenshtein(5, b"abc")
+    with pytest.raises(OverflowError):
+        T.levenshtein_simd_k(b"a", b"b", 1 << 32)

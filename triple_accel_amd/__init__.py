@@ -137,6 +137,20 @@ def hamming_search_simd(needle, haystack):
 hamming_search = hamming_search_simd   # src/hamming.rs:588
 
 
+def hamming_search_naive_with_opts(needle, haystack, k, search_type):
+    """src/hamming.rs:96 -- the scalar routine's contract: NUL bytes are fine, an empty needle matches everywhere."""
+    needle, haystack = _b(needle), _b(haystack)
+    return _matches(_n.lib().ta_hamming_search_naive_with_opts, needle, len(needle), haystack, len(haystack), _k(k),
+                    search_type)
+
+
+def hamming_search_naive(needle, haystack):
+    """src/hamming.rs:70"""
+    needle = _b(needle)
+    return hamming_search_naive_with_opts(needle, haystack, (len(needle) >> 1) + (len(needle) & 1), SearchType.Best)
+
+
+
 # ---------------------------------------------------------------- levenshtein (src/levenshtein.rs)
 _EDIT_NAMES = [EditType.Match, EditType.Mismatch, EditType.AGap, EditType.BGap, EditType.Transpose]
 
@@ -280,3 +294,69 @@ def rdamerau_simd_k(a, b, k):
     """convenience: levenshtein_simd_k_with_opts(a, b, k, false, RDAMERAU_COSTS) -> Option<u32>"""
     r = levenshtein_simd_k_with_opts(a, b, k, False, RDAMERAU_COSTS)
     return None if r is None else r[0]
+
+
+# ---- the reference's scalar entry points (same result contract as the kernels implement: the scalar path IS the
+# bit-exactness target), under their own names so that callers of any reference `pub fn` are unchanged
+hamming_naive = hamming                                   # src/hamming.rs:36
+
+
+def _symbols(*seqs):
+    """Sequences of arbitrary equality-comparable items -> byte strings over a shared code table (the generic `T: PartialEq`
+    entry points, src/levenshtein.rs:105, :148, :376).  More than 256 distinct items cannot ride the byte path."""
+    table, outs = [], []
+    for s in seqs:
+        if isinstance(s, (bytes, bytearray)):
+            outs.append(None)
+            continue
+        o = bytearray()
+        for x in s:
+            try:
+                i = table.index(x)
+            except ValueError:
+                if len(table) >= 256:
+                    raise NotImplementedError("triple_accel_amd: more than 256 distinct symbols cannot be mapped onto the byte kernels")
+                table.append(x)
+                i = len(table) - 1
+            o.append(i)
+        outs.append(bytes(o))
+    if any(o is None for o in outs):                      # byte strings go through unchanged (all of them must then be bytes)
+        return [bytes(s) for s in seqs]
+    return outs
+
+
+def levenshtein_naive_with_opts(a, b, trace_on, costs):
+    """src/levenshtein.rs:148 -> (distance, None | [Edit])"""
+    a, b = _symbols(a, b)
+    return levenshtein_simd_k_with_opts(a, b, 0xFFFFFFFF, trace_on, costs)
+
+
+def levenshtein_naive(a, b):
+    """src/levenshtein.rs:105"""
+    return levenshtein_naive_with_opts(a, b, False, LEVENSHTEIN_COSTS)[0]
+
+
+def levenstein_naive_str(a: str, b: str):
+    """src/levenshtein.rs:123 (the reference's spelling) -- over chars, not bytes"""
+    return levenshtein_naive(list(a), list(b))
+
+
+def levenshtein_naive_k_with_opts(a, b, k, trace_on, costs):
+    """src/levenshtein.rs:376"""
+    a, b = _symbols(a, b)
+    return levenshtein_simd_k_with_opts(a, b, k, trace_on, costs)
+
+
+def levenshtein_naive_k(a, b, k):
+    """src/levenshtein.rs:342"""
+    return levenshtein_simd_k(a, b, k)
+
+
+def levenshtein_search_naive_with_opts(needle, haystack, k, search_type, costs, anchored):
+    """src/levenshtein.rs:1589"""
+    return levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored)
+
+
+def levenshtein_search_naive(needle, haystack):
+    """src/levenshtein.rs:1549"""
+    return levenshtein_search_simd(needle, haystack)

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_exp_trace", "ta_levenshtein_simd_k",
     "ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_levenshtein_exp_with_opts", "ta_rdamerau_exp",
     "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
-    "ta_hamming_search", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
+    "ta_hamming_search", "ta_hamming_search_naive_with_opts", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
 ]
 
@@ -114,6 +114,7 @@ def lib():
     sig("ta_levenshtein_search", i32, [u8p, sz, u8p, sz, mpp, szp])
     sig("ta_hamming_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])
     sig("ta_hamming_search", i32, [u8p, sz, u8p, sz, mpp, szp])
+    sig("ta_hamming_search_naive_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])
     sig("ta_free", None, [C.c_void_p])
     sig("ta_thread_release", None, [])
     sig("ta_levenshtein_k_batch", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p])

@@ -33,17 +33,20 @@ static hipError_t launch_na(const LevParams &P, bool trans, bool stat, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
+hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out) {
+    LevParams P = P0;
+    if (env_int("TA_BITS_NO_COOP")) P.tune |= 1u;
     const uint32_t waves = (P.n + 63u) / 64u;
     // 4 waves per block while four rings fit a quarter of the CU's LDS; else one wave per block so that the CU packs
-    // as many waves as the LDS holds
-    const uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
+    // as many waves as the LDS holds.  TA_BITS_WPB pins the waves per block, TA_BITS_BLOCK_LDS the block's LDS request
+    // (= the resident blocks per CU), for the occupancy sweeps of profiles/.
+    uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
+    if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t grid = (waves + wpb - 1) / wpb;
     // Strings longer than one 128-byte line: three blocks (12 waves) per CU instead of the four the rings would allow.  The
     // issue slots are full either way (same run time on cfg2), and a quarter fewer pairs in flight lets the 4 MB L2 keep
-    // more lines until their second half is read (FETCH_SIZE 0.8-1.5 GB against 1.0-1.8 GB, box to box; 516 MB of
-    // strings).  TA_BITS_BLOCK_LDS overrides.
+    // more lines until their second half is read.
     size_t lds = (size_t)pl.lds_per_wave * wpb;
     if (wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
     if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }

@@ -180,7 +180,7 @@ struct LevBits {
         // pieces, and commits them to THAT pair's LDS slot (the compute side still reads its own pair's slot, lane = pair).
         // The lengths are the batch's, hence the band geometry (nlo, ea, eb) is the same number in every lane.
         // CSR batches keep the per-lane form below: every lane fetches its own pair's pieces.
-        const bool coop = !P.a.off && !P.b.off;
+        const bool coop = !P.a.off && !P.b.off && !(P.tune & 1u);
         const U32 pc = lane & 3u;                                  // piece of the chunk this lane carries
         Ptr ah[4], bh[4];
         Bool vh[4];

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -167,6 +168,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     }
     // fixed-length batches with a band of 25..45 diagonals: 32 pairs per register, three band cells per lane (lev_sliced.hip);
     // opt-in -- fewer instructions than the bit-parallel band kernel but bound by the refetch of its string lines
+#ifdef TA_EXPERIMENTAL
     uint32_t sl_strips = 0;
     const bool sliced = ch.kernel == LEV_K_BITS && unit && !trans && !subset && !dp_forced && env_int("TA_FORCE_SLICED") &&
                         lev_sliced_applies(P.a, P.b, bp.u, &sl_strips);
@@ -175,7 +177,9 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         TA_HIP(lev_sliced_launch(P.a, P.b, n_work, k, bp.u, out_dev, st, &grid, &lds, &ppw));
         li.kernel = 5; li.diags_per_lane = 3; li.lanes_per_pair = sl_strips; li.pairs_per_wave = ppw;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
-    } else if (ch.kernel == LEV_K_BITS) {
+    } else
+#endif
+    if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits_launch(P, bp, trans, max_len, st, &grid, &lds));
@@ -248,7 +252,11 @@ using namespace ta;
 
 extern "C" {
 
-const char *ta_version(void) { return "triple_accel_amd 0.1 (gfx950)"; }
+#ifdef TA_EXPERIMENTAL
+const char *ta_version(void) { return "triple_accel_amd 0.2 (gfx950) +experimental"; }
+#else
+const char *ta_version(void) { return "triple_accel_amd 0.2 (gfx950)"; }
+#endif
 
 const char *ta_status_str(int s) {
     switch (s) {
@@ -450,6 +458,7 @@ static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b
         S->sb = ta_strings{cx.pin_dev + a_pad, nullptr, 0, b_len, b_len};
         S->out_dev = (uint32_t *)(cx.pin_dev + CallCtx::RESULT_OFF);
         S->out_host = (volatile uint32_t *)(cx.pin + CallCtx::RESULT_OFF);
+        *S->out_host = TA_SLOT_EMPTY;
         return TA_OK;
     }
     Scratch &sc = tls_scratch(0);
@@ -464,8 +473,22 @@ static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b
     return TA_OK;
 }
 
-static int fetch_u32(const Staged &S, uint32_t *out) {
+// `single_store`: the call was ONE kernel whose only write to the result slot is its answer.  The slot then starts out as a
+// value no answer can take, and the host watches the pinned word instead of going through the runtime's completion
+// machinery (the store becomes visible no later than the kernel's end-of-kernel release); after 20 ms without an answer the
+// ordinary stream synchronisation takes over (and reports a fault, if that is what happened).
+constexpr uint32_t TA_SLOT_EMPTY = 0xFFFFFFFEu;    // distances stay below 0xFFFFFFF0, None is 0xFFFFFFFF
+static int fetch_u32(const Staged &S, uint32_t *out, bool single_store = false) {
     if (S.out_host) {
+        if (single_store) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spin = 0; *S.out_host == TA_SLOT_EMPTY; spin++) {
+                __builtin_ia32_pause();
+                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+            const uint32_t v = *S.out_host;
+            if (v != TA_SLOT_EMPTY) { *out = v; return TA_OK; }
+        }
         TA_HIP(hipStreamSynchronize(S.st));
         *out = *S.out_host;
         return TA_OK;
@@ -483,7 +506,7 @@ int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, u
     if (rc) return rc;
     rc = ta_hamming_batch(&S.sa, &S.sb, 1, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(S, out);
+    return fetch_u32(S, out, true);
 }
 
 int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
@@ -498,7 +521,7 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
     if (rc) return rc;
     rc = ta_levenshtein_k_batch(&S.sa, &S.sb, 1, k, costs, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(S, out);
+    return fetch_u32(S, out, true);      // (pairs that fit the pinned buffer are always a single kernel)
 }
 
 }  // extern "C"

@@ -151,9 +151,12 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     return c > cap ? TA_ERR_CAPACITY : TA_OK;
 }
 
-int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
-                          const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
-                          uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+}  // extern "C"
+
+// shared by the SIMD-contract entry (NUL bytes in the haystack are an error, src/hamming.rs:463) and the naive-contract one
+static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len,
+                                   const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                                   uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream, bool check_nul) {
     if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
@@ -164,7 +167,7 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
     int rc = cnt.ensure(16);
     if (rc) return rc;
     TA_HIP(hipMemsetAsync(cnt.dev, 0, 16, st));
-    TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, (uint32_t *)((uint8_t *)cnt.dev + 8), st));   // :463
+    if (check_nul) TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, (uint32_t *)((uint8_t *)cnt.dev + 8), st));   // :463
     SearchParams P;
     fill_params(P, needle_host, needle_len, haystack_dev, haystack_len, k, nullptr, 0, base, 0, hits_dev, cap,
                 (unsigned long long *)cnt.dev);
@@ -179,6 +182,14 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
     if ((uint32_t)c[1]) return TA_ERR_NULL_BYTE;
     *count_host = c[0];
     return c[0] > cap ? TA_ERR_CAPACITY : TA_OK;
+}
+
+extern "C" {
+
+int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
+                          const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                          uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+    return hamming_search_dev_impl(needle_host, needle_len, haystack_dev, haystack_len, k, base, hits_dev, cap, count_host, stream, true);
 }
 
 // The hits of a device-resident All-mode result that can survive the Best fold -- those with the smallest k -- sorted by end.
@@ -341,6 +352,29 @@ int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
     std::vector<ta_match> hits;
     int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         return ta_hamming_search_dev(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, st);
+    });
+    if (rc) return rc;
+    if (search_type == TA_SEARCH_BEST) hits.resize(ta_search_fold_best(hits.data(), hits.size(), k, 0));
+    return give(hits, out, n_out);
+}
+
+/* hamming_search_naive_with_opts (src/hamming.rs:96-146): the same scan under the scalar routine's contract -- NUL bytes in the
+ * haystack are fine, and an empty needle matches (with k = 0) at every offset 0..=haystack_len. */
+int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
+                                      const uint8_t *haystack, size_t haystack_len,
+                                      uint32_t k, int search_type, ta_match **out, size_t *n_out) {
+    if (!out || !n_out || (!needle && needle_len) || (!haystack && haystack_len)) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (needle_len > haystack_len) return TA_OK;                                // :100-102
+    std::vector<ta_match> hits;
+    if (needle_len == 0) {                                                      // the loop body never runs: final_res = 0 everywhere
+        if (!device_ready()) return TA_ERR_HIP;
+        hits.reserve(haystack_len + 1);
+        for (size_t i = 0; i <= haystack_len; i++) hits.push_back(ta_match{i, i, 0u, 0u});
+        return give(hits, out, n_out);
+    }
+    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
+        return hamming_search_dev_impl(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, st, false);
     });
     if (rc) return rc;
     if (search_type == TA_SEARCH_BEST) hits.resize(ta_search_fold_best(hits.data(), hits.size(), k, 0));
