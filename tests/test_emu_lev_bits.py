@@ -149,7 +149,8 @@ def test_bits_byte_values_around_the_perm_selector_codes(trans):
             assert got == oracle(a, b, k, trans), (alpha[:4], k, na, static)
 
 
-# ---- fixed-length (strided) batches take the COALESCED fetch form: four lanes per pair bring 64 consecutive bytes
+# ---- fixed-length (strided) batches take the LINE form: every 128-byte line of a string is fetched once, whole, and handed to
+# LDS piece by piece (lev_bits_body.h)
 def _fixed_batch(seed, n, la, lb, k, alpha=26, swaps=False):
     g = Dg.rng(seed)
     a = g.integers(97, 97 + alpha, size=(n, la), dtype=np.uint8)
@@ -166,7 +167,9 @@ def _fixed_batch(seed, n, la, lb, k, alpha=26, swaps=False):
 
 @pytest.mark.parametrize("la,lb,k,trans", [(256, 256, 32, False), (128, 128, 8, True), (100, 93, 12, False), (61, 70, 20, True),
                                            (300, 300, 60, False), (17, 17, 3, False), (200, 215, 127, False), (1, 1, 1, False),
-                                           (64, 64, 0, False), (130, 129, 33, True)])
+                                           (64, 64, 0, False), (130, 129, 33, True), (700, 690, 40, False), (513, 530, 19, True),
+                                           (1000, 1000, 100, False), (128, 128, 5, False), (127, 129, 6, True), (16, 16, 16, False),
+                                           (400, 385, 15, False), (400, 415, 17, True)])
 def test_emu_bits_fixed_length_coalesced(la, lb, k, trans):
     """n = 150: two full wavefronts and one with 22 live lanes (helper lanes serve live pairs while their own pair is absent)."""
     a, b = _fixed_batch(la * 7 + lb + k, 150, la, lb, k, swaps=trans)

@@ -6,7 +6,16 @@ import pytest
 import datagen as Dg
 import oracle_lib as O
 
-pytestmark = pytest.mark.gpu
+def _experimental():
+    try:
+        import triple_accel_amd as T
+        return "+experimental" in T.version()
+    except Exception:
+        return False
+
+
+# the kernel is an experiment: it is only in libraries built with `make -C triple_accel_amd/csrc EXPERIMENTAL=1`
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _experimental(), reason="library built without EXPERIMENTAL=1")]
 
 
 def _batch(seed, n, la, lb, edits):

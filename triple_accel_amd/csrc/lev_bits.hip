@@ -44,11 +44,13 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t grid = (waves + wpb - 1) / wpb;
-    // Strings longer than one 128-byte line: three blocks (12 waves) per CU instead of the four the rings would allow.  The
-    // issue slots are full either way (same run time on cfg2), and a quarter fewer pairs in flight lets the 4 MB L2 keep
-    // more lines until their second half is read.
+    // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
+    // (12 waves) per CU instead of four -- a quarter fewer pairs in flight lets the 4 MB L2 keep more lines until their second
+    // half is read.  Fixed-length batches (line form: every line requested once) run the four blocks the LDS allows: 16 waves
+    // per CU measured 8 % faster than 12 once the refetches were gone (profiles/r02/ab_band_kernel.md).
     size_t lds = (size_t)pl.lds_per_wave * wpb;
-    if (wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
+    const bool line_form = !P.a.off && !P.b.off && !(P.tune & 1u);
+    if (!line_form && wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
     if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;

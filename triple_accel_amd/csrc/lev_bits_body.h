@@ -166,55 +166,133 @@ struct LevBits {
         const uint32_t iters = T0 + W::wave_max(blen);
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
-        // ---- string streaming.  Per (pair, string) LDS holds ONE 64-byte chunk [0,64) plus the first 16 bytes of the next
-        // one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16) (the 16-byte pieces sit on
-        // the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk waits in
-        // registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is
-        // used up (32-byte refills re-read every 128-byte L2 line 4 times; measured traffic: DESIGN.md section 5).
-        // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
-        const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
-        Q S[8];
-        // COALESCED form (fixed-length batches, with or without a subset list): the wavefront fetches cooperatively.  In load
-        // p (0..3) lane l brings piece c = l & 3 (16 bytes) of pair-slot g = 16 p + (l >> 2): four consecutive lanes read 64
-        // consecutive bytes of one string, so a global_load_dwordx4 touches 16 runs of 64 bytes instead of 64 scattered 16-byte
-        // pieces, and commits them to THAT pair's LDS slot (the compute side still reads its own pair's slot, lane = pair).
-        // The lengths are the batch's, hence the band geometry (nlo, ea, eb) is the same number in every lane.
-        // CSR batches keep the per-lane form below: every lane fetches its own pair's pieces.
-        const bool coop = !P.a.off && !P.b.off && !(P.tune & 1u);
-        const U32 pc = lane & 3u;                                  // piece of the chunk this lane carries
-        Ptr ah[4], bh[4];
-        Bool vh[4];
-        U32 ea_u = ea, eb_u = eb, alen_u = alen, blen_u = blen;
-        if (coop) {
-            alen_u = W::splat((uint32_t)P.a.len); blen_u = W::splat((uint32_t)P.b.len);
-            const U32 diff_u = W::sel(blen_u >= alen_u, blen_u - alen_u, alen_u - blen_u);
-            const Bool in_u = diff_u <= P.u;
-            const U32 tb_u = W::sel(in_u, (W::splat(P.u) - diff_u) >> 1, W::splat(0));
-            const U32 nlo_u = W::sel(in_u, tb_u + W::sel(blen_u >= alen_u, W::splat(0), diff_u) + (TRANS ? 1u : 0u), W::splat(0));
-            const U32 ca_u = W::splat(T0) - nlo_u;
-            ea_u = ca_u + ((W::splat(16u) - (ca_u & 15u)) & 15u);
-            eb_u = W::splat(T0);
+        // ---- one span of iterations [tp, p_hi) on LDS-resident characters; addr_a(tp) / addr_b(tp) = LDS byte address of the
+        // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3)
+        auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b) -> uint32_t {
+            if (STATIC) {
+                // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end)
+                const bool cap = W::any(valid & (t_stop < p_hi));
+                for (; tp < p_hi; tp += 4u) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const U32 g = (lane >> 2) + 16u * (uint32_t)p;
-                ah[p] = W::shfl_ptr(aptr, g);
-                bh[p] = W::shfl_ptr(bptr, g);
-                vh[p] = W::shfl(W::sel(valid, W::splat(1), W::splat(0)), g) != 0u;
-            }
-        }
-        const U32 a_dst = (lane >> 2) * BITS_SLOT_A + pc * 16u, b_dst = (lane >> 2) * BITS_SLOT_B + pc * 16u + 64u * BITS_SLOT_A;
-        auto fetch = [&](uint32_t kc) {
-            if (coop) {
-                const U32 y0 = W::splat(kc * 64u) + pc * 16u;
-                const Bool ina = (ea_u <= y0) & ((y0 - ea_u) < alen_u), inb = (eb_u <= y0) & ((y0 - eb_u) < blen_u);
-                const U32 offa = W::sel(ina, y0 - ea_u, W::splat(0)), offb = W::sel(inb, y0 - eb_u, W::splat(0));
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    S[p] = W::gload16(W::ptr_add(ah[p], offa), vh[p] & ina);
-                    S[4 + p] = W::gload16(W::ptr_add(bh[p], offb), vh[p] & inb);
+                    for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
+                    st.AW[NA - 1] = W::lds_read32u(lds, addr_a(tp)) ^ 0x0C0C0C0Cu;
+                    if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
+                    const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
+                    if (!cap) {
+                        column<false, 0>(st, b0, M, cnt, active);
+                        if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
+                        if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);
+                        if (tp + 3u < p_hi) column<false, 3>(st, b3, M, cnt, active);
+                    } else {
+                        column<true, 0>(st, b0, M, cnt, t_stop > tp);
+                        if (tp + 1u < p_hi) column<true, 1>(st, b1, M, cnt, t_stop > (tp + 1u));
+                        if (tp + 2u < p_hi) column<true, 2>(st, b2, M, cnt, t_stop > (tp + 2u));
+                        if (tp + 3u < p_hi) column<true, 3>(st, b3, M, cnt, t_stop > (tp + 3u));
+                    }
                 }
-                return;
+                return tp;
             }
+            for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
+                advance_a(st, W::lds_u8(lds, addr_a(tp)));
+            if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the span's end
+                for (; tp + 4u <= p_hi; tp += 4u) {
+#pragma unroll
+                    for (uint32_t s4 = 0; s4 < 4u; s4++) {
+                        advance_a(st, W::lds_u8(lds, addr_a(tp + s4)));
+                        column<false>(st, W::lds_u8(lds, addr_b(tp + s4)), M, cnt, active);
+                    }
+                }
+                for (; tp < p_hi; tp++) {
+                    const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
+                    advance_a(st, a_in);
+                    column<false>(st, b_in, M, cnt, active);
+                }
+            } else {
+                for (; tp < p_hi; tp++) {
+                    const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
+                    advance_a(st, a_in);
+                    column<true>(st, b_in, M, cnt, t_stop > tp);
+                }
+            }
+            return tp;
+        };
+
+        const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
+        if (!P.a.off && !P.b.off && !(P.tune & 1u)) {
+            // ---- LINE form (fixed-length batches, with or without a subset list): every 128-byte line of a string is requested
+            // ONCE, whole -- eight 16-byte loads of the lane's own pair in one burst, parked in registers (2 x 8 x 16 bytes per
+            // lane) -- and handed to LDS piece by piece: LDS holds a ring of 5 pieces (80 bytes + a 4-byte copy of its first
+            // dword for reads that wrap) of `a` and 4 pieces of `b` per pair, the same 84 + 68 bytes as the chunk form below.
+            // The lengths are the batch's, so the geometry (ca, T0) is one number for the wavefront and every event below is
+            // wave-uniform: per 16 iterations one piece of each string moves registers -> LDS (the slot of the piece that just
+            // died), and the commit of a line's last piece is followed by the burst for the next line, whose first piece is
+            // not due for another 16 iterations.  (The chunk form fetches half lines 64 iterations apart; by then the 4 MB L2
+            // has dropped the line: 2.0x the string bytes at the L2's fabric side, measured with TCC_EA0_RDREQ_128B.)
+            const uint32_t alen_u = (uint32_t)P.a.len, blen_u = (uint32_t)P.b.len;
+            const uint32_t diff_u = blen_u >= alen_u ? blen_u - alen_u : alen_u - blen_u;
+            const uint32_t nlo_u = diff_u <= P.u ? ((P.u - diff_u) >> 1) + (blen_u >= alen_u ? 0u : diff_u) + (TRANS ? 1u : 0u) : 0u;
+            const int32_t ca_s = (int32_t)T0 - (int32_t)nlo_u;          // iteration tp inserts a[tp - ca_s], column uses b[tp - T0]
+            constexpr int32_t RA = 5, RB = 4;
+            Q SA[8], SB[8];
+            auto fetch_a = [&](int32_t m) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int32_t off = 128 * m + 16 * c;
+                    const Bool ok = (off >= 0 && (uint32_t)off < alen_u) ? valid : W::bfalse();
+                    SA[c] = W::gload16(W::ptr_add(aptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
+                }
+            };
+            auto fetch_b = [&](int32_t m) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int32_t off = 128 * m + 16 * c;
+                    const Bool ok = (off >= 0 && (uint32_t)off < blen_u) ? valid : W::bfalse();
+                    SB[c] = W::gload16(W::ptr_add(bptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
+                }
+            };
+            auto put = [&](const Q (&S)[8], int32_t piece, U32 dst, bool wrap_copy) {
+                switch (piece & 7) {                                   // wave-uniform: one of eight stores
+#define TA_PUT(c) case c: W::lds_store16(lds, dst, S[c], active); if (wrap_copy) W::lds_write32(lds, dst + 16u * RA, W::qword(S[c], 0)); break;
+                    TA_PUT(0) TA_PUT(1) TA_PUT(2) TA_PUT(3) TA_PUT(4) TA_PUT(5) TA_PUT(6) TA_PUT(7)
+#undef TA_PUT
+                }
+            };
+            auto fmod = [](int32_t x, int32_t m) -> uint32_t { const int32_t r = x % m; return (uint32_t)(r < 0 ? r + m : r); };
+            auto commit_a = [&](int32_t piece) {
+                const uint32_t slot = fmod(piece, RA);
+                put(SA, piece, a_slot + 16u * slot, slot == 0u);
+                if ((piece & 7) == 7) fetch_a((piece >> 3) + 1);
+            };
+            auto commit_b = [&](int32_t piece) {
+                put(SB, piece, b_slot + 16u * fmod(piece, RB), false);
+                if ((piece & 7) == 7) fetch_b((piece >> 3) + 1);
+            };
+            uint32_t tp = STATIC ? (tp0 & ~3u) : tp0;
+            const uint32_t tb0 = tp & ~15u;
+            // pieces the first block reads: a string offset x lives in piece x >> 4 (arithmetic shift: offsets before the string
+            // are pieces < 0, delivered as zeros)
+            int32_t qa = ((int32_t)tb0 - ca_s) >> 4, qb = ((int32_t)tb0 - (int32_t)T0) >> 4;
+            fetch_a(qa >> 3);
+            fetch_b(qb >> 3);
+            for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
+            for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
+            for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
+                commit_a(qa + RA - 1);                                  // into the slot of piece qa - 1, which the last block finished
+                commit_b(qb + RB - 1);
+                W::lds_wave_sync();
+                const uint32_t b_hi = tb + 16u < iters ? tb + 16u : iters;
+                tp = run_span(tp, b_hi,
+                              [&](uint32_t t) { return a_slot + fmod((int32_t)t - ca_s, 16 * RA); },
+                              [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); });
+            }
+        } else {
+        // ---- CHUNK form (CSR batches: every pair has its own geometry).  Per (pair, string) LDS holds ONE 64-byte chunk [0,64)
+        // plus the first 16 bytes of the next one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16)
+        // (the 16-byte pieces sit on the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk
+        // waits in registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is used up.
+        // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
+        Q S[8];
+        auto fetch = [&](uint32_t kc) {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const uint32_t y0 = kc * 64u + 16u * (uint32_t)p;
@@ -227,24 +305,11 @@ struct LevBits {
         auto commit_main = [&]() {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                if (coop) {
-                    W::lds_store16(lds, a_dst + 16u * BITS_SLOT_A * (uint32_t)p, S[p], active);
-                    W::lds_store16(lds, b_dst + 16u * BITS_SLOT_B * (uint32_t)p, S[4 + p], active);
-                } else {
-                    W::lds_store16(lds, a_slot + 16u * p, S[p], active);
-                    W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
-                }
+                W::lds_store16(lds, a_slot + 16u * p, S[p], active);
+                W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
             }
         };
-        // the look-ahead bytes are the NEXT chunk's first piece: S[0] in the per-lane form, the registers of the lanes with pc == 0
-        auto commit_look = [&]() {
-            if (coop) {
-#pragma unroll
-                for (int p = 0; p < 4; p++) W::lds_store16(lds, a_dst + 16u * BITS_SLOT_A * (uint32_t)p + 64u, S[p], pc == 0u);
-            } else {
-                W::lds_store16(lds, a_slot + 64u, S[0], active);
-            }
-        };
+        auto commit_look = [&]() { W::lds_store16(lds, a_slot + 64u, S[0], active); };
         const uint32_t kc0 = tp0 / 64u;
         fetch(kc0);
         commit_main();
@@ -262,59 +327,14 @@ struct LevBits {
                 // was issued at least 48 iterations ago)
                 const uint32_t p_hi = part == 0 ? (t_lo + 48u < t_hi ? t_lo + 48u : t_hi) : t_hi;
                 if (part == 1) { commit_look(); W::lds_wave_sync(); }
-                if (STATIC) {
-                    // groups of 4 iterations (tp a multiple of 4; T0 and the part limits are multiples of 4 except the very end)
-                    const bool cap = W::any(valid & (t_stop < p_hi));
-                    for (; tp < p_hi; tp += 4u) {
-#pragma unroll
-                        for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
-                        const U32 pa = ra + tp;
-                        st.AW[NA - 1] = W::lds_read32u(lds, pa) ^ 0x0C0C0C0Cu;
-                        if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
-                        const U32 b0 = W::lds_read32u(lds, rb + tp), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
-                        if (!cap) {
-                            column<false, 0>(st, b0, M, cnt, active);
-                            if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
-                            if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);
-                            if (tp + 3u < p_hi) column<false, 3>(st, b3, M, cnt, active);
-                        } else {
-                            column<true, 0>(st, b0, M, cnt, t_stop > tp);
-                            if (tp + 1u < p_hi) column<true, 1>(st, b1, M, cnt, t_stop > (tp + 1u));
-                            if (tp + 2u < p_hi) column<true, 2>(st, b2, M, cnt, t_stop > (tp + 2u));
-                            if (tp + 3u < p_hi) column<true, 3>(st, b3, M, cnt, t_stop > (tp + 3u));
-                        }
-                    }
-                    continue;
-                }
-                for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
-                    advance_a(st, W::lds_u8(lds, ra + tp));
-                if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the part's end
-                    for (; tp + 4u <= p_hi; tp += 4u) {        // four columns per address computation
-                        const U32 pa = ra + tp, pb = rb + tp;
-#pragma unroll
-                        for (uint32_t s4 = 0; s4 < 4u; s4++) {
-                            advance_a(st, W::lds_u8(lds, pa + s4));
-                            column<false>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
-                        }
-                    }
-                    for (; tp < p_hi; tp++) {
-                        const U32 a_in = W::lds_u8(lds, ra + tp), b_in = W::lds_u8(lds, rb + tp);
-                        advance_a(st, a_in);
-                        column<false>(st, b_in, M, cnt, active);
-                    }
-                } else {
-                    for (; tp < p_hi; tp++) {
-                        const U32 a_in = W::lds_u8(lds, ra + tp), b_in = W::lds_u8(lds, rb + tp);
-                        advance_a(st, a_in);
-                        column<true>(st, b_in, M, cnt, t_stop > tp);
-                    }
-                }
+                tp = run_span(tp, p_hi, [&](uint32_t t) { return ra + t; }, [&](uint32_t t) { return rb + t; });
             }
             if (t_hi < iters) {                                 // next chunk: registers -> LDS, then fetch the one after
                 commit_main();
                 fetch(kc + 2);
                 W::lds_wave_sync();
             }
+        }
         }
 
         const U32 d = (diff + blen) - cnt;                     // |delta| + columns - zero-difference steps

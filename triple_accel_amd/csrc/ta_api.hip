@@ -436,6 +436,7 @@ int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_
 // strings in place and writes its answer next to them (`*out_host` then reads it after one stream synchronisation).  Long
 // pairs are copied to thread-local device scratch on the thread's stream.  Either way the call runs on the thread's own
 // non-blocking stream `*st`.
+constexpr uint32_t TA_SLOT_EMPTY = 0xFFFFFFFEu;    // "no answer yet": distances stay below 0xFFFFFFF0, None is 0xFFFFFFFF
 struct Staged {
     ta_strings sa, sb;
     uint32_t *out_dev;             // where the kernel writes
@@ -477,7 +478,6 @@ static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b
 // value no answer can take, and the host watches the pinned word instead of going through the runtime's completion
 // machinery (the store becomes visible no later than the kernel's end-of-kernel release); after 20 ms without an answer the
 // ordinary stream synchronisation takes over (and reports a fault, if that is what happened).
-constexpr uint32_t TA_SLOT_EMPTY = 0xFFFFFFFEu;    // distances stay below 0xFFFFFFF0, None is 0xFFFFFFFF
 static int fetch_u32(const Staged &S, uint32_t *out, bool single_store = false) {
     if (S.out_host) {
         if (single_store) {
