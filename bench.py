@@ -126,6 +126,9 @@ def main():
     wl = args.workload
     evaluated_unit = None
     cores = O.max_threads()
+    quota = host_cpu_facts()["cgroup_cpus"]
+    if quota:                                  # a container's CPU quota caps what OpenMP can use: more threads than that only fight
+        cores = max(1, min(cores, int(quota + 0.5)))
     LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
     strong = args.scaling == "strong"
 

@@ -99,8 +99,9 @@ def hot_loop(body):
             hdr = m.group(1)
         if hdr:
             groups.setdefault(hdr, []).append((lab, ins, text))
-    def valu(g):
-        return sum(1 for _, ins, _ in g for x in ins if x.startswith("v_"))
+    def valu(g):      # blocks with next to no VALU work (switch arms, loop latches) do not make a loop "hot"
+        per = [sum(1 for x in ins if x.startswith("v_")) for _, ins, _ in g]
+        return sum(v for v in per if v >= 12)
     hdr = max(groups, key=lambda h: valu(groups[h]))
     used, skipped, all_ins, texts = [], [], [], []
     for lab, ins, text in groups[hdr]:

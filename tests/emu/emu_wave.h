@@ -58,19 +58,6 @@ struct EmuWave {
         return r;
     }
     static U32 opaque(const U32 &x) { return x; }
-    template <class F> static U32 pk2(const U32 &a, const U32 &b, F f) {
-        V32 r;
-        for (int i = 0; i < 64; i++) {
-            uint32_t lo = f(a.v[i] & 0xFFFFu, b.v[i] & 0xFFFFu) & 0xFFFFu, hi = f(a.v[i] >> 16, b.v[i] >> 16) & 0xFFFFu;
-            r.v[i] = lo | (hi << 16);
-        }
-        return r;
-    }
-    static U32 pk_add_sat(const U32 &a, const U32 &b) { return pk2(a, b, [](uint32_t x, uint32_t y) { uint32_t s = x + y; return s > 0xFFFFu ? 0xFFFFu : s; }); }
-    static U32 pk_min(const U32 &a, const U32 &b) { return pk2(a, b, [](uint32_t x, uint32_t y) { return x < y ? x : y; }); }
-    static U32 pk_mul(const U32 &a, const U32 &b) { return pk2(a, b, [](uint32_t x, uint32_t y) { return x * y; }); }
-    static U32 pk_sub(const U32 &a, const U32 &b) { return pk2(a, b, [](uint32_t x, uint32_t y) { return x - y; }); }
-    static U32 alignbit16(const U32 &hi, const U32 &lo) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (hi.v[i] << 16) | (lo.v[i] >> 16); return r; }
     static U32 dot4_byte(const U32 &x, int n, uint32_t m, const U32 &acc) {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + ((x.v[i] >> (8 * n)) & 0xffu) * (m & 0xffu); return r;
     }

@@ -46,7 +46,7 @@ struct LevParams {
     uint32_t lds_per_wave;    // bytes
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
     uint32_t ch;              // bytes per string per streamed chunk
-    uint32_t tune = 0;        // A/B switches (TA_TUNING builds of a measurement): bit 0 = per-lane fetch for fixed-length batches too
+    uint32_t tune = 0;        // bit 0: chunk form of the bit-parallel band kernel's fetch also for fixed-length batches (set by the launcher)
     uint32_t *bnd = nullptr;  // lev_widebits: per wave 6 boundary lines of bnd_line u32 (strings spanning several stripes)
     uint64_t bnd_line = 0;
     uint64_t trace_cols = 0;  // lev_widebits TRACE: columns per stripe in P.trace (>= b_len + 64)

@@ -36,7 +36,10 @@ static hipError_t launch_na(const LevParams &P, bool trans, bool stat, uint32_t 
 hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out) {
     LevParams P = P0;
-    if (env_int("TA_BITS_NO_COOP")) P.tune |= 1u;
+    // fixed-length batches of strings longer than one 128-byte line take the line form of the fetch (lev_bits_body.h); up to one
+    // line the chunk form has nothing to refetch and its coarser events (one per 64 columns, not per 16) are cheaper:
+    // cfg4 0.150 ms against 0.180 ms (profiles/r02/ab_band_kernel.md).  TA_BITS_NO_COOP=1 pins the chunk form.
+    if (max_len <= 128u || env_int("TA_BITS_NO_COOP")) P.tune |= 1u;
     const uint32_t waves = (P.n + 63u) / 64u;
     // 4 waves per block while four rings fit a quarter of the CU's LDS; else one wave per block so that the CU packs
     // as many waves as the LDS holds.  TA_BITS_WPB pins the waves per block, TA_BITS_BLOCK_LDS the block's LDS request

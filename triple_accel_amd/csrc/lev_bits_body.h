@@ -195,11 +195,12 @@ struct LevBits {
             for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
                 advance_a(st, W::lds_u8(lds, addr_a(tp)));
             if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the span's end
-                for (; tp + 4u <= p_hi; tp += 4u) {
+                for (; tp + 4u <= p_hi; tp += 4u) {        // four columns per address computation (the rings carry 4 bytes of wrap copy)
+                    const U32 pa = addr_a(tp), pb = addr_b(tp);
 #pragma unroll
                     for (uint32_t s4 = 0; s4 < 4u; s4++) {
-                        advance_a(st, W::lds_u8(lds, addr_a(tp + s4)));
-                        column<false>(st, W::lds_u8(lds, addr_b(tp + s4)), M, cnt, active);
+                        advance_a(st, W::lds_u8(lds, pa + s4));
+                        column<false>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
                     }
                 }
                 for (; tp < p_hi; tp++) {
@@ -221,8 +222,8 @@ struct LevBits {
         if (!P.a.off && !P.b.off && !(P.tune & 1u)) {
             // ---- LINE form (fixed-length batches, with or without a subset list): every 128-byte line of a string is requested
             // ONCE, whole -- eight 16-byte loads of the lane's own pair in one burst, parked in registers (2 x 8 x 16 bytes per
-            // lane) -- and handed to LDS piece by piece: LDS holds a ring of 5 pieces (80 bytes + a 4-byte copy of its first
-            // dword for reads that wrap) of `a` and 4 pieces of `b` per pair, the same 84 + 68 bytes as the chunk form below.
+            // lane) -- and handed to LDS piece by piece: LDS holds a ring of 5 pieces of `a` and 4 pieces of `b` per pair, each followed by
+            // a 4-byte copy of its first dword for reads that run over the end: the same 84 + 68 bytes as the chunk form below.
             // The lengths are the batch's, so the geometry (ca, T0) is one number for the wavefront and every event below is
             // wave-uniform: per 16 iterations one piece of each string moves registers -> LDS (the slot of the piece that just
             // died), and the commit of a line's last piece is followed by the burst for the next line, whose first piece is
@@ -250,9 +251,9 @@ struct LevBits {
                     SB[c] = W::gload16(W::ptr_add(bptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
                 }
             };
-            auto put = [&](const Q (&S)[8], int32_t piece, U32 dst, bool wrap_copy) {
+            auto put = [&](const Q (&S)[8], int32_t piece, U32 dst, uint32_t wrap_copy_at) {     // wrap_copy_at: 0 = none
                 switch (piece & 7) {                                   // wave-uniform: one of eight stores
-#define TA_PUT(c) case c: W::lds_store16(lds, dst, S[c], active); if (wrap_copy) W::lds_write32(lds, dst + 16u * RA, W::qword(S[c], 0)); break;
+#define TA_PUT(c) case c: W::lds_store16(lds, dst, S[c], active); if (wrap_copy_at) W::lds_write32(lds, dst + wrap_copy_at, W::qword(S[c], 0)); break;
                     TA_PUT(0) TA_PUT(1) TA_PUT(2) TA_PUT(3) TA_PUT(4) TA_PUT(5) TA_PUT(6) TA_PUT(7)
 #undef TA_PUT
                 }
@@ -260,11 +261,12 @@ struct LevBits {
             auto fmod = [](int32_t x, int32_t m) -> uint32_t { const int32_t r = x % m; return (uint32_t)(r < 0 ? r + m : r); };
             auto commit_a = [&](int32_t piece) {
                 const uint32_t slot = fmod(piece, RA);
-                put(SA, piece, a_slot + 16u * slot, slot == 0u);
+                put(SA, piece, a_slot + 16u * slot, slot == 0u ? 16u * RA : 0u);
                 if ((piece & 7) == 7) fetch_a((piece >> 3) + 1);
             };
             auto commit_b = [&](int32_t piece) {
-                put(SB, piece, b_slot + 16u * fmod(piece, RB), false);
+                const uint32_t slot = fmod(piece, RB);
+                put(SB, piece, b_slot + 16u * slot, slot == 0u ? 16u * RB : 0u);
                 if ((piece & 7) == 7) fetch_b((piece >> 3) + 1);
             };
             uint32_t tp = STATIC ? (tp0 & ~3u) : tp0;

@@ -46,16 +46,6 @@ struct DevWave {
     template <int N> static __device__ __forceinline__ U32 alignbyte(U32 hi, U32 lo) {
         return __builtin_amdgcn_alignbyte(hi, lo, N);
     }
-    // packed 2 x u16 arithmetic on one VGPR (VOP3P): the reference's 8/16-bit cell classes live in these lanes
-    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ u16x2_t as16(U32 x) { return __builtin_bit_cast(u16x2_t, x); }
-    static __device__ __forceinline__ U32 as32(u16x2_t x) { return __builtin_bit_cast(U32, x); }
-    static __device__ __forceinline__ U32 pk_add_sat(U32 a, U32 b) { return as32(__builtin_elementwise_add_sat(as16(a), as16(b))); }   // v_pk_add_u16 clamp
-    static __device__ __forceinline__ U32 pk_min(U32 a, U32 b) { return as32(__builtin_elementwise_min(as16(a), as16(b))); }            // v_pk_min_u16
-    static __device__ __forceinline__ U32 pk_mul(U32 a, U32 b) { return as32(as16(a) * as16(b)); }                                      // v_pk_mul_lo_u16
-    static __device__ __forceinline__ U32 pk_sub(U32 a, U32 b) { return as32(as16(a) - as16(b)); }                                      // v_pk_sub_u16 (wraps)
-    // ({hi,lo} >> 16)[31:0] -> v_alignbit_b32
-    static __device__ __forceinline__ U32 alignbit16(U32 hi, U32 lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
     // value barrier: stops instcombine from re-associating across it
     static __device__ __forceinline__ U32 opaque(U32 x) { asm volatile("" : "+v"(x)); return x; }
     // acc + byte n of x * m  (m <= 255)  -> v_dot4_u32_u8 with a one-hot multiplier
