@@ -68,3 +68,37 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     return 0;
 }
 
+
+// ---- two pairs per lane (lev_bits2_body.h): fixed-length batches, narrow bands
+#include "lev_bits2_body.h"
+
+extern "C" int emu_lev_bits2(const uint8_t *a_blob, uint64_t a_len, const uint8_t *b_blob, uint64_t b_len, const uint32_t *subset,
+                             uint32_t n, uint32_t k, int has_t, uint32_t *out, uint32_t *plan_out /* NA, u, Tw */) {
+    const uint64_t max_len = a_len > b_len ? a_len : b_len;
+    LevBits2Plan pl = lev_bits2_make_plan(k, 1, 1, 0, has_t != 0, 1, max_len, true, LEV_BITS2_MIN_PAIRS);
+    if (!pl.ok) return 1;
+    LevParams P;
+    P.a = StrView{a_blob, nullptr, a_len, a_len};
+    P.b = StrView{b_blob, nullptr, b_len, b_len};
+    P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
+    P.u = pl.u; P.o = 0; P.L = 1; P.PW = 128; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = 64;
+    if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; }
+    uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
+    const uint32_t waves = (n + 127) / 128;
+    for (uint32_t w = 0; w < waves; w++) {
+        switch (pl.NA * 2 + (has_t ? 1 : 0)) {
+            case 2: LevBits2<EmuWave, 1, false>::run(P, w, lds); break;
+            case 3: LevBits2<EmuWave, 1, true>::run(P, w, lds); break;
+            case 4: LevBits2<EmuWave, 2, false>::run(P, w, lds); break;
+            case 5: LevBits2<EmuWave, 2, true>::run(P, w, lds); break;
+            case 6: LevBits2<EmuWave, 3, false>::run(P, w, lds); break;
+            case 7: LevBits2<EmuWave, 3, true>::run(P, w, lds); break;
+            case 8: LevBits2<EmuWave, 4, false>::run(P, w, lds); break;
+            case 9: LevBits2<EmuWave, 4, true>::run(P, w, lds); break;
+            default: free(lds); return 2;
+        }
+    }
+    free(lds);
+    return 0;
+}

@@ -39,6 +39,9 @@ def lib():
         L.emu_lev_bits_any.restype = C.c_int
         L.emu_lev_bits_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_lev_bits2.restype = C.c_int
+        L.emu_lev_bits2.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                    C.c_void_p, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -118,6 +121,27 @@ def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
         raise RuntimeError("emu_lev_bits_any rc=%d" % rc)
     res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=bool(plan[3]))
+
+
+def lev_bits2(a2d, b2d, k, trans=False, subset=None):
+    """Two pairs per lane (lev_bits2_body.h) on a fixed-length batch; None when the planner declines (band wider than 15)."""
+    a2d, b2d = np.ascontiguousarray(a2d, dtype=np.uint8), np.ascontiguousarray(b2d, dtype=np.uint8)
+    n_all, la = a2d.shape
+    lb = b2d.shape[1]
+    ab = np.concatenate([a2d.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    bb = np.concatenate([b2d.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    out = np.full(n_all, 0xDEADBEEF, dtype=np.uint32)
+    plan = np.zeros(3, dtype=np.uint32)
+    sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
+    n = n_all if sub is None else len(sub)
+    rc = lib().emu_lev_bits2(ab.ctypes.data, la, bb.ctypes.data, lb, None if sub is None else sub.ctypes.data, n, k, int(bool(trans)),
+                             out.ctypes.data, plan.ctypes.data)
+    if rc == 1:
+        return None, None
+    if rc:
+        raise RuntimeError("emu_lev_bits2 rc=%d" % rc)
+    res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
+    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
 
 
 def lev_widebits(a_list, b_list, k, trans=False, nwl=2, nwaves=3):

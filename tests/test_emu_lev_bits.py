@@ -205,3 +205,33 @@ def test_emu_bits_fixed_length_nul_and_high_bytes():
     got, _ = E.lev_bits_fixed(a, b, 30, False)
     want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 30, False, (1, 1, 0, None))[0] for i in range(70)]
     assert got == want
+
+
+# ---- two pairs per lane (lev_bits2_body.h): narrow bands of fixed-length batches
+@pytest.mark.parametrize("la,lb,k,trans", [(128, 128, 8, True), (128, 128, 8, False), (64, 64, 0, False), (64, 64, 1, True), (100, 97, 5, True),
+                                           (100, 104, 12, False), (200, 200, 14, False), (200, 193, 12, True), (30, 30, 3, False),
+                                           (17, 19, 2, True), (1, 1, 1, False), (300, 300, 4, True), (70, 70, 13, False), (129, 120, 10, True)])
+def test_emu_bits2_two_pairs_per_lane(la, lb, k, trans):
+    """n = 300: two full 128-pair wavefronts and one with 44 pairs (pair B absent in most of its lanes)."""
+    a, b = _fixed_batch(la * 11 + lb + k, 300, la, lb, k, swaps=trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(300)]
+    got, plan = E.lev_bits2(a, b, k, trans)
+    assert got is not None, "planner declined"
+    assert got == want, (la, lb, k, trans, plan, [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w][:5])
+
+
+def test_emu_bits2_declines_wide_bands_and_follows_subsets():
+    a, b = _fixed_batch(3, 10, 64, 64, 20)
+    assert E.lev_bits2(a, b, 15, False)[0] is None and E.lev_bits2(a, b, 13, True)[0] is None     # 16 / 16 diagonals
+    assert E.lev_bits2(a, b, 14, False)[0] is not None and E.lev_bits2(a, b, 12, True)[0] is not None
+    a, b = _fixed_batch(8, 400, 90, 90, 9)
+    g = Dg.rng(4)
+    subset = np.sort(g.choice(400, size=201, replace=False)).astype(np.uint32)
+    got, _ = E.lev_bits2(a, b, 9, False, subset=subset)
+    chosen = set(int(x) for x in subset)
+    for i in range(400):
+        if i in chosen:
+            assert got[i] == O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 9, False, (1, 1, 0, None))[0], i
+        else:
+            assert got[i] == "untouched", i

@@ -344,3 +344,46 @@ def test_byte_values_around_the_perm_selector_codes():
             got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
             assert kernel_id() == 3
             assert np.array_equal(got, want), (alpha[:4], k, costs, np.flatnonzero(got != want)[:10])
+
+
+@pytest.mark.parametrize("L,Lb,k,costs", [(128, 128, 8, (1, 1, 0, 1)), (128, 128, 8, (1, 1, 0, None)), (96, 100, 12, (1, 1, 0, None)),
+                                          (64, 61, 10, (1, 1, 0, 1)), (200, 200, 14, (1, 1, 0, None))])
+def test_two_pairs_per_lane_narrow_bands(monkeypatch, L, Lb, k, costs):
+    """Big fixed-length batches with a band of at most 15 diagonals run two pairs per lane (lev_bits2_body.h, 128 pairs per
+    wavefront): vs the oracle on a sample, and pair by pair against the one-pair-per-lane kernel (TA_NO_BITS2=1)."""
+    import torch
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n = 300_000 + 77                                   # a ragged last wavefront
+    g = Dg.rng(L * 3 + k)
+    a = g.integers(97, 101, size=(n, L), dtype=np.uint8)
+    b = g.integers(97, 101, size=(n, Lb), dtype=np.uint8)
+    m = min(L, Lb)
+    sim = g.random(n) < 0.8
+    b[sim, :m] = a[sim, :m]
+    for row in np.nonzero(sim)[0][:20000]:
+        s = Dg.mutate(g, bytes(b[row]), int(g.integers(0, k + 3)), swaps=costs[3] is not None)
+        s = (s + bytes(g.integers(97, 101, size=Lb, dtype=np.uint8)))[:Lb]
+        b[row] = np.frombuffer(s, dtype=np.uint8)
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    got = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    info = T.last_launch_info()
+    assert info["kernel"] == 3 and info["pairs_per_wave"] == 128, info
+    ns = 30000
+    want = O.levenshtein_k_batch(O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns]), k, costs)
+    assert np.array_equal(got[:ns], want)
+    tail = O.levenshtein_k_batch(O.csr_from_fixed(a[-500:]), O.csr_from_fixed(b[-500:]), k, costs)
+    assert np.array_equal(got[-500:], tail)
+    assert (want != 0xFFFFFFFF).any() and (want == 0xFFFFFFFF).any()
+    monkeypatch.setenv("TA_NO_BITS2", "1")
+    one = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    assert T.last_launch_info()["pairs_per_wave"] == 64
+    assert np.array_equal(got, one)
+
+
+def test_two_pairs_per_lane_is_for_big_batches_only():
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    a, b = Dg.pairs_mutated_fixed(5, 5000, 128, 8)
+    B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 8)
+    assert T.last_launch_info()["pairs_per_wave"] == 64

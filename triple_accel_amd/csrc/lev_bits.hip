@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "lev_bits_body.h"
+#include "lev_bits2_body.h"
 #include "lev_plan.h"
 #include "ta_internal.h"
 
@@ -15,6 +16,33 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(Lev
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
     LevBits<DevWave, NA, TRANS, STATIC>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+}
+
+template <int NA, bool TRANS>
+__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6;
+    LevBits2<DevWave, NA, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+}
+
+// two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront, 4 wavefronts per block, two blocks per CU
+hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
+    const uint32_t waves = (P.n + 127u) / 128u, wpb = BITS_WAVES_PER_BLOCK, grid = (waves + wpb - 1) / wpb;
+    const size_t lds = (size_t)pl.lds_per_wave * wpb;
+    if (grid_out) *grid_out = grid;
+    if (lds_out) *lds_out = (uint32_t)lds;
+    if (grid == 0) return hipSuccess;
+    dim3 g(grid), b(64 * wpb);
+    switch (pl.NA) {
+#define TA_CASE2(n) case n: { auto kt = lev_bits2_kernel<n, true>; auto kf = lev_bits2_kernel<n, false>; \
+        hipError_t e = hipFuncSetAttribute((const void *)(trans ? kt : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e; \
+        if (trans) hipLaunchKernelGGL(kt, g, b, lds, s, P); else hipLaunchKernelGGL(kf, g, b, lds, s, P); \
+        return hipGetLastError(); }
+        TA_CASE2(1) TA_CASE2(2) TA_CASE2(3) TA_CASE2(4)
+#undef TA_CASE2
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int NA>

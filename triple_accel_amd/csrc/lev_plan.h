@@ -127,6 +127,27 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     return p;
 }
 
+// ---- two pairs per lane (lev_bits2_body.h): fixed-length unit-cost batches whose band (+ the transposition test's two extra
+// rows) is at most 15 diagonals wide, and big enough that halving the number of wavefronts still leaves >= 2 per SIMD
+struct LevBits2Plan {
+    bool ok;
+    int NA;                  // packed dwords of `a` under each pair's window (window = min(4 NA, 15) bits)
+    uint32_t u, Tw, lds_per_wave;
+};
+constexpr uint32_t LEV_BITS2_MIN_PAIRS = 262144;     // 128 pairs per wavefront x 2 wavefronts x 1024 SIMDs
+static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len,
+                                               bool fixed_length, uint64_t pairs) {
+    LevBits2Plan p;
+    p.u = lev_batch_unit_k(k, mc, gc, sg, max_len);
+    const uint64_t w = (uint64_t)p.u + 1u + (has_t ? 2u : 0u);
+    p.ok = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1) && fixed_length && w <= 15 && max_len <= 65000 && max_len >= 1 &&
+           pairs >= LEV_BITS2_MIN_PAIRS;
+    p.NA = (int)((w + 3) / 4);
+    p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;
+    p.lds_per_wave = 128u * (84u + 68u);
+    return p;
+}
+
 // ---- which kernel runs a k-bounded pass, and roughly what it costs (wave-instructions per pair; only ratios matter)
 enum LevKernel { LEV_K_BAND = 1, LEV_K_WIDE = 2, LEV_K_BITS = 3, LEV_K_WIDEBITS = 4 };
 

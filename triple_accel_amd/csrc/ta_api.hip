@@ -179,7 +179,15 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else
 #endif
-    if (ch.kernel == LEV_K_BITS) {
+    const LevBits2Plan b2 = lev_bits2_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, !a->off && !b->off, n_work);
+    if (ch.kernel == LEV_K_BITS && b2.ok && !pinned && !env_int("TA_NO_BITS2")) {
+        // narrow band, big fixed-length batch: two pairs per lane share the recurrence (lev_bits2_body.h)
+        P.u = b2.u; P.o = 0; P.L = 1; P.PW = 128; P.lds_per_wave = b2.lds_per_wave; P.Tw = b2.Tw; P.ch = 64;
+        uint32_t grid = 0, lds = 0;
+        TA_HIP(lev_bits2_launch(P, b2, trans, st, &grid, &lds));
+        li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)b2.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 128;
+        li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
+    } else if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits_launch(P, bp, trans, max_len, st, &grid, &lds));
