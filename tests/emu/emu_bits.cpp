@@ -102,3 +102,24 @@ extern "C" int emu_lev_bits2(const uint8_t *a_blob, uint64_t a_len, const uint8_
     free(lds);
     return 0;
 }
+
+// ---- one pair, one wavefront (lev_one_body.h)
+#include "lev_one_body.h"
+
+extern "C" int emu_lev_one(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len, uint32_t k, int has_t, uint32_t *out) {
+    const uint64_t max_len = a_len > b_len ? a_len : b_len;
+    uint32_t u = 0;
+    if (!lev_one_applies(k, 1, 1, 0, has_t != 0, 1, max_len, &u)) return 1;
+    LevParams P;
+    P.a = StrView{a, nullptr, a_len, a_len};
+    P.b = StrView{b, nullptr, b_len, b_len};
+    P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = 1; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
+    P.u = u; P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+    const size_t lds_bytes = (LEV_ONE_PAD_LO + max_len + LEV_ONE_PAD_HI + 15u) & ~(size_t)15;
+    uint8_t *lds = (uint8_t *)malloc(lds_bytes);
+    memset(lds, 0xA5, lds_bytes);                      // nothing may depend on what the pads hold
+    if (has_t) LevOne<EmuWave, true>::run(P, lds); else LevOne<EmuWave, false>::run(P, lds);
+    free(lds);
+    return 0;
+}

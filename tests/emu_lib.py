@@ -42,6 +42,8 @@ def lib():
         L.emu_lev_bits2.restype = C.c_int
         L.emu_lev_bits2.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_void_p]
+        L.emu_lev_one.restype = C.c_int
+        L.emu_lev_one.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_lev_search.restype = C.c_int
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -142,6 +144,19 @@ def lev_bits2(a2d, b2d, k, trans=False, subset=None):
         raise RuntimeError("emu_lev_bits2 rc=%d" % rc)
     res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
+
+
+def lev_one(a, b, k, trans=False):
+    """One pair through the single-pair kernel body (lev_one_body.h).  -> dist | None, or "declined" (band wider than 64)."""
+    ab = np.frombuffer(bytes(a) + bytes(32), dtype=np.uint8).copy()
+    bb = np.frombuffer(bytes(b) + bytes(32), dtype=np.uint8).copy()
+    out = np.full(1, 0xDEADBEEF, dtype=np.uint32)
+    rc = lib().emu_lev_one(ab.ctypes.data, len(a), bb.ctypes.data, len(b), k, int(bool(trans)), out.ctypes.data)
+    if rc == 1:
+        return "declined"
+    if rc:
+        raise RuntimeError("emu_lev_one rc=%d" % rc)
+    return None if int(out[0]) == 0xFFFFFFFF else int(out[0])
 
 
 def lev_widebits(a_list, b_list, k, trans=False, nwl=2, nwaves=3):

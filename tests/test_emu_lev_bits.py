@@ -235,3 +235,42 @@ def test_emu_bits2_declines_wide_bands_and_follows_subsets():
             assert got[i] == O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 9, False, (1, 1, 0, None))[0], i
         else:
             assert got[i] == "untouched", i
+
+
+# ---- one pair, one wavefront, the recurrence on the scalar unit (lev_one_body.h)
+@pytest.mark.parametrize("trans", [False, True])
+def test_emu_lev_one_single_pair(trans):
+    g = Dg.rng(77 + trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    n_checked = 0
+    for _ in range(400):
+        la = int(g.choice([0, 1, 2, 5, 17, 63, 64, 65, 100, 256, 300, 700]))
+        alpha = int(g.choice([2, 4, 26]))
+        a = g.integers(97, 97 + alpha, size=la, dtype=np.uint8).tobytes()
+        if g.random() < 0.7:
+            b = Dg.mutate(g, a, int(g.integers(0, 40)), swaps=trans)
+        else:
+            b = g.integers(97, 97 + alpha, size=int(g.integers(0, la + 40)), dtype=np.uint8).tobytes()
+        if not a and not b:
+            continue
+        k = int(g.choice([0, 1, 2, 7, 8, 15, 16, 30, 31, 32, 33, 40, 60, 61, 62, 63, 0xFFFFFFFF]))
+        got = E.lev_one(a, b, k, trans)
+        if got == "declined":
+            continue
+        want = O.levenshtein_naive_k_with_opts(a, b, k, False, costs)[0]
+        assert got == want, (a, b, k, trans, got, want)
+        n_checked += 1
+    assert n_checked > 250
+
+
+def test_emu_lev_one_edges():
+    # the band limit: 64 diagonals (61 with the transposition rows); unbounded k on short strings clamps into it
+    assert E.lev_one(b"a" * 100, b"b" * 100, 63, False) is None
+    assert E.lev_one(b"a" * 100, b"b" * 100, 64, False) == "declined"
+    assert E.lev_one(b"a" * 100, b"b" * 100, 61, True) is None and E.lev_one(b"a" * 100, b"b" * 100, 62, True) == "declined"
+    assert E.lev_one(b"kitten", b"sitting", 0xFFFFFFFF, False) == 3
+    assert E.lev_one(b"", b"abc", 5, False) == 3 and E.lev_one(b"abc", b"", 2, False) is None
+    assert E.lev_one(b"abcdef", b"badcfe", 10, True) == 3 and E.lev_one(b"abcdef", b"badcfe", 10, False) == 4
+    x = bytes(range(256)) * 4
+    y = x[1:] + bytes([0])
+    assert E.lev_one(x, x, 0, False) == 0 and E.lev_one(x, y, 2, False) == O.levenshtein_naive_k_with_opts(x, y, 2, False, LEV)[0] == 2

@@ -284,9 +284,10 @@ def test_a_few_long_pairs_in_a_fixed_length_batch():
 
 
 def test_small_passes_are_chosen_by_wavefront_latency(monkeypatch):
-    """Up to 1024 pairs the pass lasts as long as its slowest wavefront: a 256-byte pair goes through the row-blocked
-    kernel (one pair per wavefront) although the band kernel (64 pairs per wavefront) is cheaper per pair; the results
-    are the oracle's either way, and TA_NO_LATENCY_RULE=1 restores the throughput choice."""
+    """Up to 1024 pairs the pass lasts as long as its slowest wavefront: 256-byte pairs go through the row-blocked
+    kernel (one pair per wavefront) although the band kernel (64 pairs per wavefront) is cheaper per pair, and a LONE pair
+    whose band fits 64 diagonals through the single-pair kernel (match vectors 64 columns at a time, the recurrence on the
+    scalar unit); the results are the oracle's either way, and TA_NO_LATENCY_RULE=1 restores the throughput choice."""
     import triple_accel_amd as T
     g = Dg.rng(0x1A7)
     for n_pairs in (1, 40, 900):
@@ -300,7 +301,10 @@ def test_small_passes_are_chosen_by_wavefront_latency(monkeypatch):
             kid = kernel_id()
             want = oracle_k(a, b, k, costs)
             assert np.array_equal(got, want), (n_pairs, k, costs)
-            assert (kid in (3, 4)) if k == 8 else kid == 4, (n_pairs, k, costs, kid)
+            if n_pairs == 1 and k <= 32:
+                assert kid == 6, (k, costs, kid)          # a lone pair, band <= 64 diagonals: the single-pair kernel (lev_one_body.h)
+            else:
+                assert (kid in (3, 4)) if k == 8 else kid == 4, (n_pairs, k, costs, kid)
             monkeypatch.setenv("TA_NO_LATENCY_RULE", "1")
             assert np.array_equal(gpu_k(a, b, k, costs), want)
             assert kernel_id() == (3 if k <= 32 else 1)
@@ -387,3 +391,33 @@ def test_two_pairs_per_lane_is_for_big_batches_only():
     a, b = Dg.pairs_mutated_fixed(5, 5000, 128, 8)
     B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 8)
     assert T.last_launch_info()["pairs_per_wave"] == 64
+
+
+@pytest.mark.parametrize("costs", [LEV, RDAM])
+def test_single_pair_kernel(monkeypatch, costs):
+    """Single calls with a band of up to 64 diagonals: lev_one_body.h against the oracle and against the kernels it replaces
+    (TA_NO_ONE=1), over lengths around the 64-column blocks, all window widths, empty strings, NUL bytes."""
+    import triple_accel_amd as T
+    g = Dg.rng(0x0E1 + (costs[3] or 0))
+    C = T.EditCosts(*costs)
+    seen = 0
+    for rnd in range(250):
+        la = int(g.choice([0, 1, 3, 16, 63, 64, 65, 127, 128, 129, 256, 1000, 4096]))
+        a = g.integers(0, 4, size=la, dtype=np.uint8).tobytes() if rnd % 5 == 0 else Dg.rand_str(g, la)
+        b = Dg.mutate(g, a, int(g.integers(0, 50)), True) if g.random() < 0.7 else Dg.rand_str(g, int(g.integers(0, la + 30)))
+        if not a and not b:
+            continue
+        k = int(g.choice([0, 1, 5, 8, 16, 31, 32, 33, 48, 60, 61, 62, 63]))
+        monkeypatch.delenv("TA_NO_ONE", raising=False)
+        got = T.levenshtein_simd_k_with_opts(a, b, k, False, C)
+        kid = kernel_id()
+        want = O.levenshtein_naive_k_with_opts(a, b, k, False, costs)[0]
+        assert (None if got is None else got[0]) == want, (a, b, k, costs)
+        if kid == 6:
+            seen += 1
+            monkeypatch.setenv("TA_NO_ONE", "1")
+            other = T.levenshtein_simd_k_with_opts(a, b, k, False, C)
+            assert kernel_id() != 6 and (None if other is None else other[0]) == want
+    assert seen > 150
+    monkeypatch.delenv("TA_NO_ONE", raising=False)
+    assert T.levenshtein(b"kitten", b"sitting") == 3 and kernel_id() == 6          # unbounded k on short strings clamps into the band

@@ -148,6 +148,13 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
     return p;
 }
 
+// ---- ONE pair, band of at most 64 diagonals (lev_one_body.h: match vectors 64 columns at a time, the recurrence on the scalar unit)
+static inline bool lev_one_applies(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len, uint32_t *u_out) {
+    const uint32_t u = lev_batch_unit_k(k, mc, gc, sg, max_len);
+    if (u_out) *u_out = u;
+    return mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1) && (uint64_t)u + 1u + (has_t ? 2u : 0u) <= 64u && max_len <= 32000u;
+}
+
 // ---- which kernel runs a k-bounded pass, and roughly what it costs (wave-instructions per pair; only ratios matter)
 enum LevKernel { LEV_K_BAND = 1, LEV_K_WIDE = 2, LEV_K_BITS = 3, LEV_K_WIDEBITS = 4 };
 

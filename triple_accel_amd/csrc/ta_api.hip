@@ -179,6 +179,19 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else
 #endif
+    uint32_t u_one = 0;
+    if (n_work == 1 && !dp_forced && !pinned && !env_int("TA_FORCE_WIDEBITS") && !env_int("TA_NO_ONE") &&
+        lev_one_applies(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, &u_one)) {
+        // a lone pair with a band of up to 64 diagonals: match vectors 64 columns at a time, the recurrence on the scalar unit
+        P.u = u_one; P.o = 0; P.L = 64; P.PW = 1; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+        uint32_t lds = 0;
+        TA_HIP(lev_one_launch(P, trans, max_len, st, &lds));
+        li.kernel = 6; li.diags_per_lane = 64; li.lanes_per_pair = 64; li.pairs_per_wave = 1;
+        li.grid = 1; li.lds_bytes = lds; li.band_offset = 0;
+        if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=1 k=%u u=%u kernel=6 (single pair, scalar-unit recurrence) lds=%u\n", k, u_one, lds);
+        g_last_launch = li;
+        return TA_OK;
+    }
     const LevBits2Plan b2 = lev_bits2_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, !a->off && !b->off, n_work);
     if (ch.kernel == LEV_K_BITS && b2.ok && !pinned && !env_int("TA_NO_BITS2")) {
         // narrow band, big fixed-length batch: two pairs per lane share the recurrence (lev_bits2_body.h)

@@ -72,6 +72,7 @@ hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool aff
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
+hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipStream_t s, uint32_t *lds_out);
 bool lev_sliced_applies(const StrView &a, const StrView &b, uint32_t unit_k, uint32_t *strips_out);
 hipError_t lev_sliced_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t k, uint32_t unit_k, uint32_t *out,
                              hipStream_t st, uint32_t *grid_out, uint32_t *lds_out, uint32_t *pairs_per_wave);
