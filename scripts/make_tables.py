@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""profiles/<round>/*.json (written by scripts/gpu_profiles.sh on one GPU box) -> profiles/<round>/SUMMARY.md: the tables README.md and
+DESIGN.md quote.  Nothing is typed by hand: every figure is a field of a committed file, named in the table's last column."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+D = os.path.join(ROOT, "profiles", RND)
+
+
+def J(name):
+    try:
+        return json.load(open(os.path.join(D, name)))
+    except Exception:
+        return None
+
+
+def kernel_us(wl, needle):
+    """average duration (us) and calls of the kernel whose name contains `needle`, from rocprofv3 --kernel-trace --stats"""
+    try:
+        rows = list(csv.DictReader(open(os.path.join(D, "bench_%s_kernel_stats.csv" % wl))))
+    except Exception:
+        return None
+    for r in rows:
+        if needle in r.get("Name", ""):
+            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    return None
+
+
+def main():
+    out = ["# profiles/%s — measured on one MI355X box by `scripts/gpu_profiles.sh`, tabulated by `scripts/make_tables.py`" % RND, ""]
+    out += ["Credited cells = the cells the reference's scalar band visits (SURVEY.md 8d); evaluated = the cells inside the half band the kernels "
+            "compute (DESIGN.md 3.1).  HBM fraction = algorithmic bytes / device time / 8 TB/s.  Fabric-side bytes = 128 x `TCC_EA0_RDREQ_128B` + "
+            "64 x `TCC_EA0_RDREQ_64B` + `WRITE_SIZE`, every kernel of one pass.  VALU cycles per instruction = 1024 SIMDs x `GRBM_GUI_ACTIVE`/8 / "
+            "`SQ_INSTS_VALU` of the dominant kernel.", ""]
+    out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
+            "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
+    for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg3", "cfg5", "cfg1"):
+        b = J("bench_%s.json" % wl)
+        if not b:
+            continue
+        base = wl.split("_")[0]
+        p = J("bench_%s_pmc.json" % base) if wl == base else None
+        r = b["roofline"]
+        v = r.get("valu_issue") or {}
+        ev = b.get("value_evaluated_cells")
+        tr = (p or {}).get("_traffic", {}).get("bytes_per_pass")
+        out.append("| %s | %.0f | %s | %.4f | %.4f | %.0f | %.1f %% | %s | %s | %s | %s | %s | `bench_%s.json`%s |" % (
+            wl, b["value"], "%.0f" % ev if ev else "—", b["ms_per_step"], r["device_ms_per_pass"], r["achieved"], 100 * r["frac"],
+            "%.2f" % (tr / r["algorithmic_bytes_per_pass"]) if tr else "—",
+            "%.3g" % v["valu_insts_per_launch"] if v else "—", "%.2f" % v["cycles_per_valu_inst_per_simd"] if v else "—",
+            "%.2f" % v["frac_of_2cycle_ceiling"] if v else "—",
+            "%.2f" % v["frac_of_mixed_stream_rate"] if v.get("frac_of_mixed_stream_rate") else "—",
+            wl, ", `bench_%s_pmc.json`" % base if p else ""))
+    out.append("")
+    b2 = J("bench_cfg2.json")
+    if b2 and b2.get("cpu_baseline"):
+        c = b2["cpu_baseline"]
+        out += ["## CPU baseline of the same run (cfg2, `bench_cfg2.json`)", "",
+                "%.1f GCUPS, effective cores %.1f, threads used %s; host: %s" % (c["value"], c["cores"], c.get("threads_used"), json.dumps(c.get("host"))), "",
+                "| restatement | GCUPS all threads | GCUPS one thread |", "|---|---|---|"]
+        for nm, (va, v1) in c.get("variants_gcups_all_threads_and_one_thread", {}).items():
+            out.append("| %s | %.2f | %.3f |" % (nm, va, v1))
+        out += ["", "thread scaling of the best variant (threads, GCUPS): " + ", ".join("%d: %.1f" % (t, g) for t, g in c.get("thread_scaling_gcups", [])), ""]
+    out += ["## Dominant kernels (rocprofv3 --kernel-trace --stats, `bench_cfgN_kernel_stats.csv`)", "", "| config | kernel | calls | average us |", "|---|---|---|---|"]
+    for wl, needle in (("cfg2", "lev_bits_kernel"), ("cfg4", "lev_bits"), ("cfg3", "lev_widebits_kernel"), ("cfg3", "bag_bound"), ("cfg5", "lev_filter_kernel"),
+                       ("cfg5", "lev_search_list"), ("cfg1", "hamming")):
+        k = kernel_us(wl, needle)
+        if k:
+            out.append("| %s | `%s` | %d | %.1f |" % (wl, needle, k[1], k[0]))
+    mix = J("isa_mix.json")
+    if mix:
+        out += ["", "## Inner loops (`isa_mix.json`, `inner_loop_cfgN.s`; scripts/isa_mix.py)", "",
+                "| config | kernel | instructions | VALU | full-rate / bitop3 / half-rate | s_nop | LDS | modelled cycles per VALU instr (per-opcode costs) | VGPRs |", "|" + "---|" * 9]
+        for wl, m in mix.items():
+            bc = m["by_class"]
+            out.append("| %s | `%s` | %d | %d | %d / %d / %d | %d | %d | %.2f | %d |" % (wl, m["kernel"][:70], m["instructions"], m["valu"], bc.get("full", 0),
+                                                                                         bc.get("bitop3", 0), bc.get("half", 0), m["s_nop"], m["lds"],
+                                                                                         m["modelled_cycles_per_valu_inst"], m.get("vgprs", 0)))
+    open(os.path.join(D, "SUMMARY.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

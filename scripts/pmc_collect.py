@@ -67,7 +67,7 @@ def main():
         out[k] = {"launches": max(len(v) for v in cs.values())}
         for c, v in cs.items():
             vv = v[-args.steps:] if len(v) >= args.steps else v
-            out[k][c] = {"mean_per_launch": sum(vv) / len(vv), "launches_averaged": len(vv), "launches_seen": len(v)}
+            out[k][c] = {"mean_per_launch": sum(vv) / len(vv), "launches_averaged": len(vv), "launches_seen": len(v), "sum_all_launches": sum(v)}
     def weight(k):
         d = out[k]
         return d.get("SQ_INSTS_VALU", {}).get("mean_per_launch", 0) * d["launches"] + d.get("FETCH_SIZE", {}).get("mean_per_launch", 0) * d["launches"]
@@ -76,6 +76,18 @@ def main():
         flat = dict(out[dom])
         flat["_dominant"] = dom
         flat["_kernels"] = out
+        # fabric-side bytes of one bench pass, every kernel of the path included: size-resolved read requests (32 / 64 / 128 B) +
+        # 64-byte write requests, summed over all launches and divided by the passes (= launches of the dominant kernel)
+        passes = out[dom]["launches"]
+        def tot(c):
+            return sum(d[c]["sum_all_launches"] for d in out.values() if c in d)
+        if any("TCC_EA0_RDREQ_128B_sum" in d for d in out.values()):
+            rd = 128.0 * tot("TCC_EA0_RDREQ_128B_sum") + 64.0 * tot("TCC_EA0_RDREQ_64B_sum")
+            wr = 1024.0 * tot("WRITE_SIZE")
+            flat["_traffic"] = {"bytes_per_pass": (rd + wr) / passes, "read_bytes_per_pass": rd / passes, "write_bytes_per_pass": wr / passes,
+                                "passes": passes, "fetch_size_x2_plus_write_size_bytes_per_pass": (2048.0 * tot("FETCH_SIZE") + wr) / passes,
+                                "method": "128 x TCC_EA0_RDREQ_128B + 64 x TCC_EA0_RDREQ_64B + WRITE_SIZE (KiB), all kernels of the pass; beside it "
+                                          "the guide's FETCH_SIZE x 2 + WRITE_SIZE"}
         flat["_command"] = "bench.py --workload %s --steps %d --warmup 1 --no-cpu %s" % (args.workload, args.steps, args.extra)
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         json.dump(flat, open(args.out, "w"), indent=1)

@@ -119,7 +119,9 @@ extern "C" int emu_lev_one(const uint8_t *a, uint64_t a_len, const uint8_t *b, u
     const size_t lds_bytes = (LEV_ONE_PAD_LO + max_len + LEV_ONE_PAD_HI + 15u) & ~(size_t)15;
     uint8_t *lds = (uint8_t *)malloc(lds_bytes);
     memset(lds, 0xA5, lds_bytes);                      // nothing may depend on what the pads hold
-    if (has_t) LevOne<EmuWave, true>::run(P, lds); else LevOne<EmuWave, false>::run(P, lds);
+    const bool wide = u + 1u + (has_t ? 2u : 0u) > 32u;
+    if (has_t) { if (wide) LevOne<EmuWave, true, true>::run(P, lds); else LevOne<EmuWave, true, false>::run(P, lds); }
+    else { if (wide) LevOne<EmuWave, false, true>::run(P, lds); else LevOne<EmuWave, false, false>::run(P, lds); }
     free(lds);
     return 0;
 }

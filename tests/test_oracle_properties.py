@@ -158,3 +158,14 @@ def test_select_ladder_on_baseline_configs():
     assert O.band_cells(256, 256, 32) == 15584
     assert O.band_cells(128, 128, 8, O.RDAMERAU_COSTS) == 2104
     assert O.band_cells(4096, 4096, 0xFFFFFFFF) == 4096 * 4096
+
+
+def test_scalar_choice_where_the_simd_blend_differs():
+    """The oracle (and so the product) returns the SCALAR path's value on the inputs where the reference's SIMD transposition
+    blend gives another one; the blend model reproduces the listed SIMD-side values, so the split is deliberate and visible."""
+    from scalar_vs_simd_cases import CASES, blend_model
+    for a, b, costs, scalar, blend in CASES:
+        assert O.levenshtein_naive_with_opts(a, b, False, costs)[0] == scalar
+        assert O.levenshtein_naive_k_with_opts(a, b, 10, False, costs)[0] == scalar
+        assert O.levenshtein_simd_k_with_opts(a, b, 10, False, costs)[0] == scalar        # the public-contract restatement: scalar rules
+        assert blend_model(a, b, costs[0], costs[1], costs[3]) == blend != scalar

@@ -46,18 +46,19 @@ hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool tra
     }
 }
 
-template <bool TRANS>
+template <bool TRANS, bool WIDE>
 __global__ __launch_bounds__(64) void lev_one_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    LevOne<DevWave, TRANS>::run(P, lds);
+    LevOne<DevWave, TRANS, WIDE>::run(P, lds);
 }
 
 // one pair, one wavefront (lev_one_body.h); max_len = the longer string (the launcher's promise: <= LEV_ONE_MAX_LEN, band <= 64)
 hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipStream_t s, uint32_t *lds_out) {
     const size_t lds = (LEV_ONE_PAD_LO + (size_t)max_len + LEV_ONE_PAD_HI + 15u) & ~(size_t)15;
     if (lds_out) *lds_out = (uint32_t)lds;
-    if (trans) hipLaunchKernelGGL(lev_one_kernel<true>, dim3(1), dim3(64), lds, s, P);
-    else hipLaunchKernelGGL(lev_one_kernel<false>, dim3(1), dim3(64), lds, s, P);
+    const bool wide = P.u + 1u + (trans ? 2u : 0u) > 32u;
+    if (trans) { if (wide) hipLaunchKernelGGL((lev_one_kernel<true, true>), dim3(1), dim3(64), lds, s, P); else hipLaunchKernelGGL((lev_one_kernel<true, false>), dim3(1), dim3(64), lds, s, P); }
+    else { if (wide) hipLaunchKernelGGL((lev_one_kernel<false, true>), dim3(1), dim3(64), lds, s, P); else hipLaunchKernelGGL((lev_one_kernel<false, false>), dim3(1), dim3(64), lds, s, P); }
     return hipGetLastError();
 }
 
