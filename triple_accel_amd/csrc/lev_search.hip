@@ -117,29 +117,35 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
     uint64_t i = emit_begin;
     const uint64_t full_end = emit_begin + ((emit_end - emit_begin) & ~(uint64_t)(FILTER_BLOCK - 1));
-    // a whole 64-byte block per lane is requested at once, one block ahead: each 128-byte line is touched by two bursts
-    // only, so it need not survive in L2 while the lane chews through it
-    u32x4u nxt[4];
+    // a whole 128-byte LINE per lane is requested at once (eight 16-byte loads in one burst, tiles start on 128-byte
+    // multiples), one line ahead: every line of the haystack crosses the L2's fabric side once (two 64-byte bursts 64 columns
+    // apart measured 1.31x: the second half had left the 4 MB L2 by the time its lane came back for it)
+    constexpr uint32_t LINE = 2 * FILTER_BLOCK;
+    u32x4u nxt[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++) nxt[q] = (i + 16u * q < emit_end) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
-    while (i < full_end) {                                        // whole 64-column blocks
-        u32x4u cur[4];
+    for (int q = 0; q < 8; q++) nxt[q] = (i + 16u * q < emit_end) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                        // whole 64-column blocks, two per line
+        u32x4u cur[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
 #pragma unroll
-        for (int q = 0; q < 4; q++)                               // blobs carry 16 bytes of slack
-            if (i + FILTER_BLOCK + 16u * q < emit_end) nxt[q] = *(const u32x4u *)(hay + i + FILTER_BLOCK + 16u * q);
-        bool any = false;
+        for (int q = 0; q < 8; q++)                               // blobs carry 16 bytes of slack
+            if (i + LINE + 16u * q < emit_end) nxt[q] = *(const u32x4u *)(hay + i + LINE + 16u * q);
+#pragma unroll 1
+        for (int blk = 0; blk < 2 && i < full_end; blk++) {
+            bool any = false;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < 4; q++) {
+                const u32x4u v = blk == 0 ? cur[q] : cur[4 + q];
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint32_t c = (cur[q][b >> 2] >> (8 * (b & 3))) & 0xffu;
-                any |= lev_filter_step<TRANS>(st, peq[c]) <= k;
+                for (int b = 0; b < 16; b++) {
+                    const uint32_t c = (v[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    any |= lev_filter_step<TRANS>(st, peq[c]) <= k;
+                }
             }
+            if (any) flag(i);
+            i += FILTER_BLOCK;
         }
-        if (any) flag(i);
-        i += FILTER_BLOCK;
     }
     if (i < emit_end) {                                           // the shard's last, partial block
         bool any = false;

@@ -125,7 +125,7 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
         SearchParams F = P;
         uint64_t ft = (h + 131071) / 131072;                          // one set of resident lanes (256 CUs x 8 waves x 64)
         if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
-        ft = (ft + FILTER_BLOCK - 1) / FILTER_BLOCK * FILTER_BLOCK;
+        ft = (ft + 2 * FILTER_BLOCK - 1) / (2 * FILTER_BLOCK) * (2 * FILTER_BLOCK);      // whole 128-byte lines per lane
         if (const char *e = env_str("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
         F.tile = (uint32_t)(ft > 0x7FFFFFC0ull ? 0x7FFFFFC0ull : ft);
         TA_HIP(lev_filter_launch(F, costs->has_transpose != 0, (uint32_t *)ls.dev, (uint32_t)cap_list, (unsigned int *)lc.dev, st));
