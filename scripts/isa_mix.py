@@ -37,7 +37,7 @@ KERNELS = [
     ("cfg2", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi9ELb0ELb1E\w*", "4 columns of 64 pairs (33-diagonal band, static window)"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
     ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
-    ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernel\w*", "haystack bytes per lane (bit-parallel filter scan)"),
+    ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernelILb0E\w*", "haystack bytes per lane (bit-parallel filter scan)"),
 ]
 
 
@@ -104,8 +104,14 @@ def hot_loop(body):
         return sum(v for v in per if v >= 12)
     hdr = max(groups, key=lambda h: valu(groups[h]))
     used, skipped, all_ins, texts = [], [], [], []
+    def nvalu(ins):
+        return sum(1 for x in ins if x.startswith("v_"))
+    def ragged(ins):
+        return any(x.startswith("v_cndmask") for x in ins) and any(x.startswith("v_cmp") for x in ins)
+    plain = [nvalu(ins) for _, ins, _ in groups[hdr] if not ragged(ins)]
     for lab, ins, text in groups[hdr]:
-        if len(groups[hdr]) > 1 and any(x.startswith("v_cndmask") for x in ins) and any(x.startswith("v_cmp") for x in ins):
+        # a block with the liveness select is left out only if the loop also holds its plain twin (a block of comparable size without it)
+        if ragged(ins) and any(v >= 0.5 * nvalu(ins) for v in plain):
             skipped.append(lab)
             continue
         used.append(lab)

@@ -30,6 +30,19 @@ def kernel_us(wl, needle):
     return None
 
 
+def mixed_rate():
+    """cycles per VALU instruction of a strictly alternating full-rate / half-rate stream at 4 waves per SIMD (ubench_mix.txt)"""
+    try:
+        ub = open(os.path.join(D, "ubench_mix.txt")).read()
+        sect = ub[ub.index("4 wave(s) per SIMD"):]
+        return float(sect[sect.index("xor/perm strictly alternating"):].split("ms")[1].split("cycles")[0])
+    except Exception:
+        return None
+
+
+MIXED = mixed_rate()
+
+
 def main():
     out = ["# profiles/%s — measured on one MI355X box by `scripts/gpu_profiles.sh`, tabulated by `scripts/make_tables.py`" % RND, ""]
     out += ["Credited cells = the cells the reference's scalar band visits (SURVEY.md 8d); evaluated = the cells inside the half band the kernels "
@@ -45,15 +58,18 @@ def main():
         base = wl.split("_")[0]
         p = J("bench_%s_pmc.json" % base) if wl == base else None
         r = b["roofline"]
-        v = r.get("valu_issue") or {}
         ev = b.get("value_evaluated_cells")
         tr = (p or {}).get("_traffic", {}).get("bytes_per_pass")
+        v = {}
+        if p and "SQ_INSTS_VALU" in p and "GRBM_GUI_ACTIVE" in p:
+            insts, busy = p["SQ_INSTS_VALU"]["mean_per_launch"], p["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+            cyc = 1024.0 * busy / insts
+            v = {"insts": insts, "cyc": cyc, "f2": 2.0 / cyc, "fm": MIXED / cyc if MIXED else None, "clock": busy / (kernel_us(base, p["_dominant"].split("::")[-1].split("<")[0]) or (1e9, 0))[0] / 1e3}
         out.append("| %s | %.0f | %s | %.4f | %.4f | %.0f | %.1f %% | %s | %s | %s | %s | %s | `bench_%s.json`%s |" % (
             wl, b["value"], "%.0f" % ev if ev else "—", b["ms_per_step"], r["device_ms_per_pass"], r["achieved"], 100 * r["frac"],
             "%.2f" % (tr / r["algorithmic_bytes_per_pass"]) if tr else "—",
-            "%.3g" % v["valu_insts_per_launch"] if v else "—", "%.2f" % v["cycles_per_valu_inst_per_simd"] if v else "—",
-            "%.2f" % v["frac_of_2cycle_ceiling"] if v else "—",
-            "%.2f" % v["frac_of_mixed_stream_rate"] if v.get("frac_of_mixed_stream_rate") else "—",
+            "%.3g" % v["insts"] if v else "—", "%.2f" % v["cyc"] if v else "—",
+            "%.2f" % v["f2"] if v else "—", "%.2f" % v["fm"] if v and v["fm"] else "—",
             wl, ", `bench_%s_pmc.json`" % base if p else ""))
     out.append("")
     b2 = J("bench_cfg2.json")
