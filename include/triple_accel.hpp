@@ -122,4 +122,32 @@ inline std::vector<Match> hamming_search(bytes needle, bytes haystack) {        
     return take_(m, n);
 }
 
+// ---- the reference's scalar entry points: the kernels implement the scalar rules, so these are the same calls under the other names
+inline std::uint32_t hamming_naive(bytes a, bytes b) { return hamming(a, b); }                                  // src/hamming.rs:36
+inline std::uint32_t hamming_words_64(bytes a, bytes b) { return hamming(a, b); }                               // :176
+inline std::uint32_t hamming_words_128(bytes a, bytes b) { return hamming(a, b); }                              // :249
+inline std::uint32_t hamming_simd_parallel(bytes a, bytes b) { return hamming(a, b); }                          // :317
+inline std::uint32_t hamming_simd_movemask(bytes a, bytes b) { return hamming(a, b); }                          // :354
+inline std::vector<Match> hamming_search_naive_with_opts(bytes needle, bytes haystack, std::uint32_t k, SearchType st) {   // :96 (no NUL-byte panic)
+    ta_match *m; std::size_t n;
+    check_(ta_hamming_search_naive_with_opts(needle.data(), needle.size(), haystack.data(), haystack.size(), k, (int)st, &m, &n));
+    return take_(m, n);
+}
+inline std::vector<Match> hamming_search_naive(bytes needle, bytes haystack) {                                   // :70
+    return hamming_search_naive_with_opts(needle, haystack, (std::uint32_t)((needle.size() >> 1) + (needle.size() & 1)), SearchType::Best);
+}
+inline std::optional<std::uint32_t> levenshtein_naive_k(bytes a, bytes b, std::uint32_t k) { return levenshtein_simd_k(a, b, k); }    // src/levenshtein.rs:342
+inline std::optional<std::pair<std::uint32_t, Traceback>> levenshtein_naive_k_with_opts(bytes a, bytes b, std::uint32_t k, bool trace_on, const EditCosts &costs) {
+    return levenshtein_simd_k_with_opts(a, b, k, trace_on, costs);                                               // :376
+}
+inline std::pair<std::uint32_t, Traceback> levenshtein_naive_with_opts(bytes a, bytes b, bool trace_on, const EditCosts &costs) {   // :148
+    return *levenshtein_simd_k_with_opts(a, b, 0xFFFFFFFFu, trace_on, costs);
+}
+inline std::uint32_t levenshtein_naive(bytes a, bytes b) { return levenshtein(a, b); }                          // :105
+inline std::vector<Match> levenshtein_search_naive_with_opts(bytes needle, bytes haystack, std::uint32_t k, SearchType st, const EditCosts &costs, bool anchored) {
+    return levenshtein_search_simd_with_opts(needle, haystack, k, st, costs, anchored);                          // :1589
+}
+inline std::vector<Match> levenshtein_search_naive(bytes needle, bytes haystack) { return levenshtein_search(needle, haystack); }   // :1549
+inline std::vector<Match> levenshtein_search_simd(bytes needle, bytes haystack) { return levenshtein_search(needle, haystack); }    // :1866
+
 }  // namespace triple_accel
