@@ -271,6 +271,26 @@ static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::ve
     CallCtx &cx = call_ctx();
     int rc = cx.ensure();
     if (rc) return rc;
+    // a short haystack goes through the thread's pinned, device-mapped buffer like a short pair does (ta_api.hip): the kernels
+    // read it in place and write their hits next to it -- no staging copy in, no copy of the hits out.  Room for the haystack
+    // and at least 64 hits; a denser result falls through to the general path below.
+    const size_t hay_pad = (haystack_len + TA_BLOB_SLACK + 255) & ~(size_t)255;
+    if (hay_pad + 64 * sizeof(ta_match) <= CallCtx::RESULT_OFF) {
+        const size_t pcap = (CallCtx::RESULT_OFF - hay_pad) / sizeof(ta_match);
+        if (haystack_len) memcpy(cx.pin, haystack, haystack_len);
+        memset(cx.pin + haystack_len, 0, TA_BLOB_SLACK);
+        uint64_t count = 0;
+        rc = launch((const uint8_t *)cx.pin_dev, (ta_match *)(cx.pin_dev + hay_pad), pcap, &count, cx.st);   // synchronises
+        if (rc == TA_OK) {
+            const ta_match *h = (const ta_match *)(cx.pin + hay_pad);
+            hits.assign(h, h + count);
+            std::sort(hits.begin(), hits.end(), [](const ta_match &x, const ta_match &y) {
+                return x.end != y.end ? x.end < y.end : x.start < y.start;
+            });
+            return TA_OK;
+        }
+        if (rc != TA_ERR_CAPACITY) return rc;
+    }
     Scratch &hs = tls_scratch(0), &ob = tls_scratch(1);
     if ((rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64))) return rc;
     size_t cap = haystack_len + 2;
