@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed passes for this long BEFORE the W warm-up steps: the input set-up on the host leaves the GPU idle for "
+                         "seconds and its clocks take longer than a handful of 0.4 ms passes to come back (0 = off)")
     return ap.parse_args()
 
 
@@ -249,8 +252,22 @@ def main():
         torch.cuda.synchronize()
 
     def timed_region(run, steps, warmup):
-        """W untimed warm-ups, then EXACTLY `steps` passes between barrier + synchronize; max over ranks.
-        -> (wall seconds, mean device ms per pass from HIP events on the launch stream)"""
+        """clock ramp (untimed, --prewarm-ms), W untimed warm-ups, then EXACTLY `steps` passes between barrier + synchronize;
+        max over ranks.  -> (wall seconds, mean device ms per pass from HIP events on the launch stream)"""
+        if args.prewarm_ms > 0:
+            # the number of ramp passes is agreed between the ranks (a pass may hold collectives): one timed pass, the maximum over ranks
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            n_ramp = int(min(4000, max(1, args.prewarm_ms / 1e3 / max(time.perf_counter() - t1, 1e-6))))
+            if world > 1:
+                tn = torch.tensor([n_ramp], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                n_ramp = int(tn.item())
+            for _ in range(n_ramp):
+                run()
+            torch.cuda.synchronize()
         for _ in range(warmup):
             run()
         barrier()
@@ -431,7 +448,7 @@ def main():
     evaluated_value = value * evaluated_unit / cells_unit if evaluated_unit else None
     line = {
         "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
-        "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "units_total": all_units,

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _bench(*flags):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", *flags],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--prewarm-ms", "20", *flags],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -20,6 +20,8 @@
 // the recurrence with or without spurious matches, and rows below a_len never feed the rows above them.
 // Strings are streamed HBM -> registers -> LDS, 64 bytes per string per refill (see run()).
 #pragma once
+#include <type_traits>
+
 #include "lev_band_body.h"
 
 namespace ta {
@@ -55,7 +57,9 @@ struct LevBits {
     }
 
     // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
-    template <bool CAP, int S = 0>
+    // ANSW >= 0: the answer diagonal's bit lies in word ANSW for every pair of the wavefront (fixed-length batches), so the
+    // count needs that word only -- one instruction per column less than the per-lane form (ANSW = -1)
+    template <bool CAP, int S = 0, int ANSW = -1>
     static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
         // STATIC: b_in holds the four column characters of the group, sub-column S takes byte S
         const U32 Bs = STATIC ? W::template splat_byte_n<S>(b_in) : W::splat_byte(b_in);
@@ -111,7 +115,8 @@ struct LevBits {
             const U32 D0s = (q + 1 < NW) ? W::template alignbit<1>(D0[q + 1], D0[q]) : (D0[q] >> 1);   // next window's rows
             st.VP[q] = HN | ~(D0s | HP);
             st.VN[q] = D0s & HP;
-            z = z | (D0[q] & M[q]);
+            if (ANSW < 0) z = z | (D0[q] & M[q]);
+            else if (q == ANSW) z = D0[q] & M[q];
             if (TRANS) { st.PMp[q] = PM[q]; st.D0p[q] = D0[q]; }
         }
         if (CAP) z = W::sel(live, z, W::splat(0));
@@ -168,7 +173,8 @@ struct LevBits {
 
         // ---- one span of iterations [tp, p_hi) on LDS-resident characters; addr_a(tp) / addr_b(tp) = LDS byte address of the
         // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3)
-        auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b) -> uint32_t {
+        auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b, auto answ_tag) -> uint32_t {
+            constexpr int AN = decltype(answ_tag)::value;
             if (STATIC) {
                 // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end)
                 const bool cap = W::any(valid & (t_stop < p_hi));
@@ -179,15 +185,15 @@ struct LevBits {
                     if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
                     const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
                     if (!cap) {
-                        column<false, 0>(st, b0, M, cnt, active);
-                        if (tp + 1u < p_hi) column<false, 1>(st, b1, M, cnt, active);
-                        if (tp + 2u < p_hi) column<false, 2>(st, b2, M, cnt, active);
-                        if (tp + 3u < p_hi) column<false, 3>(st, b3, M, cnt, active);
+                        column<false, 0, AN>(st, b0, M, cnt, active);
+                        if (tp + 1u < p_hi) column<false, 1, AN>(st, b1, M, cnt, active);
+                        if (tp + 2u < p_hi) column<false, 2, AN>(st, b2, M, cnt, active);
+                        if (tp + 3u < p_hi) column<false, 3, AN>(st, b3, M, cnt, active);
                     } else {
-                        column<true, 0>(st, b0, M, cnt, t_stop > tp);
-                        if (tp + 1u < p_hi) column<true, 1>(st, b1, M, cnt, t_stop > (tp + 1u));
-                        if (tp + 2u < p_hi) column<true, 2>(st, b2, M, cnt, t_stop > (tp + 2u));
-                        if (tp + 3u < p_hi) column<true, 3>(st, b3, M, cnt, t_stop > (tp + 3u));
+                        column<true, 0, AN>(st, b0, M, cnt, t_stop > tp);
+                        if (tp + 1u < p_hi) column<true, 1, AN>(st, b1, M, cnt, t_stop > (tp + 1u));
+                        if (tp + 2u < p_hi) column<true, 2, AN>(st, b2, M, cnt, t_stop > (tp + 2u));
+                        if (tp + 3u < p_hi) column<true, 3, AN>(st, b3, M, cnt, t_stop > (tp + 3u));
                     }
                 }
                 return tp;
@@ -200,19 +206,19 @@ struct LevBits {
 #pragma unroll
                     for (uint32_t s4 = 0; s4 < 4u; s4++) {
                         advance_a(st, W::lds_u8(lds, pa + s4));
-                        column<false>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
+                        column<false, 0, AN>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
                     }
                 }
                 for (; tp < p_hi; tp++) {
                     const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
                     advance_a(st, a_in);
-                    column<false>(st, b_in, M, cnt, active);
+                    column<false, 0, AN>(st, b_in, M, cnt, active);
                 }
             } else {
                 for (; tp < p_hi; tp++) {
                     const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
                     advance_a(st, a_in);
-                    column<true>(st, b_in, M, cnt, t_stop > tp);
+                    column<true, 0, AN>(st, b_in, M, cnt, t_stop > tp);
                 }
             }
             return tp;
@@ -278,15 +284,23 @@ struct LevBits {
             fetch_b(qb >> 3);
             for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
             for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
-            for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
-                commit_a(qa + RA - 1);                                  // into the slot of piece qa - 1, which the last block finished
-                commit_b(qb + RB - 1);
-                W::lds_wave_sync();
-                const uint32_t b_hi = tb + 16u < iters ? tb + 16u : iters;
-                tp = run_span(tp, b_hi,
-                              [&](uint32_t t) { return a_slot + fmod((int32_t)t - ca_s, 16 * RA); },
-                              [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); });
-            }
+            // the answer diagonal's bit index is the same in every lane: dhi + alen - blen (as idx_ans above, on the batch's lengths)
+            const uint32_t ans_u = diff_u <= P.u ? (uint32_t)WB - 1u - nlo_u + alen_u - blen_u : 0u;
+            auto blocks = [&](auto answ_tag) {
+                for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
+                    commit_a(qa + RA - 1);                                  // into the slot of piece qa - 1, which the last block finished
+                    commit_b(qb + RB - 1);
+                    W::lds_wave_sync();
+                    const uint32_t b_hi = tb + 16u < iters ? tb + 16u : iters;
+                    tp = run_span(tp, b_hi,
+                                  [&](uint32_t t) { return a_slot + fmod((int32_t)t - ca_s, 16 * RA); },
+                                  [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); }, answ_tag);
+                }
+            };
+            if (NW == 1) blocks(std::integral_constant<int, 0>());
+            else if (NW == 2 && (ans_u >> 5) == 0u) blocks(std::integral_constant<int, 0>());
+            else if (NW == 2) blocks(std::integral_constant<int, 1>());
+            else blocks(std::integral_constant<int, -1>());
         } else {
         // ---- CHUNK form (CSR batches: every pair has its own geometry).  Per (pair, string) LDS holds ONE 64-byte chunk [0,64)
         // plus the first 16 bytes of the next one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16)
@@ -329,7 +343,7 @@ struct LevBits {
                 // was issued at least 48 iterations ago)
                 const uint32_t p_hi = part == 0 ? (t_lo + 48u < t_hi ? t_lo + 48u : t_hi) : t_hi;
                 if (part == 1) { commit_look(); W::lds_wave_sync(); }
-                tp = run_span(tp, p_hi, [&](uint32_t t) { return ra + t; }, [&](uint32_t t) { return rb + t; });
+                tp = run_span(tp, p_hi, [&](uint32_t t) { return ra + t; }, [&](uint32_t t) { return rb + t; }, std::integral_constant<int, -1>());
             }
             if (t_hi < iters) {                                 // next chunk: registers -> LDS, then fetch the one after
                 commit_main();
