@@ -29,7 +29,8 @@ namespace ta {
 // STATIC: the bytes of `a` under the window stay put for 4 columns (sub-column s reads window bit i from byte i + s and
 // shifts the packed mismatch bits by s instead); the registers move a whole dword every 4th column.  Saves the NA
 // v_alignbyte per column of the sliding form at the price of 3 window bits.
-template <class W, int NA, bool TRANS, bool STATIC = false>
+// ANSW >= 0 (line-form launches only): the word that holds the answer diagonal's bit, known per launch for a fixed-length batch
+template <class W, int NA, bool TRANS, bool STATIC = false, int ANSW = -1>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
@@ -57,9 +58,9 @@ struct LevBits {
     }
 
     // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
-    // ANSW >= 0: the answer diagonal's bit lies in word ANSW for every pair of the wavefront (fixed-length batches), so the
-    // count needs that word only -- one instruction per column less than the per-lane form (ANSW = -1)
-    template <bool CAP, int S = 0, int ANSW = -1>
+    // AN >= 0: the answer diagonal's bit lies in word AN for every pair of the wavefront (fixed-length batches), so the
+    // count needs that word only -- fewer instructions per column than the per-lane form (AN = -1)
+    template <bool CAP, int S = 0, int AN = -1>
     static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
         // STATIC: b_in holds the four column characters of the group, sub-column S takes byte S
         const U32 Bs = STATIC ? W::template splat_byte_n<S>(b_in) : W::splat_byte(b_in);
@@ -115,8 +116,8 @@ struct LevBits {
             const U32 D0s = (q + 1 < NW) ? W::template alignbit<1>(D0[q + 1], D0[q]) : (D0[q] >> 1);   // next window's rows
             st.VP[q] = HN | ~(D0s | HP);
             st.VN[q] = D0s & HP;
-            if (ANSW < 0) z = z | (D0[q] & M[q]);
-            else if (q == ANSW) z = D0[q] & M[q];
+            if (AN < 0) z = z | (D0[q] & M[q]);
+            else if (q == AN) z = D0[q] & M[q];
             if (TRANS) { st.PMp[q] = PM[q]; st.D0p[q] = D0[q]; }
         }
         if (CAP) z = W::sel(live, z, W::splat(0));
@@ -284,7 +285,8 @@ struct LevBits {
             fetch_b(qb >> 3);
             for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
             for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
-            // the answer diagonal's bit index is the same in every lane: dhi + alen - blen (as idx_ans above, on the batch's lengths)
+            // the answer diagonal's bit index is the same in every lane: dhi + alen - blen (as idx_ans above, on the batch's lengths);
+            // the launcher picked the instantiation whose ANSW is its word (lev_bits_answer_word, lev_plan.h)
             const uint32_t ans_u = diff_u <= P.u ? (uint32_t)WB - 1u - nlo_u + alen_u - blen_u : 0u;
             auto blocks = [&](auto answ_tag) {
                 for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
@@ -297,11 +299,9 @@ struct LevBits {
                                   [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); }, answ_tag);
                 }
             };
-            if (NW == 1) blocks(std::integral_constant<int, 0>());
-            else if (NW == 2 && (ans_u >> 5) == 0u) blocks(std::integral_constant<int, 0>());
-            else if (NW == 2) blocks(std::integral_constant<int, 1>());
-            else blocks(std::integral_constant<int, -1>());
-        } else {
+            blocks(std::integral_constant<int, (ANSW >= 0 || NW > 1) ? ANSW : 0>());     // (a one-word window has its answer in word 0)
+            (void)ans_u;
+        } else if constexpr (ANSW < 0) {
         // ---- CHUNK form (CSR batches: every pair has its own geometry).  Per (pair, string) LDS holds ONE 64-byte chunk [0,64)
         // plus the first 16 bytes of the next one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16)
         // (the 16-byte pieces sit on the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk
