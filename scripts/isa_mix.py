@@ -114,9 +114,24 @@ def hot_loop(body, pick="largest"):
     def ragged(ins):
         return any(x.startswith("v_cndmask") for x in ins) and any(x.startswith("v_cmp") for x in ins)
     plain = [nvalu(ins) for _, ins, _ in groups[hdr] if not ragged(ins)]
+    # twins without a visible select (the compiler folded it into a bitop): the loop holds every column block twice, in the same
+    # order -- second half = the ragged-tail copies of the first.  Recognised by the big blocks pairing up in size.
+    big = [(lab, nvalu(ins)) for lab, ins, _ in groups[hdr] if nvalu(ins) >= 30]
+    twin_skip = set()
+    if len(big) >= 8 and len(big) % 2 == 0 and not any(ragged(ins) for _, ins, _ in groups[hdr]):
+        sizes = sorted(v for _, v in big)
+        if all(abs(sizes[i] - sizes[i + 1]) <= 3 for i in range(0, len(sizes), 2)):
+            seen = {}
+            for lab, v in big:                        # keep the first block of every size class pair, drop its twin
+                key = min(seen, key=lambda k: abs(k - v)) if seen and min(abs(k - v) for k in seen) <= 3 else None
+                if key is not None and seen[key] > 0:
+                    seen[key] -= 1
+                    twin_skip.add(lab)
+                else:
+                    seen[v] = seen.get(v, 0) + 1
     for lab, ins, text in groups[hdr]:
         # a block with the liveness select is left out only if the loop also holds its plain twin (a block of comparable size without it)
-        if ragged(ins) and any(v >= 0.5 * nvalu(ins) for v in plain):
+        if (ragged(ins) and any(v >= 0.5 * nvalu(ins) for v in plain)) or lab in twin_skip:
             skipped.append(lab)
             continue
         used.append(lab)

@@ -177,8 +177,9 @@ struct LevBits {
         auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b, auto answ_tag) -> uint32_t {
             constexpr int AN = decltype(answ_tag)::value;
             if (STATIC) {
-                // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end)
-                const bool cap = W::any(valid & (t_stop < p_hi));
+                // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end).
+                // (AN >= 0 = line form = one geometry for the wavefront: every live pair runs to the last column, no pair needs capping)
+                const bool cap = AN >= 0 ? false : W::any(valid & (t_stop < p_hi));
                 for (; tp < p_hi; tp += 4u) {
 #pragma unroll
                     for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
@@ -201,7 +202,7 @@ struct LevBits {
             }
             for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
                 advance_a(st, W::lds_u8(lds, addr_a(tp)));
-            if (!W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the span's end
+            if (AN >= 0 || !W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the span's end
                 for (; tp + 4u <= p_hi; tp += 4u) {        // four columns per address computation (the rings carry 4 bytes of wrap copy)
                     const U32 pa = addr_a(tp), pb = addr_b(tp);
 #pragma unroll
