@@ -82,7 +82,7 @@ def main():
             out.append("| %s | %.2f | %.3f |" % (nm, va, v1))
         out += ["", "thread scaling of the best variant (threads, GCUPS): " + ", ".join("%d: %.1f" % (t, g) for t, g in c.get("thread_scaling_gcups", [])), ""]
     out += ["## Dominant kernels (rocprofv3 --kernel-trace --stats, `bench_cfgN_kernel_stats.csv`)", "", "| config | kernel | calls | average us |", "|---|---|---|---|"]
-    for wl, needle in (("cfg2", "lev_bits_kernel"), ("cfg4", "lev_bits"), ("cfg3", "lev_widebits_kernel"), ("cfg3", "bag_bound"), ("cfg5", "lev_filter_kernel"),
+    for wl, needle in (("cfg2", "lev_bits_"), ("cfg4", "lev_bits"), ("cfg3", "lev_widebits_kernel"), ("cfg3", "bag_bound"), ("cfg5", "lev_filter_kernel"),
                        ("cfg5", "lev_search_list"), ("cfg1", "hamming")):
         k = kernel_us(wl, needle)
         if k:
