@@ -1,5 +1,6 @@
-"""How much of the band kernel's time is memory?  The same launch (1M pairs, 256 B, k = 32) with every pair reading the SAME
-256 bytes (stride 0: all hits in L1/L2, no HBM traffic) against the real batch; and the real batch at several occupancies."""
+"""How much of the band kernel's time is memory?  The same launch (cfg2: 1M pairs, 256 B, k = 32; EXP_WL=cfg4: 128 B, k = 8, RDAMERAU)
+with every pair reading the SAME bytes (stride 0: all hits in L1/L2, no HBM traffic) against the real batch; and the real batch
+under the environment switches given as arguments ("TA_BITS_WPB=1,TA_BITS_BLOCK_LDS=40000" ...; needs TA_TUNING=1)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,17 +9,19 @@ import datagen as Dg
 import triple_accel_amd as T
 from triple_accel_amd import batch as B
 
-n, L, k = 1_000_000, 256, 32
-a, b = Dg.pairs_random(0x7A02, n, L)
+CFG4 = os.environ.get("EXP_WL") == "cfg4"
+n, L, k = (1_000_000, 128, 8) if CFG4 else (1_000_000, 256, 32)
+COSTS = T.RDAMERAU_COSTS if CFG4 else T.LEVENSHTEIN_COSTS
+a, b = Dg.pairs_random(0x7A04 if CFG4 else 0x7A02, n, L)
 sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
 out = torch.empty(n, dtype=torch.int32, device="cuda")
 
 def dev_ms(fa, fb, reps=50):
-    for _ in range(5): B.levenshtein_k_batch(fa, fb, k, out=out)
+    for _ in range(5): B.levenshtein_k_batch(fa, fb, k, COSTS, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): B.levenshtein_k_batch(fa, fb, k, out=out)
+    for _ in range(reps): B.levenshtein_k_batch(fa, fb, k, COSTS, out=out)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 

@@ -15,25 +15,15 @@ extern int g_emu_force_ch;
 // ---- bit-parallel band kernel (lev_bits_body.h)
 #include "lev_bits_body.h"
 
-template <int NA> static void run_bits(const LevParams &P, bool trans, bool stat, uint32_t waves, int answ = -1) {
+template <int NA> static void run_bits(const LevParams &P, bool trans, bool stat, bool line, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     for (uint32_t w = 0; w < waves; w++) {
-        if constexpr (NA >= 9 && NA <= 16) {
-            if (stat && answ >= 0 && answ <= 1) {          // as lev_bits.hip: line-form launches specialised on the answer's word
-                if (trans) { if (answ) LevBits<EmuWave, NA, true, true, 1>::run(P, w, lds); else LevBits<EmuWave, NA, true, true, 0>::run(P, w, lds); }
-                else { if (answ) LevBits<EmuWave, NA, false, true, 1>::run(P, w, lds); else LevBits<EmuWave, NA, false, true, 0>::run(P, w, lds); }
-                continue;
-            }
-        }
+#define GO(T, S) do { if (line) LevBits<EmuWave, NA, T, S, true>::run(P, w, lds); else LevBits<EmuWave, NA, T, S, false>::run(P, w, lds); } while (0)
         if constexpr (NA >= 8) {
-            if (stat) {
-                if (trans) LevBits<EmuWave, NA, true, true>::run(P, w, lds);
-                else LevBits<EmuWave, NA, false, true>::run(P, w, lds);
-                continue;
-            }
+            if (stat) { if (trans) GO(true, true); else GO(false, true); continue; }
         }
-        if (trans) LevBits<EmuWave, NA, true, false>::run(P, w, lds);
-        else LevBits<EmuWave, NA, false, false>::run(P, w, lds);
+        if (trans) GO(true, false); else GO(false, false);
+#undef GO
     }
     free(lds);
 }
@@ -66,10 +56,9 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.stat; }
     const uint32_t waves = (n + 63) / 64;
     // fixed-length batches take the line form here whatever their length (the launcher keeps the chunk form up to one line per
-    // string -- a speed choice; the emulation covers the line form on short strings too), specialised on the answer's word
-    const int answ = (!a_off && !b_off) ? lev_bits_answer_word(pl, has_t != 0, a_len, b_len) : -1;
+    // string -- a speed choice; the emulation covers the line form on short strings too)
     switch (pl.NA) {
-#define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, waves, answ); break;
+#define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, !a_off && !b_off, waves); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
         CASE(13) CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(26) CASE(28) CASE(30) CASE(32)
 #undef CASE

@@ -157,6 +157,7 @@ struct EmuWave {
         for (int l = 0; l < 64; l++) r.v[l] = i == 0 ? q.v[l].x : i == 1 ? q.v[l].y : i == 2 ? q.v[l].z : q.v[l].w;
         return r;
     }
+    static Q128V qxor(Q128V q, uint32_t c) { for (int l = 0; l < 64; l++) { q.v[l].x ^= c; q.v[l].y ^= c; q.v[l].z ^= c; q.v[l].w ^= c; } return q; }
     static void lds_store16(uint8_t *lds, const U32 &off, const Q128V &q, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &q.v[i], 16);
     }

@@ -19,12 +19,12 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(Lev
     LevBits<DevWave, NA, TRANS, STATIC>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
-// line-form launches of the two-word static windows (NA = 9..16): the word of the answer diagonal's bit is a template argument
-template <int NA, bool TRANS, int ANSW>
+// line-form launches (fixed-length batches of strings longer than one line)
+template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_line_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, NA, TRANS, true, ANSW>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    LevBits<DevWave, NA, TRANS, STATIC, true>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
 template <int NA, bool TRANS>
@@ -71,26 +71,16 @@ hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipS
 }
 
 template <int NA>
-static hipError_t launch_na(const LevParams &P, bool trans, bool stat, uint32_t grid, uint32_t wpb, size_t lds, hipStream_t s, int answ) {
+static hipError_t launch_na(const LevParams &P, bool trans, bool stat, bool line, uint32_t grid, uint32_t wpb, size_t lds, hipStream_t s) {
     dim3 g(grid), b(64 * wpb);
-    if constexpr (NA >= 9 && NA <= 16) {
-        if (stat && answ >= 0 && answ <= 1) {       // fixed-length batch in the line form, two-word window: specialised on the answer's word
-            if (trans) { if (answ) hipLaunchKernelGGL((lev_bits_line_kernel<NA, true, 1>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_line_kernel<NA, true, 0>), g, b, lds, s, P); }
-            else { if (answ) hipLaunchKernelGGL((lev_bits_line_kernel<NA, false, 1>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_line_kernel<NA, false, 0>), g, b, lds, s, P); }
-            return hipGetLastError();
-        }
-    }
+#define TA_GO(T, S) do { if (line) hipLaunchKernelGGL((lev_bits_line_kernel<NA, T, S>), g, b, lds, s, P); \
+                         else hipLaunchKernelGGL((lev_bits_kernel<NA, T, S>), g, b, lds, s, P); return hipGetLastError(); } while (0)
     if constexpr (NA >= 8) {
-        if (stat) {
-            if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true, true>), g, b, lds, s, P);
-            else hipLaunchKernelGGL((lev_bits_kernel<NA, false, true>), g, b, lds, s, P);
-            return hipGetLastError();
-        }
+        if (stat) { if (trans) TA_GO(true, true); else TA_GO(false, true); }
     }
     if (stat) return hipErrorInvalidValue;
-    if (trans) hipLaunchKernelGGL((lev_bits_kernel<NA, true, false>), g, b, lds, s, P);
-    else hipLaunchKernelGGL((lev_bits_kernel<NA, false, false>), g, b, lds, s, P);
-    return hipGetLastError();
+    if (trans) TA_GO(true, false); else TA_GO(false, false);
+#undef TA_GO
 }
 
 hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
@@ -118,9 +108,8 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
-    const int answ = line_form ? lev_bits_answer_word(pl, trans, P.a.len, P.b.len) : -1;
     switch (pl.NA) {
-#define TA_CASE(n) case n: return launch_na<n>(P, trans, pl.stat, grid, wpb, lds, s, answ);
+#define TA_CASE(n) case n: return launch_na<n>(P, trans, pl.stat, line_form, grid, wpb, lds, s);
         TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)
         TA_CASE(9) TA_CASE(10) TA_CASE(11) TA_CASE(12) TA_CASE(13) TA_CASE(14) TA_CASE(15) TA_CASE(16)
         TA_CASE(18) TA_CASE(20) TA_CASE(22) TA_CASE(24) TA_CASE(26) TA_CASE(28) TA_CASE(30) TA_CASE(32)

@@ -7,9 +7,12 @@
 // matrix are in {-1, 0, +1} for unit costs, so a column is two bit-vectors (VP: +1, VN: -1) and a column step is
 // ~10 bitwise ops per 32 cells (Myers 1999; Hyyro 2003, "A bit-vector algorithm for computing Levenshtein and
 // Damerau edit distances", whose diagonal-band form is used here: the window slides one row down per column,
-// so a DIAGONAL is a fixed bit position and the distance is read off the answer cell's diagonal:
-//     d = |delta| + sum over columns (1 - D0[bit of that diagonal]),
-// D0 = "the cell equals its diagonal predecessor").  What dominates is no longer the recurrence but building
+// so a DIAGONAL is a fixed bit position and a cell's value is its diagonal's start plus the steps on it,
+//     D[r][j] on diagonal x = start(x) + sum over columns (1 - D0[bit of x]),
+// D0 = "the cell equals its diagonal predecessor").  The diagonal that is followed is the window's TOP one (bit 0, the same
+// in every lane: one v_alignbit per column shifts its D0 bit into a 32-column register, one v_bcnt per 32 columns counts them);
+// the answer cell sits idx_ans rows further down its column and is reached over that column's vertical differences:
+//     d = d_hi + b_len - zero steps on the top diagonal + popcount(VP & below) - popcount(VN & below).  What dominates is no longer the recurrence but building
 // the match vector: the window keeps `a` XOR 0x0C, so after the XOR with the column character a byte is 12 exactly
 // where the two agree; ONE v_perm_b32 with all-ones sources maps byte 12 to 0x00 and every other value to 0xFF (W::ne12),
 // and v_dot4_i32_i8 with the weights -1, -2, ... -128 adds eight such 0 / -1 flags up to their bit mask: 3 instructions
@@ -29,8 +32,9 @@ namespace ta {
 // STATIC: the bytes of `a` under the window stay put for 4 columns (sub-column s reads window bit i from byte i + s and
 // shifts the packed mismatch bits by s instead); the registers move a whole dword every 4th column.  Saves the NA
 // v_alignbyte per column of the sliding form at the price of 3 window bits.
-// ANSW >= 0 (line-form launches only): the word that holds the answer diagonal's bit, known per launch for a fixed-length batch
-template <class W, int NA, bool TRANS, bool STATIC = false, int ANSW = -1>
+// LINE: the line form of the fetch (fixed-length batches, see run()); else the chunk form -- one form per instantiation, so that a
+// kernel holds ONE copy of the column loop (two copies behind a wave-uniform branch cost 60 % more VGPRs and a wavefront per SIMD)
+template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
@@ -41,6 +45,9 @@ struct LevBits {
     using Q = typename W::Q;
     static constexpr uint32_t BITS_SLOT_A = 84;        // LDS bytes per pair for `a`: 64 + 16 look-ahead + 4 (odd number of dwords)
     static constexpr uint32_t BITS_SLOT_B = 68;        // ... for `b`: 64 + 4
+    // the sliding form takes `a` out of LDS a byte per column: its bytes are stored XOR 0x0C already (the static form reads a
+    // dword per 4 columns and XORs that)
+    static constexpr bool PREX = !STATIC;
 
     static constexpr uint32_t wmask(int q) { return (q == NW - 1 && (WB & 31)) ? ((1u << (WB & 31)) - 1u) : 0xFFFFFFFFu; }
 
@@ -48,20 +55,20 @@ struct LevBits {
         U32 VP[NW], VN[NW];     // vertical +1 / -1 differences of the previous column, at the current window's rows
         U32 AW[NA];             // byte i = a[row(i) - 1] ^ 0x0C, row(i) = j - d_hi + i: window bit i <-> byte i
         U32 PMp[NW], D0p[NW];   // TRANS: previous column's match vector and D0
+        U32 acc;                // D0 of the window's top diagonal (bit 0), the last columns' bits from bit 31 down; zeros below them
     };
 
     // the window moves one row down: byte i <- byte i+1, the next byte of `a` enters on top
     static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in) {
 #pragma unroll
         for (int k = 0; k < NA - 1; k++) st.AW[k] = W::template alignbyte<1>(st.AW[k + 1], st.AW[k]);
-        st.AW[NA - 1] = W::template alignbyte<1>(a_in ^ 0x0Cu, st.AW[NA - 1]);
+        st.AW[NA - 1] = W::template alignbyte<1>(a_in, st.AW[NA - 1]);      // (a_in = a ^ 0x0C: PREX)
     }
 
-    // One column: b_in = b[j-1].  M = one-hot mask of the answer diagonal; cnt += D0 on that diagonal (live lanes).
-    // AN >= 0: the answer diagonal's bit lies in word AN for every pair of the wavefront (fixed-length batches), so the
-    // count needs that word only -- fewer instructions per column than the per-lane form (AN = -1)
-    template <bool CAP, int S = 0, int AN = -1>
-    static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, const U32 (&M)[NW], U32 &cnt, Bool live) {
+    // One column: b_in = b[j-1].  D0 of the top diagonal is shifted into st.acc (CAP: a zero for lanes whose pair is finished;
+    // the caller counts and clears st.acc at least every 32 columns).
+    template <bool CAP, int S = 0>
+    static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 b_in, Bool live) {
         // STATIC: b_in holds the four column characters of the group, sub-column S takes byte S
         const U32 Bs = STATIC ? W::template splat_byte_n<S>(b_in) : W::splat_byte(b_in);
         U32 PM[NW], D0[NW], NE[NW];
@@ -108,7 +115,7 @@ struct LevBits {
             }
         }
         if (WB & 31) D0[NW - 1] = D0[NW - 1] & wmask(NW - 1);
-        U32 z = W::splat(0);
+        st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0[0], W::splat(0)) : D0[0], st.acc);
 #pragma unroll
         for (int q = 0; q < NW; q++) {
             const U32 HP = st.VN[q] | ~(D0[q] | st.VP[q]);
@@ -116,12 +123,8 @@ struct LevBits {
             const U32 D0s = (q + 1 < NW) ? W::template alignbit<1>(D0[q + 1], D0[q]) : (D0[q] >> 1);   // next window's rows
             st.VP[q] = HN | ~(D0s | HP);
             st.VN[q] = D0s & HP;
-            if (AN < 0) z = z | (D0[q] & M[q]);
-            else if (q == AN) z = D0[q] & M[q];
             if (TRANS) { st.PMp[q] = PM[q]; st.D0p[q] = D0[q]; }
         }
-        if (CAP) z = W::sel(live, z, W::splat(0));
-        cnt = W::bcnt(z, cnt);
     }
 
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
@@ -146,7 +149,6 @@ struct LevBits {
         const U32 idx_ans = W::sel(inband, (dhi + alen) - blen, W::splat(0));   // row a_len at column b_len
 
         State st;
-        U32 M[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
             const uint32_t lo = 32u * (uint32_t)q;
@@ -157,11 +159,27 @@ struct LevBits {
             st.VP[q] = ~below & wmask(q);
             st.PMp[q] = W::splat(0);
             st.D0p[q] = W::splat(wmask(q));
-            M[q] = W::sel((idx_ans >> 5) == (uint32_t)q, W::shlv(W::splat(1), idx_ans & 31u), W::splat(0));
         }
 #pragma unroll
         for (int k = 0; k < NA; k++) st.AW[k] = W::splat(0);
+        st.acc = W::splat(0);
         U32 cnt = W::splat(0);
+        uint32_t nacc = 0;                                     // columns whose bits (the top nacc of st.acc) are not counted yet, <= 32
+        auto flush = [&]() { cnt = W::bcnt(st.acc >> (32u - nacc), cnt); nacc = 0; };      // (nacc >= 1)
+        // the column just finished (st.VP / st.VN: bit i = the step from window row i to row i + 1): the way down from the top
+        // diagonal's cell to row a_len, idx_ans steps
+        auto way_down = [&]() -> U32 {
+            U32 t = W::splat(0);
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const uint32_t lo = 32u * (uint32_t)q;
+                const U32 mb = W::sel(idx_ans >= lo + 32u, W::splat(0xFFFFFFFFu),
+                                      W::sel(idx_ans <= lo, W::splat(0), W::shlv(W::splat(1), idx_ans - lo) - 1u));
+                t = W::bcnt(st.VP[q] & mb, t) - W::bcnt(st.VN[q] & mb, W::splat(0));
+            }
+            return t;
+        };
+        U32 tail = way_down();                                 // (column 0: a pair without columns ends here)
 
         // iteration tp inserts a[tp - ca] into the window and, from tp = T0 on, runs column tp - T0 + 1 with b[tp - T0]
         const uint32_t T0 = P.Tw;
@@ -173,61 +191,81 @@ struct LevBits {
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
         // ---- one span of iterations [tp, p_hi) on LDS-resident characters; addr_a(tp) / addr_b(tp) = LDS byte address of the
-        // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3)
-        auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b, auto answ_tag) -> uint32_t {
-            constexpr int AN = decltype(answ_tag)::value;
+        // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3).
+        // A pair whose last column has just run takes its way down from the state as it is now:
+        auto finished = [&](Bool fin) { if (W::any(fin)) tail = W::sel(fin, way_down(), tail); };
+        auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b, auto uniform_tag) -> uint32_t {
+            // UNI = line form = one geometry for the wavefront: every pair runs to the last column, none is capped, and the way
+            // down is taken once after the last span
+            constexpr bool UNI = decltype(uniform_tag)::value;
             if (STATIC) {
-                // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end).
-                // (AN >= 0 = line form = one geometry for the wavefront: every live pair runs to the last column, no pair needs capping)
-                const bool cap = AN >= 0 ? false : W::any(valid & (t_stop < p_hi));
+                // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end);
+                // the top diagonal's bits are counted when another group would not fit the register (every 8th group)
+                const bool cap = UNI ? false : W::any(t_stop < p_hi);
                 for (; tp < p_hi; tp += 4u) {
 #pragma unroll
                     for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
                     st.AW[NA - 1] = W::lds_read32u(lds, addr_a(tp)) ^ 0x0C0C0C0Cu;
                     if (tp < T0) continue;                 // warm-up: rows 1..nlo slide in
+                    if (__builtin_expect(nacc > 28u, 0)) flush();
                     const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = b0, b2 = b0, b3 = b0;   // one dword: column s is byte s
                     if (!cap) {
-                        column<false, 0, AN>(st, b0, M, cnt, active);
-                        if (tp + 1u < p_hi) column<false, 1, AN>(st, b1, M, cnt, active);
-                        if (tp + 2u < p_hi) column<false, 2, AN>(st, b2, M, cnt, active);
-                        if (tp + 3u < p_hi) column<false, 3, AN>(st, b3, M, cnt, active);
-                    } else {
-                        column<true, 0, AN>(st, b0, M, cnt, t_stop > tp);
-                        if (tp + 1u < p_hi) column<true, 1, AN>(st, b1, M, cnt, t_stop > (tp + 1u));
-                        if (tp + 2u < p_hi) column<true, 2, AN>(st, b2, M, cnt, t_stop > (tp + 2u));
-                        if (tp + 3u < p_hi) column<true, 3, AN>(st, b3, M, cnt, t_stop > (tp + 3u));
+                        column<false, 0>(st, b0, active);
+                        if (tp + 1u < p_hi) column<false, 1>(st, b1, active);
+                        if (tp + 2u < p_hi) column<false, 2>(st, b2, active);
+                        if (tp + 3u < p_hi) column<false, 3>(st, b3, active);
+                    } else {                               // (a pair's last column: live now, not in the next one)
+                        const Bool l0 = t_stop > tp, l1 = t_stop > (tp + 1u), l2 = t_stop > (tp + 2u), l3 = t_stop > (tp + 3u);
+                        column<true, 0>(st, b0, l0);
+                        finished(l0 & !l1);
+                        if (tp + 1u < p_hi) { column<true, 1>(st, b1, l1); finished(l1 & !l2); }
+                        if (tp + 2u < p_hi) { column<true, 2>(st, b2, l2); finished(l2 & !l3); }
+                        if (tp + 3u < p_hi) { column<true, 3>(st, b3, l3); finished(l3 & !(t_stop > (tp + 4u))); }
                     }
+                    nacc += p_hi - tp < 4u ? p_hi - tp : 4u;
                 }
+                if (!UNI && !cap) finished(t_stop == p_hi);
                 return tp;
             }
             for (; tp < p_hi && tp < T0; tp++)             // warm-up: rows 1..nlo slide in
                 advance_a(st, W::lds_u8(lds, addr_a(tp)));
-            if (AN >= 0 || !W::any(valid & (t_stop < p_hi))) {        // every pair still has columns up to the span's end
+            if (UNI || !W::any(t_stop < p_hi)) {           // every pair still has columns up to the span's end
                 for (; tp + 4u <= p_hi; tp += 4u) {        // four columns per address computation (the rings carry 4 bytes of wrap copy)
+                    if (__builtin_expect(nacc > 28u, 0)) flush();
                     const U32 pa = addr_a(tp), pb = addr_b(tp);
 #pragma unroll
                     for (uint32_t s4 = 0; s4 < 4u; s4++) {
                         advance_a(st, W::lds_u8(lds, pa + s4));
-                        column<false, 0, AN>(st, W::lds_u8(lds, pb + s4), M, cnt, active);
+                        column<false, 0>(st, W::lds_u8(lds, pb + s4), active);
                     }
+                    nacc += 4u;
                 }
                 for (; tp < p_hi; tp++) {
+                    if (nacc > 31u) flush();
                     const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
                     advance_a(st, a_in);
-                    column<false, 0, AN>(st, b_in, M, cnt, active);
+                    column<false, 0>(st, b_in, active);
+                    nacc++;
                 }
+                if (!UNI) finished(t_stop == p_hi);
             } else {
+                Bool live = t_stop > tp;
                 for (; tp < p_hi; tp++) {
+                    if (nacc > 31u) flush();
                     const U32 a_in = W::lds_u8(lds, addr_a(tp)), b_in = W::lds_u8(lds, addr_b(tp));
                     advance_a(st, a_in);
-                    column<true, 0, AN>(st, b_in, M, cnt, t_stop > tp);
+                    column<true, 0>(st, b_in, live);
+                    nacc++;
+                    const Bool next = t_stop > (tp + 1u);
+                    finished(live & !next);                // a pair's last column: live now, not in the next one
+                    live = next;
                 }
             }
             return tp;
         };
 
         const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
-        if (!P.a.off && !P.b.off && !(P.tune & 1u)) {
+        if constexpr (LINE) {
             // ---- LINE form (fixed-length batches, with or without a subset list): every 128-byte line of a string is requested
             // ONCE, whole -- eight 16-byte loads of the lane's own pair in one burst, parked in registers (2 x 8 x 16 bytes per
             // lane) -- and handed to LDS piece by piece: LDS holds a ring of 5 pieces of `a` and 4 pieces of `b` per pair, each followed by
@@ -259,9 +297,9 @@ struct LevBits {
                     SB[c] = W::gload16(W::ptr_add(bptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
                 }
             };
-            auto put = [&](const Q (&S)[8], int32_t piece, U32 dst, uint32_t wrap_copy_at) {     // wrap_copy_at: 0 = none
+            auto put = [&](const Q (&S)[8], int32_t piece, U32 dst, uint32_t wrap_copy_at, uint32_t x) {     // wrap_copy_at: 0 = none
                 switch (piece & 7) {                                   // wave-uniform: one of eight stores
-#define TA_PUT(c) case c: W::lds_store16(lds, dst, S[c], active); if (wrap_copy_at) W::lds_write32(lds, dst + wrap_copy_at, W::qword(S[c], 0)); break;
+#define TA_PUT(c) case c: { const Q q = x ? W::qxor(S[c], x) : S[c]; W::lds_store16(lds, dst, q, active); if (wrap_copy_at) W::lds_write32(lds, dst + wrap_copy_at, W::qword(q, 0)); } break;
                     TA_PUT(0) TA_PUT(1) TA_PUT(2) TA_PUT(3) TA_PUT(4) TA_PUT(5) TA_PUT(6) TA_PUT(7)
 #undef TA_PUT
                 }
@@ -269,12 +307,12 @@ struct LevBits {
             auto fmod = [](int32_t x, int32_t m) -> uint32_t { const int32_t r = x % m; return (uint32_t)(r < 0 ? r + m : r); };
             auto commit_a = [&](int32_t piece) {
                 const uint32_t slot = fmod(piece, RA);
-                put(SA, piece, a_slot + 16u * slot, slot == 0u ? 16u * RA : 0u);
+                put(SA, piece, a_slot + 16u * slot, slot == 0u ? 16u * RA : 0u, PREX ? 0x0C0C0C0Cu : 0u);
                 if ((piece & 7) == 7) fetch_a((piece >> 3) + 1);
             };
             auto commit_b = [&](int32_t piece) {
                 const uint32_t slot = fmod(piece, RB);
-                put(SB, piece, b_slot + 16u * slot, slot == 0u ? 16u * RB : 0u);
+                put(SB, piece, b_slot + 16u * slot, slot == 0u ? 16u * RB : 0u, 0u);
                 if ((piece & 7) == 7) fetch_b((piece >> 3) + 1);
             };
             uint32_t tp = STATIC ? (tp0 & ~3u) : tp0;
@@ -286,10 +324,7 @@ struct LevBits {
             fetch_b(qb >> 3);
             for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
             for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
-            // the answer diagonal's bit index is the same in every lane: dhi + alen - blen (as idx_ans above, on the batch's lengths);
-            // the launcher picked the instantiation whose ANSW is its word (lev_bits_answer_word, lev_plan.h)
-            const uint32_t ans_u = diff_u <= P.u ? (uint32_t)WB - 1u - nlo_u + alen_u - blen_u : 0u;
-            auto blocks = [&](auto answ_tag) {
+            {
                 for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
                     commit_a(qa + RA - 1);                                  // into the slot of piece qa - 1, which the last block finished
                     commit_b(qb + RB - 1);
@@ -297,12 +332,11 @@ struct LevBits {
                     const uint32_t b_hi = tb + 16u < iters ? tb + 16u : iters;
                     tp = run_span(tp, b_hi,
                                   [&](uint32_t t) { return a_slot + fmod((int32_t)t - ca_s, 16 * RA); },
-                                  [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); }, answ_tag);
+                                  [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); }, std::true_type());
                 }
-            };
-            blocks(std::integral_constant<int, (ANSW >= 0 || NW > 1) ? ANSW : 0>());     // (a one-word window has its answer in word 0)
-            (void)ans_u;
-        } else if constexpr (ANSW < 0) {
+            }
+            tail = way_down();                                  // every pair's last column was the last one run
+        } else {
         // ---- CHUNK form (CSR batches: every pair has its own geometry).  Per (pair, string) LDS holds ONE 64-byte chunk [0,64)
         // plus the first 16 bytes of the next one [64,80): the read position of iteration tp is tp + d - 64 kc with d in [0,16)
         // (the 16-byte pieces sit on the string's own 16-byte grid), so it may run up to 15 bytes past the chunk.  The next chunk
@@ -322,11 +356,11 @@ struct LevBits {
         auto commit_main = [&]() {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                W::lds_store16(lds, a_slot + 16u * p, S[p], active);
+                W::lds_store16(lds, a_slot + 16u * p, PREX ? W::qxor(S[p], 0x0C0C0C0Cu) : S[p], active);
                 W::lds_store16(lds, b_slot + 16u * p, S[4 + p], active);
             }
         };
-        auto commit_look = [&]() { W::lds_store16(lds, a_slot + 64u, S[0], active); };
+        auto commit_look = [&]() { W::lds_store16(lds, a_slot + 64u, PREX ? W::qxor(S[0], 0x0C0C0C0Cu) : S[0], active); };
         const uint32_t kc0 = tp0 / 64u;
         fetch(kc0);
         commit_main();
@@ -344,7 +378,7 @@ struct LevBits {
                 // was issued at least 48 iterations ago)
                 const uint32_t p_hi = part == 0 ? (t_lo + 48u < t_hi ? t_lo + 48u : t_hi) : t_hi;
                 if (part == 1) { commit_look(); W::lds_wave_sync(); }
-                tp = run_span(tp, p_hi, [&](uint32_t t) { return ra + t; }, [&](uint32_t t) { return rb + t; }, std::integral_constant<int, -1>());
+                tp = run_span(tp, p_hi, [&](uint32_t t) { return ra + t; }, [&](uint32_t t) { return rb + t; }, std::false_type());
             }
             if (t_hi < iters) {                                 // next chunk: registers -> LDS, then fetch the one after
                 commit_main();
@@ -354,7 +388,8 @@ struct LevBits {
         }
         }
 
-        const U32 d = (diff + blen) - cnt;                     // |delta| + columns - zero-difference steps
+        if (nacc) flush();
+        const U32 d = (dhi + blen) - cnt + tail;               // the top diagonal starts at d_hi; + columns - zero-difference steps + way down
         const Bool some = inband & (d <= P.k);                 // :539-541, :1166-1168
         W::store_u32(P.out, pair, W::sel(some, d, W::splat(0xFFFFFFFFu)), valid);
     }

@@ -127,17 +127,6 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     return p;
 }
 
-// Word of the bit-parallel band kernel's window that holds the answer diagonal's bit for a FIXED-LENGTH batch (lev_bits_body.h: bit
-// d_hi + a_len - b_len, d_hi = WB - 1 - nlo) -- the launcher picks the kernel instantiation specialised for it.  -1: not in band.
-static inline int lev_bits_answer_word(const LevBitsPlan &p, bool has_t, uint64_t a_len, uint64_t b_len) {
-    const uint64_t diff = a_len > b_len ? a_len - b_len : b_len - a_len;
-    if (diff > p.u) return -1;
-    const uint32_t wb = p.stat ? 4u * (uint32_t)p.NA - 3u : 4u * (uint32_t)p.NA;
-    const uint64_t nlo = ((p.u - diff) >> 1) + (b_len >= a_len ? 0 : diff) + (has_t ? 1u : 0u);
-    const uint64_t ans = (uint64_t)wb - 1u - nlo + a_len - b_len;
-    return (int)(ans >> 5);
-}
-
 // ---- two pairs per lane (lev_bits2_body.h): fixed-length unit-cost batches whose band (+ the transposition test's two extra
 // rows) is at most 15 diagonals wide, and big enough that halving the number of wavefronts still leaves >= 2 per SIMD
 struct LevBits2Plan {

@@ -169,6 +169,7 @@ struct DevWave {
         return q;
     }
     static __device__ __forceinline__ U32 qword(const Q128 &q, int i) { return i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w; }
+    static __device__ __forceinline__ Q128 qxor(Q128 q, uint32_t c) { q.x ^= c; q.y ^= c; q.z ^= c; q.w ^= c; return q; }
     static __device__ __forceinline__ void lds_store16(uint8_t *lds, U32 off, Q128 q, Bool pred) {
         if (pred) {   // 4-byte aligned only (slot stride is an odd number of dwords)
             uint32_t *d = (uint32_t *)(lds + off);
