@@ -39,6 +39,12 @@ struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
     static constexpr int NW = (WB + 31) / 32;          // dwords per bit-vector (also holds the 4*NA packed mismatch bits)
+    // ONEBIT: the window's last word holds ONE diagonal -- the band's bottom one (static windows of 33, 65, 97 bits: cfg2's 33).
+    // That cell has no left neighbour, so its vertical step stays +1 for ever (VP = 1, VN = 0 reproduce themselves) and its
+    // D0 is just  match | carry out of the words above;  it feeds the word above through D0 >> 1 and nothing else.  The
+    // recurrence then runs on NWF = NW - 1 full words plus one v_cndmask: 6 instructions per column less on cfg2.
+    static constexpr bool ONEBIT = STATIC && (WB % 32) == 1 && NW > 1;
+    static constexpr int NWF = ONEBIT ? NW - 1 : NW;   // words the recurrence keeps state for
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
@@ -92,39 +98,46 @@ struct LevBits {
             NE[q] = ne;
         }
 #pragma unroll
-        for (int q = 0; q < NW; q++) {                  // STATIC: window bit i is register byte i + S
+        for (int q = 0; q < NWF; q++) {                 // STATIC: window bit i is register byte i + S
             const U32 ne = (!STATIC || S == 0) ? NE[q] : ((q + 1 < NW) ? W::template alignbit<(S ? S : 1)>(NE[q + 1], NE[q]) : (NE[q] >> S));
             PM[q] = ~ne & wmask(q);
         }
+        // ONEBIT: bit 0 = "the bottom diagonal's characters match" (the bits above it are not used)
+        const U32 pm_bot = ONEBIT ? ~(S == 0 ? NE[NW - 1] : (NE[NW - 1] >> S)) : W::splat(0);
         // D0 = (((PM & VP) + VP) ^ VP) | PM | VN      (Hyyro 2003, eq. for the diagonal zero-difference vector)
         Bool carry = W::bfalse();
 #pragma unroll
-        for (int q = 0; q < NW; q++) {
+        for (int q = 0; q < NWF; q++) {
             U32 s;
             W::addc(PM[q] & st.VP[q], st.VP[q], carry, s, carry);
             D0[q] = ((s ^ st.VP[q]) | PM[q]) | st.VN[q];
         }
         if (TRANS) {
             // a[i-1] == b[j-2] && a[i-2] == b[j-1] (src/levenshtein.rs:517-521) and the diagonal step before was +1:
-            // D0 |= ~D0_prev & (PM << 1) & (PM_prev >> 1)      (window indices: a diagonal keeps its bit)
+            // D0 |= ~D0_prev & (PM << 1) & (PM_prev >> 1)      (window indices: a diagonal keeps its bit; ONEBIT: the bottom
+            // diagonal has nothing below it to swap with, its own match bit of the column before is st.PMp[NW - 1])
 #pragma unroll
-            for (int q = 0; q < NW; q++) {
+            for (int q = 0; q < NWF; q++) {
                 const U32 pml = q ? W::template alignbit<31>(PM[q], PM[q - 1]) : (PM[q] << 1);
                 const U32 pmr = (q + 1 < NW) ? W::template alignbit<1>(st.PMp[q + 1], st.PMp[q]) : (st.PMp[q] >> 1);
                 D0[q] = D0[q] | (~st.D0p[q] & pml & pmr);
             }
         }
-        if (WB & 31) D0[NW - 1] = D0[NW - 1] & wmask(NW - 1);
+        if (!ONEBIT && (WB & 31)) D0[NW - 1] = D0[NW - 1] & wmask(NW - 1);
+        // ONEBIT: the bottom diagonal's D0 = match | carry, in bit 0
+        const U32 d0_bot = ONEBIT ? W::sel(carry, W::splat(0xFFFFFFFFu), pm_bot) : W::splat(0);
         st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0[0], W::splat(0)) : D0[0], st.acc);
 #pragma unroll
-        for (int q = 0; q < NW; q++) {
+        for (int q = 0; q < NWF; q++) {
             const U32 HP = st.VN[q] | ~(D0[q] | st.VP[q]);
             const U32 HN = D0[q] & st.VP[q];
-            const U32 D0s = (q + 1 < NW) ? W::template alignbit<1>(D0[q + 1], D0[q]) : (D0[q] >> 1);   // next window's rows
+            const U32 D0s = (q + 1 < NWF) ? W::template alignbit<1>(D0[q + 1], D0[q])                     // next window's rows
+                                          : (ONEBIT ? W::template alignbit<1>(d0_bot, D0[q]) : (D0[q] >> 1));
             st.VP[q] = HN | ~(D0s | HP);
             st.VN[q] = D0s & HP;
             if (TRANS) { st.PMp[q] = PM[q]; st.D0p[q] = D0[q]; }
         }
+        if (TRANS && ONEBIT) st.PMp[NW - 1] = pm_bot;
     }
 
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
