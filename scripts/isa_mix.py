@@ -34,7 +34,7 @@ HALF = 4.2
 
 # (config, translation unit, mangled-name regex of the dominant kernel, columns / steps one iteration of the block advances)
 KERNELS = [
-    ("cfg2", "lev_bits.hip", r"_ZN2ta20lev_bits_line_kernelILi9ELb0ELb1E\w*", "4 columns of 64 pairs (33-diagonal band, static window, line form)"),
+    ("cfg2", "lev_bits.hip", r"_ZN2ta18lev_bits_s8_kernelILb0ELb1E\w*", "8 columns of 64 pairs (33-diagonal band, stride-8 window, line form)"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
     ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
     ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernelILb0E\w*", "haystack bytes per lane (bit-parallel filter scan)"),

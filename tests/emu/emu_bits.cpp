@@ -53,10 +53,20 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
-    if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.stat; }
+    if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.s8 ? 3 : pl.stat; }
     const uint32_t waves = (n + 63) / 64;
     // fixed-length batches take the line form here whatever their length (the launcher keeps the chunk form up to one line per
     // string -- a speed choice; the emulation covers the line form on short strings too)
+    if (pl.s8) {
+        uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
+        const bool line = !a_off && !b_off;
+        for (uint32_t w = 0; w < waves; w++) {
+            if (has_t) { if (line) LevBits<EmuWave, 8, true, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, true, false, false, true>::run(P, w, lds); }
+            else { if (line) LevBits<EmuWave, 8, false, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, false, true>::run(P, w, lds); }
+        }
+        free(lds);
+        return 0;
+    }
     switch (pl.NA) {
 #define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, !a_off && !b_off, waves); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)

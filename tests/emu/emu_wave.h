@@ -165,6 +165,11 @@ struct EmuWave {
     static U32 lds_read32u(const uint8_t *lds, const U32 &off) { return lds_read32(lds, off); }
     template <int N>
     static U32 splat_byte_n(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) * 0x01010101u; return r; }
+    template <int N>
+    static U32 slide_in_byte(const U32 &hi, const U32 &lo) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (lo.v[i] >> 8) | (((hi.v[i] >> (8 * N)) & 0xffu) << 24); return r; }
+    static U32 and_or(const U32 &a, uint32_t m, const U32 &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m) | c.v[i]; return r; }
+    template <int N>
+    static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }
     static U32 lds_read32(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], lds + off.v[i], 4); return r; }
     static void lds_write32(uint8_t *lds, const U32 &off, const U32 &v) { for (int i = 0; i < 64; i++) memcpy(lds + off.v[i], &v.v[i], 4); }
     static void lds_or32(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) {

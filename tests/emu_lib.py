@@ -87,7 +87,7 @@ def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, for
 
 
 def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
-    """Bit-parallel band kernel body (unit costs).  static: 0 planner's choice, 1 sliding window, 2 static window.
+    """Bit-parallel band kernel body (unit costs).  static: 0 planner's choice, 1 sliding window, 2 static window, 3 stride-8 window.
     -> (list of dist|None, plan dict)"""
     lib().emu_lev_set_chunk(int(chunk))
     n = len(a_list)
@@ -102,7 +102,7 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
     if rc:
         raise RuntimeError("emu_lev_bits rc=%d" % rc)
     res = [None if int(x) == 0xFFFFFFFF else int(x) for x in out]
-    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=bool(plan[3]))
+    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
 def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
@@ -122,7 +122,7 @@ def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
     if rc:
         raise RuntimeError("emu_lev_bits_any rc=%d" % rc)
     res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
-    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=bool(plan[3]))
+    return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
 def lev_bits2(a2d, b2d, k, trans=False, subset=None):

@@ -53,7 +53,7 @@ def test_bits_cfg2_cfg4_shapes():
     a = [x.tobytes() for x in ar] + [x.tobytes() for x in am]
     b = [x.tobytes() for x in br] + [x.tobytes() for x in bm]
     got, plan = E.lev_bits(a, b, 32, False)
-    assert plan["NA"] == 9 and got == oracle(a, b, 32, False)
+    assert plan["s8"] and got == oracle(a, b, 32, False)
     assert sum(x is not None for x in got) >= 60
     ar, br = Dg.pairs_random(0x7A04, 40, 128)
     am, bm = Dg.pairs_mutated_fixed(0x7A14, 90, 128, 8, swaps=True)
@@ -116,9 +116,38 @@ def test_bits_static_window_form(trans):
         assert got == slid == oracle(ea, eb, k, trans), (k, trans, plan, plan2)
 
 
+@pytest.mark.parametrize("trans", [False, True])
+def test_bits_stride8_window_form(trans):
+    """The stride-8 form (33 diagonals in 8 registers, register m = the bytes of window bits m, m+8, m+16, m+24; renamed, not
+    moved, from column to column; the 33rd diagonal as match | carry) against the oracle and the sliding form: every k it serves,
+    ragged lengths (blocks of 8 columns cut by a pair's end, pairs ending inside a block while others run on), several chunks,
+    pairs whose only optimal path runs along a band edge."""
+    a, b = make_pairs(0x57A8, 140, 300, 20, trans)
+    kmax = 33 - 1 - (2 if trans else 0)
+    for k in sorted({0, 1, 5, 17, 24, kmax - 1, kmax}):
+        got, plan = E.lev_bits(a, b, k, trans, static=3)
+        assert plan["s8"] and plan["NA"] == 8
+        assert got == oracle(a, b, k, trans), (k, trans, plan)
+    for dist in (30, 32):
+        ea, eb = _edge_pairs(0xB175 + dist, 70, 80, dist)
+        for k in (kmax - 2, kmax - 1, kmax):
+            got, plan = E.lev_bits(ea, eb, k, trans, static=3)
+            slid, plan2 = E.lev_bits(ea, eb, k, trans, static=1)
+            assert plan["s8"] and not plan2["s8"] and not plan2["static"]
+            assert got == slid == oracle(ea, eb, k, trans), (dist, k, trans, plan, plan2)
+    # short strings, empty strings, one side empty
+    sa = [b"", b"a", b"", b"abc", b"kitten", b"x" * 40, b"ab" * 9]
+    sb = [b"", b"", b"b", b"abd", b"sitting", b"x" * 9, b"ba" * 9]
+    for k in (0, 3, kmax):
+        got, plan = E.lev_bits(sa, sb, k, trans, static=3)
+        assert plan["s8"] and got == oracle(sa, sb, k, trans), (k, trans)
+
+
 def test_bits_planner_picks_the_static_form_from_8_dwords():
     got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 32, False)
-    assert plan["static"] and plan["NA"] == 9                                 # cfg2: 33 diagonals in a 36-byte window
+    assert plan["s8"] and plan["NA"] == 8                                     # cfg2: 33 diagonals, the stride-8 form
+    got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 20, False)
+    assert not plan["s8"] and not plan["static"] and plan["NA"] == 6          # 21 diagonals: the sliding form is cheaper
     got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 8, True)
     assert not plan["static"] and plan["NA"] == 3                             # cfg4: too narrow to pay for itself
     got, plan = E.lev_bits([b"a" * 300], [b"b" * 300], 33, False)
@@ -175,8 +204,10 @@ def test_emu_bits_fixed_length_coalesced(la, lb, k, trans):
     a, b = _fixed_batch(la * 7 + lb + k, 150, la, lb, k, swaps=trans)
     costs = (1, 1, 0, 1 if trans else None)
     want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(150)]
-    for static in (1, 2):
+    for static in (1, 2, 3):
         if static == 2 and k >= 124:
+            continue
+        if static == 3 and k + 1 + (2 if trans else 0) > 33:
             continue
         got, plan = E.lev_bits_fixed(a, b, k, trans, static=static)
         assert got == want, (la, lb, k, trans, static, plan)

@@ -27,6 +27,14 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_line_kerne
     LevBits<DevWave, NA, TRANS, STATIC, true>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
+// stride-8 form (bands of up to 33 diagonals), either fetch form
+template <bool TRANS, bool LINE>
+__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6;
+    LevBits<DevWave, 8, TRANS, false, LINE, true>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+}
+
 template <int NA, bool TRANS>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -108,6 +116,12 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
+    if (pl.s8) {
+        dim3 g(grid), b(64 * wpb);
+        if (trans) { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<true, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<true, false>), g, b, lds, s, P); }
+        else { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<false, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<false, false>), g, b, lds, s, P); }
+        return hipGetLastError();
+    }
     switch (pl.NA) {
 #define TA_CASE(n) case n: return launch_na<n>(P, trans, pl.stat, line_form, grid, wpb, lds, s);
         TA_CASE(1) TA_CASE(2) TA_CASE(3) TA_CASE(4) TA_CASE(5) TA_CASE(6) TA_CASE(7) TA_CASE(8)

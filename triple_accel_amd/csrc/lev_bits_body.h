@@ -34,16 +34,25 @@ namespace ta {
 // v_alignbyte per column of the sliding form at the price of 3 window bits.
 // LINE: the line form of the fetch (fixed-length batches, see run()); else the chunk form -- one form per instantiation, so that a
 // kernel holds ONE copy of the column loop (two copies behind a wave-uniform branch cost 60 % more VGPRs and a wavefront per SIMD)
-template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false>
+// S8: the STRIDE-8 form of the 33-diagonal window (NA = 8, bands of up to 33 diagonals: cfg2).  The 32 bytes of `a` under window
+// bits 0..31 sit in 8 registers with register m holding the bytes of bits m, m + 8, m + 16, m + 24.  Then
+//   * the mismatch flags of register m (0x00 / 0xFF per byte, v_xor + v_perm as everywhere) only need masking with
+//     0x01010101 << m and OR-ing together -- one v_and_or_b32 per register -- to land on their window bits: no Horner shifts;
+//   * the window moves one row down per column by RENAMING the registers (m <- m + 1) and pushing the new byte into the one
+//     register that wraps around (one v_perm_b32); the loop is unrolled 8 columns so the names are fixed: no moves at all;
+//   * the 33rd diagonal is the ONEBIT one (below): its byte is the one about to enter, its match a v_cmp on that byte.
+// 39 VALU instructions per column instead of 48 (static form).
+template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
-    static constexpr int WB = STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
+    static_assert(!S8 || (NA == 8 && !STATIC), "the stride-8 form is its own window layout: 8 registers, 33 diagonals");
+    static constexpr int WB = S8 ? 33 : STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
     static constexpr int NW = (WB + 31) / 32;          // dwords per bit-vector (also holds the 4*NA packed mismatch bits)
     // ONEBIT: the window's last word holds ONE diagonal -- the band's bottom one (static windows of 33, 65, 97 bits: cfg2's 33).
     // That cell has no left neighbour, so its vertical step stays +1 for ever (VP = 1, VN = 0 reproduce themselves) and its
     // D0 is just  match | carry out of the words above;  it feeds the word above through D0 >> 1 and nothing else.  The
     // recurrence then runs on NWF = NW - 1 full words plus one v_cndmask: 6 instructions per column less on cfg2.
-    static constexpr bool ONEBIT = STATIC && (WB % 32) == 1 && NW > 1;
+    static constexpr bool ONEBIT = (STATIC || S8) && (WB % 32) == 1 && NW > 1;
     static constexpr int NWF = ONEBIT ? NW - 1 : NW;   // words the recurrence keeps state for
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
@@ -53,7 +62,7 @@ struct LevBits {
     static constexpr uint32_t BITS_SLOT_B = 68;        // ... for `b`: 64 + 4
     // the sliding form takes `a` out of LDS a byte per column: its bytes are stored XOR 0x0C already (the static form reads a
     // dword per 4 columns and XORs that)
-    static constexpr bool PREX = !STATIC;
+    static constexpr bool PREX = !STATIC && !S8;
 
     static constexpr uint32_t wmask(int q) { return (q == NW - 1 && (WB & 31)) ? ((1u << (WB & 31)) - 1u) : 0xFFFFFFFFu; }
 
@@ -140,6 +149,38 @@ struct LevBits {
         if (TRANS && ONEBIT) st.PMp[NW - 1] = pm_bot;
     }
 
+    // S8: iteration tp with C = tp % 8, warm-up or column.  Before it, register r holds the bytes of window bits
+    // ((r - C) & 7) + 8 q; b_dw / a_raw = the dwords whose byte C & 3 is this iteration's column character / the byte of `a` that
+    // enters (it is the bottom diagonal's byte now and the top byte of register C afterwards); a_x = a_raw ^ 0x0C0C0C0C.
+    template <bool CAP, int C, bool COLUMN>
+    static TA_HD inline __attribute__((always_inline)) void step8(State &st, U32 b_dw, U32 a_raw, U32 a_x, Bool live) {
+        if (COLUMN) {
+            const U32 Bs = W::template splat_byte_n<(C & 3)>(b_dw);
+            U32 t = W::ne12(st.AW[C] ^ Bs) & 0x01010101u;                    // register C holds bits 0, 8, 16, 24
+#pragma unroll
+            for (int m = 1; m < 8; m++) t = W::and_or(W::ne12(st.AW[(C + m) & 7] ^ Bs), 0x01010101u << m, t);
+            const Bool m_bot = W::template byte_eq<(C & 3)>(a_raw, b_dw);
+            const U32 PM = ~t;
+            Bool carry = W::bfalse();
+            U32 sum;
+            W::addc(PM & st.VP[0], st.VP[0], carry, sum, carry);
+            U32 D0 = ((sum ^ st.VP[0]) | PM) | st.VN[0];
+            if (TRANS) {   // as column(): the bottom diagonal's own match bit of the column before is st.PMp[1] bit 0
+                const U32 pml = PM << 1, pmr = W::template alignbit<1>(st.PMp[NW - 1], st.PMp[0]);
+                D0 = D0 | (~st.D0p[0] & pml & pmr);
+            }
+            const U32 d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));          // ONEBIT: match | carry
+            st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0, W::splat(0)) : D0, st.acc);
+            const U32 HP = st.VN[0] | ~(D0 | st.VP[0]);
+            const U32 HN = D0 & st.VP[0];
+            const U32 D0s = W::template alignbit<1>(d0_bot, D0);
+            st.VP[0] = HN | ~(D0s | HP);
+            st.VN[0] = D0s & HP;
+            if (TRANS) { st.PMp[0] = PM; st.D0p[0] = D0; st.PMp[NW - 1] = W::sel(m_bot, W::splat(1), W::splat(0)); }
+        }
+        st.AW[C] = W::template slide_in_byte<(C & 3)>(a_x, st.AW[C]);
+    }
+
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
         const U32 lane = W::lane();
         const U32 grp = lane;
@@ -211,6 +252,44 @@ struct LevBits {
             // UNI = line form = one geometry for the wavefront: every pair runs to the last column, none is capped, and the way
             // down is taken once after the last span
             constexpr bool UNI = decltype(uniform_tag)::value;
+            if constexpr (S8) {
+                // blocks of 8 iterations (tp a multiple of 8, like T0 and the span limits except the very end): two dwords of each
+                // string, eight steps with their register names fixed
+                const bool cap = UNI ? false : W::any(t_stop < p_hi);
+                for (; tp < p_hi; tp += 8u) {
+                    const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
+                    const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
+                    if (tp < T0) {                         // warm-up: rows 1..nlo slide in (whole blocks: T0 is a multiple of 64)
+                        step8<false, 0, false>(st, x0, r0, x0, active); step8<false, 1, false>(st, x0, r0, x0, active);
+                        step8<false, 2, false>(st, x0, r0, x0, active); step8<false, 3, false>(st, x0, r0, x0, active);
+                        step8<false, 4, false>(st, x1, r1, x1, active); step8<false, 5, false>(st, x1, r1, x1, active);
+                        step8<false, 6, false>(st, x1, r1, x1, active); step8<false, 7, false>(st, x1, r1, x1, active);
+                        continue;
+                    }
+                    if (__builtin_expect(nacc > 24u, 0)) flush();
+                    const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
+                    const uint32_t left = p_hi - tp;       // >= 1 columns of this block run
+                    if (!cap) {
+                        step8<false, 0, true>(st, b0, r0, x0, active);
+                        if (left > 1u) step8<false, 1, true>(st, b0, r0, x0, active);
+                        if (left > 2u) step8<false, 2, true>(st, b0, r0, x0, active);
+                        if (left > 3u) step8<false, 3, true>(st, b0, r0, x0, active);
+                        if (left > 4u) step8<false, 4, true>(st, b1, r1, x1, active);
+                        if (left > 5u) step8<false, 5, true>(st, b1, r1, x1, active);
+                        if (left > 6u) step8<false, 6, true>(st, b1, r1, x1, active);
+                        if (left > 7u) step8<false, 7, true>(st, b1, r1, x1, active);
+                    } else {                               // (a pair's last column: live now, not in the next one)
+                        Bool l = t_stop > tp, n;
+#define TA_STEP8(c, bw, rw, xw) if (left > (uint32_t)c) { n = t_stop > (tp + (uint32_t)c + 1u); step8<true, c, true>(st, bw, rw, xw, l); finished(l & !n); l = n; }
+                        TA_STEP8(0, b0, r0, x0) TA_STEP8(1, b0, r0, x0) TA_STEP8(2, b0, r0, x0) TA_STEP8(3, b0, r0, x0)
+                        TA_STEP8(4, b1, r1, x1) TA_STEP8(5, b1, r1, x1) TA_STEP8(6, b1, r1, x1) TA_STEP8(7, b1, r1, x1)
+#undef TA_STEP8
+                    }
+                    nacc += left < 8u ? left : 8u;
+                }
+                if (!UNI && !cap) finished(t_stop == p_hi);
+                return tp;
+            }
             if (STATIC) {
                 // groups of 4 iterations (tp a multiple of 4; T0 and the span limits are multiples of 4 except the very end);
                 // the top diagonal's bits are counted when another group would not fit the register (every 8th group)
@@ -328,7 +407,7 @@ struct LevBits {
                 put(SB, piece, b_slot + 16u * slot, slot == 0u ? 16u * RB : 0u, 0u);
                 if ((piece & 7) == 7) fetch_b((piece >> 3) + 1);
             };
-            uint32_t tp = STATIC ? (tp0 & ~3u) : tp0;
+            uint32_t tp = S8 ? (tp0 & ~7u) : STATIC ? (tp0 & ~3u) : tp0;
             const uint32_t tb0 = tp & ~15u;
             // pieces the first block reads: a string offset x lives in piece x >> 4 (arithmetic shift: offsets before the string
             // are pieces < 0, delivered as zeros)
@@ -386,6 +465,7 @@ struct LevBits {
             const U32 ra = a_slot + da - t_lo, rb = b_slot + db - t_lo;   // LDS address = r + tp
             uint32_t tp = t_lo > tp0 ? t_lo : tp0;
             if (STATIC) tp &= ~3u;                             // whole groups (the extra leading iterations slide zeros in)
+            if (S8) tp &= ~7u;
             for (int part = 0; part < 2; part++) {
                 // the last 16 iterations of a chunk may read into the look-ahead bytes: commit them first (the fetch
                 // was issued at least 48 iterations ago)

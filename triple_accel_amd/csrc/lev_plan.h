@@ -90,16 +90,18 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32
 
 // ---- bit-parallel band kernel (lev_bits_body.h): unit costs only, one pair per lane, window of 4*NA diagonals
 static const int LEV_BITS_MAX_NA = 32;      // kernels exist for NA = 1..16 and the even NA up to 32
+static const uint32_t LEV_BITS_S8_MIN = 25; // narrowest band (diagonals) the planner gives to the stride-8 form
 
 struct LevBitsPlan {
     bool ok;                 // false: costs are not a unit-cost family, or the band is wider than the window
     uint32_t u;              // unit_k of the batch
     int NA;                  // packed dwords of `a` under the window (window = 4*NA bits, 4*NA - 3 in the static form)
     bool stat;               // static form: the window registers move a dword every 4th column (lev_bits_body.h)
+    bool s8;                 // stride-8 form: 33 diagonals in 8 registers, no shifts and no moves (lev_bits_body.h); NA = 8, stat = false
     uint32_t Tw, ch, lds_per_wave;
 };
 
-// force_static: 0 = planner's choice, 1 = sliding form, 2 = static form
+// force_static: 0 = planner's choice, 1 = sliding form, 2 = static form, 3 = stride-8 form (bands of up to 33 diagonals)
 static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc,
                                              uint64_t max_len, int force_NA = 0, int force_ch = 0, int force_static = 0) {
     LevBitsPlan p;
@@ -117,6 +119,11 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
     if (p.stat && na_st > (uint64_t)LEV_BITS_MAX_NA) p.stat = false;
     if (p.stat) na = na_st;
     if (na > (uint64_t)LEV_BITS_MAX_NA) { p.ok = false; na = LEV_BITS_MAX_NA; }
+    // bands of LEV_BITS_S8_MIN..33 diagonals: the stride-8 form (39 instructions per column whatever the width; the sliding form
+    // needs 7 dwords from 25 diagonals on: 44, the static one 43 / 48 at 8 / 9 dwords)
+    p.s8 = force_NA <= 0 && w <= 33u && (force_static == 3 || (force_static == 0 && w >= LEV_BITS_S8_MIN));
+    if (force_static == 3 && !p.s8) p.ok = false;
+    if (p.s8) { p.stat = false; na = 8; }
     p.NA = (int)na;
     (void)force_ch;
     p.ch = 64u;                                                    // one 64-byte line per string per refill

@@ -187,6 +187,19 @@ struct DevWave {
     // byte N of x in all four bytes -> v_perm_b32
     template <int N>
     static __device__ __forceinline__ U32 splat_byte_n(U32 x) { return __builtin_amdgcn_perm(x, x, 0x04040404u + 0x01010101u * (uint32_t)N); }
+    // (lo >> 8) | (byte N of hi << 24): the dword slides one byte down, byte N of `hi` enters on top -> one v_perm_b32
+    template <int N>
+    static __device__ __forceinline__ U32 slide_in_byte(U32 hi, U32 lo) { return __builtin_amdgcn_perm(hi, lo, 0x00030201u | ((4u + (uint32_t)N) << 24)); }
+    // (a & m) | c -> v_and_or_b32
+    // (hipcc would rather emit v_and per term and join three terms per v_or3: 11 instructions for 8 terms instead of 8)
+    static __device__ __forceinline__ U32 and_or(U32 a, uint32_t m, U32 c) {
+        U32 d;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "v"(c));
+        return d;
+    }
+    // byte N of x == byte N of y -> one v_cmp_eq_u32 with SDWA byte selects
+    template <int N>
+    static __device__ __forceinline__ Bool byte_eq(U32 x, U32 y) { return ((x >> (8 * N)) & 0xFFu) == ((y >> (8 * N)) & 0xFFu); }
     static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
     static __device__ __forceinline__ void lds_or32(uint8_t *lds, U32 off, U32 v, Bool pred) {   // ds_or_b32, no return
         if (pred) (void)__hip_atomic_fetch_or((uint32_t *)(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
