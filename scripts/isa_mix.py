@@ -34,7 +34,7 @@ HALF = 4.2
 
 # (config, translation unit, mangled-name regex of the dominant kernel, columns / steps one iteration of the block advances)
 KERNELS = [
-    ("cfg2", "lev_bits.hip", r"_ZN2ta18lev_bits_s8_kernelILb0ELb1E\w*", "8 columns of 64 pairs (33-diagonal band, stride-8 window, line form)"),
+    ("cfg2", "lev_bits.hip", r"_ZN2ta18lev_bits_s8_kernelILb0ELb1E\w*", "8 columns of 64 pairs (33-diagonal band, stride-8 window, line form)", "all_live"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
     ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
     ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernelILb0E\w*", "haystack bytes per lane (bit-parallel filter scan)"),
@@ -103,6 +103,14 @@ def hot_loop(body, pick="largest"):
         per = [sum(1 for x in ins if x.startswith("v_")) for _, ins, _ in g]
         return sum(v for v in per if v >= 12)
     hdr = max(groups, key=lambda h: valu(groups[h]))
+    if pick == "all_live":
+        # the kernel keeps its whole blocks (every pair live) and its capped / cut-short blocks in separate loops of about the same
+        # size: the BASELINE configuration runs the former -- the one with the fewest selects (the capped loop has one more
+        # v_cndmask per column, the liveness select)
+        top = valu(groups[hdr])
+        def selects(g):
+            return sum(1 for _, ins, _ in g for x in ins if x.startswith("v_cndmask"))
+        hdr = min((h for h in groups if valu(groups[h]) >= 0.8 * top), key=lambda h: selects(groups[h]))
     if pick == "smallest_hot":
         # the kernel holds several copies of its inner loop (chunk form, line form specialised by the answer's word): the BASELINE
         # configuration runs the specialised line-form copy -- the leanest of the hot loops

@@ -165,11 +165,11 @@ struct LevBits {
             U32 sum;
             W::addc(PM & st.VP[0], st.VP[0], carry, sum, carry);
             U32 D0 = ((sum ^ st.VP[0]) | PM) | st.VN[0];
-            if (TRANS) {   // as column(): the bottom diagonal's own match bit of the column before is st.PMp[1] bit 0
+            if (TRANS) {   // as column(): the bottom diagonal's own match bit of the column before is st.PMp[NW - 1] bit 0
                 const U32 pml = PM << 1, pmr = W::template alignbit<1>(st.PMp[NW - 1], st.PMp[0]);
                 D0 = D0 | (~st.D0p[0] & pml & pmr);
             }
-            const U32 d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));          // ONEBIT: match | carry
+            const U32 d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));          // ONEBIT: match | carry, in bit 0
             st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0, W::splat(0)) : D0, st.acc);
             const U32 HP = st.VN[0] | ~(D0 | st.VP[0]);
             const U32 HN = D0 & st.VP[0];
@@ -254,40 +254,43 @@ struct LevBits {
             constexpr bool UNI = decltype(uniform_tag)::value;
             if constexpr (S8) {
                 // blocks of 8 iterations (tp a multiple of 8, like T0 and the span limits except the very end): two dwords of each
-                // string, eight steps with their register names fixed
+                // string, eight steps with their register names fixed.  One loop per kind of block -- warm-up, whole, capped /
+                // cut short -- so that no loop body has paths to join (joins cost a copy per window register).
+                for (; tp < p_hi && tp < T0; tp += 8u) {   // warm-up: rows 1..nlo slide in (whole blocks: T0 is a multiple of 64)
+                    const U32 x0 = W::lds_read32u(lds, addr_a(tp)) ^ 0x0C0C0C0Cu, x1 = W::lds_read32u(lds, addr_a(tp + 4u)) ^ 0x0C0C0C0Cu;
+                    step8<false, 0, false>(st, x0, x0, x0, active); step8<false, 1, false>(st, x0, x0, x0, active);
+                    step8<false, 2, false>(st, x0, x0, x0, active); step8<false, 3, false>(st, x0, x0, x0, active);
+                    step8<false, 4, false>(st, x1, x1, x1, active); step8<false, 5, false>(st, x1, x1, x1, active);
+                    step8<false, 6, false>(st, x1, x1, x1, active); step8<false, 7, false>(st, x1, x1, x1, active);
+                }
                 const bool cap = UNI ? false : W::any(t_stop < p_hi);
-                for (; tp < p_hi; tp += 8u) {
+                if (!cap) {
+                    for (; tp + 8u <= p_hi; tp += 8u) {    // the hot loop: whole blocks, every pair live
+                        if (__builtin_expect(nacc > 24u, 0)) flush();
+                        const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
+                        const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
+                        const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
+                        step8<false, 0, true>(st, b0, r0, x0, active); step8<false, 1, true>(st, b0, r0, x0, active);
+                        step8<false, 2, true>(st, b0, r0, x0, active); step8<false, 3, true>(st, b0, r0, x0, active);
+                        step8<false, 4, true>(st, b1, r1, x1, active); step8<false, 5, true>(st, b1, r1, x1, active);
+                        step8<false, 6, true>(st, b1, r1, x1, active); step8<false, 7, true>(st, b1, r1, x1, active);
+                        nacc += 8u;
+                    }
+                    if (!UNI && tp >= p_hi) finished(t_stop == p_hi);
+                }
+                for (; tp < p_hi; tp += 8u) {              // capped blocks, and the last one when the columns end inside it
+                    if (nacc > 24u) flush();
                     const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
                     const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
-                    if (tp < T0) {                         // warm-up: rows 1..nlo slide in (whole blocks: T0 is a multiple of 64)
-                        step8<false, 0, false>(st, x0, r0, x0, active); step8<false, 1, false>(st, x0, r0, x0, active);
-                        step8<false, 2, false>(st, x0, r0, x0, active); step8<false, 3, false>(st, x0, r0, x0, active);
-                        step8<false, 4, false>(st, x1, r1, x1, active); step8<false, 5, false>(st, x1, r1, x1, active);
-                        step8<false, 6, false>(st, x1, r1, x1, active); step8<false, 7, false>(st, x1, r1, x1, active);
-                        continue;
-                    }
-                    if (__builtin_expect(nacc > 24u, 0)) flush();
                     const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
                     const uint32_t left = p_hi - tp;       // >= 1 columns of this block run
-                    if (!cap) {
-                        step8<false, 0, true>(st, b0, r0, x0, active);
-                        if (left > 1u) step8<false, 1, true>(st, b0, r0, x0, active);
-                        if (left > 2u) step8<false, 2, true>(st, b0, r0, x0, active);
-                        if (left > 3u) step8<false, 3, true>(st, b0, r0, x0, active);
-                        if (left > 4u) step8<false, 4, true>(st, b1, r1, x1, active);
-                        if (left > 5u) step8<false, 5, true>(st, b1, r1, x1, active);
-                        if (left > 6u) step8<false, 6, true>(st, b1, r1, x1, active);
-                        if (left > 7u) step8<false, 7, true>(st, b1, r1, x1, active);
-                    } else {                               // (a pair's last column: live now, not in the next one)
-                        Bool l = t_stop > tp, n;
+                    Bool l = t_stop > tp, n;               // (a pair's last column: live now, not in the next one)
 #define TA_STEP8(c, bw, rw, xw) if (left > (uint32_t)c) { n = t_stop > (tp + (uint32_t)c + 1u); step8<true, c, true>(st, bw, rw, xw, l); finished(l & !n); l = n; }
-                        TA_STEP8(0, b0, r0, x0) TA_STEP8(1, b0, r0, x0) TA_STEP8(2, b0, r0, x0) TA_STEP8(3, b0, r0, x0)
-                        TA_STEP8(4, b1, r1, x1) TA_STEP8(5, b1, r1, x1) TA_STEP8(6, b1, r1, x1) TA_STEP8(7, b1, r1, x1)
+                    TA_STEP8(0, b0, r0, x0) TA_STEP8(1, b0, r0, x0) TA_STEP8(2, b0, r0, x0) TA_STEP8(3, b0, r0, x0)
+                    TA_STEP8(4, b1, r1, x1) TA_STEP8(5, b1, r1, x1) TA_STEP8(6, b1, r1, x1) TA_STEP8(7, b1, r1, x1)
 #undef TA_STEP8
-                    }
                     nacc += left < 8u ? left : 8u;
                 }
-                if (!UNI && !cap) finished(t_stop == p_hi);
                 return tp;
             }
             if (STATIC) {

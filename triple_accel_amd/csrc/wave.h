@@ -197,7 +197,7 @@ struct DevWave {
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "v"(c));
         return d;
     }
-    // byte N of x == byte N of y -> one v_cmp_eq_u32 with SDWA byte selects
+    // byte N of x == byte N of y (hipcc: v_bitop3 (x ^ y) & mask, v_cmp_eq 0)
     template <int N>
     static __device__ __forceinline__ Bool byte_eq(U32 x, U32 y) { return ((x >> (8 * N)) & 0xFFu) == ((y >> (8 * N)) & 0xFFu); }
     static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
