@@ -36,7 +36,7 @@ HALF = 4.2
 KERNELS = [
     ("cfg2", "lev_bits.hip", r"_ZN2ta18lev_bits_s8_kernelILb0ELb1E\w*", "8 columns of 64 pairs (33-diagonal band, stride-8 window, line form)", "all_live"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta15lev_bits_kernelILi3ELb1ELb0E\w*", "columns of 64 pairs (11-diagonal band + transposition, sliding window)"),
-    ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "steps of 4096 rows (one pair per wavefront)"),
+    ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "two steps of the sweep: 2 x (64 lanes x 64 rows) cells of one pair (one pair per wavefront)", "first_dpp"),
     ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernelILb0E\w*", "haystack bytes per lane (bit-parallel filter scan)"),
 ]
 
@@ -90,6 +90,7 @@ def hot_loop(body, pick="largest"):
     last chunk of a batch takes them) are left out, so the histogram is the path a full chunk runs."""
     bl = blocks_of(body)
     groups = {}
+    depth_of = {}
     for lab, ins, depth, text in bl:
         m = re.search(r"Header=(BB\d+_\d+) Depth=(\d+)", text[:600])
         hdr = None
@@ -99,10 +100,22 @@ def hot_loop(body, pick="largest"):
             hdr = m.group(1)
         if hdr:
             groups.setdefault(hdr, []).append((lab, ins, text))
+            dm = re.search(r"Depth=(\d+)", text[:600])
+            if dm and "Inner Loop Header" in text[:600] or (m and lab.lstrip(".L") != hdr):
+                depth_of[hdr] = max(depth_of.get(hdr, 0), int((dm or m).group(1) if dm else m.group(2)))
     def valu(g):      # blocks with next to no VALU work (switch arms, loop latches) do not make a loop "hot"
         per = [sum(1 for x in ins if x.startswith("v_")) for _, ins, _ in g]
         return sum(v for v in per if v >= 12)
     hdr = max(groups, key=lambda h: valu(groups[h]))
+    if pick == "deepest":
+        # a loop nest whose outer loops carry more code than the innermost one: the innermost (deepest) loop with the most VALU work
+        dmax = max(depth_of.get(h, 0) for h in groups)
+        hdr = max((h for h in groups if depth_of.get(h, 0) == dmax), key=lambda h: sum(1 for _, ins, _ in groups[h] for x in ins if x.startswith("v_")))
+    if pick == "first_dpp":
+        # lev_widebits: six instantiations of the sweep loop (one per role of the stripe) next to the table-building loop, all at the
+        # same depth; a single-stripe pair (cfg3) runs the first sweep loop in program order -- the first loop with a DPP hand-off
+        dmax = max(depth_of.get(h, 0) for h in groups)
+        hdr = next(h for h in groups if depth_of.get(h, 0) == dmax and any(x.endswith("_dpp") for _, ins, _ in groups[h] for x in ins))
     if pick == "all_live":
         # the kernel keeps its whole blocks (every pair live) and its capped / cut-short blocks in separate loops of about the same
         # size: the BASELINE configuration runs the former -- the one with the fewest selects (the capped loop has one more
