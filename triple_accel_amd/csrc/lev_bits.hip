@@ -98,21 +98,22 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     // line the chunk form has nothing to refetch and its coarser events (one per 64 columns, not per 16) are cheaper:
     // cfg4 0.150 ms against 0.180 ms (profiles/r02/ab_band_kernel.md).  TA_BITS_NO_COOP=1 pins the chunk form.
     if (max_len <= 128u || env_int("TA_BITS_NO_COOP")) P.tune |= 1u;
+    const bool line_form = !P.a.off && !P.b.off && !(P.tune & 1u);
+    if (pl.s8 && line_form) P.lds_per_wave = 64u * (52u + 36u);       // the stride-8 line form's small rings (lev_bits_body.h)
     const uint32_t waves = (P.n + 63u) / 64u;
     // 4 waves per block while four rings fit a quarter of the CU's LDS; else one wave per block so that the CU packs
     // as many waves as the LDS holds.  TA_BITS_WPB pins the waves per block, TA_BITS_BLOCK_LDS the block's LDS request
     // (= the resident blocks per CU), for the occupancy sweeps of profiles/.
-    uint32_t wpb = pl.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
+    uint32_t wpb = P.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t grid = (waves + wpb - 1) / wpb;
     // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
     // (12 waves) per CU instead of four -- a quarter fewer pairs in flight lets the 4 MB L2 keep more lines until their second
     // half is read.  Fixed-length batches (line form: every line requested once) run the four blocks the LDS allows: 16 waves
     // per CU measured 8 % faster than 12 once the refetches were gone (profiles/r02/ab_band_kernel.md).
-    size_t lds = (size_t)pl.lds_per_wave * wpb;
-    const bool line_form = !P.a.off && !P.b.off && !(P.tune & 1u);
+    size_t lds = (size_t)P.lds_per_wave * wpb;
     if (!line_form && wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
-    if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)pl.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
+    if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)P.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;

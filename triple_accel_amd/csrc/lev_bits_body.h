@@ -58,8 +58,11 @@ struct LevBits {
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
     using Q = typename W::Q;
-    static constexpr uint32_t BITS_SLOT_A = 84;        // LDS bytes per pair for `a`: 64 + 16 look-ahead + 4 (odd number of dwords)
-    static constexpr uint32_t BITS_SLOT_B = 68;        // ... for `b`: 64 + 4
+    // LDS bytes per pair: `a` 64 + 16 look-ahead + 4, `b` 64 + 4 (odd numbers of dwords); the stride-8 line form reads a dword per
+    // 4 columns from at most two 16-byte pieces of `a` and one of `b`, so its rings are 3 and 2 pieces (+ 4 bytes of wrap copy)
+    static constexpr bool SMALL_RINGS = S8 && LINE;
+    static constexpr uint32_t BITS_SLOT_A = SMALL_RINGS ? 52 : 84;
+    static constexpr uint32_t BITS_SLOT_B = SMALL_RINGS ? 36 : 68;
     // the sliding form takes `a` out of LDS a byte per column: its bytes are stored XOR 0x0C already (the static form reads a
     // dword per 4 columns and XORs that)
     static constexpr bool PREX = !STATIC && !S8;
@@ -374,7 +377,7 @@ struct LevBits {
             const uint32_t diff_u = blen_u >= alen_u ? blen_u - alen_u : alen_u - blen_u;
             const uint32_t nlo_u = diff_u <= P.u ? ((P.u - diff_u) >> 1) + (blen_u >= alen_u ? 0u : diff_u) + (TRANS ? 1u : 0u) : 0u;
             const int32_t ca_s = (int32_t)T0 - (int32_t)nlo_u;          // iteration tp inserts a[tp - ca_s], column uses b[tp - T0]
-            constexpr int32_t RA = 5, RB = 4;
+            constexpr int32_t RA = SMALL_RINGS ? 3 : 5, RB = SMALL_RINGS ? 2 : 4;
             Q SA[8], SB[8];
             auto fetch_a = [&](int32_t m) {
 #pragma unroll
