@@ -55,40 +55,50 @@ __global__ __launch_bounds__(256) void k_blk64(unsigned *out) {
 }
 static const int k_blk64_n = 8;   // per REP8 element on average: ITER/2 trips x 128 = ITER x 64
 
-// ---- part 2: the column code on register-resident inputs
-template <int NA, bool TRANS, bool STATIC>
+// ---- part 2: the column code on register-resident inputs.  MODE 0 = sliding window, 1 = static window, 2 = stride-8 window (NA = 8)
+template <int NA, bool TRANS, int MODE>
 __global__ __launch_bounds__(256) void k_columns(unsigned *out, unsigned groups, unsigned seed) {
     extern __shared__ unsigned char lds_dummy[];        // only sizes the block's LDS footprint (= the kernel's occupancy)
-    using LB = ta::LevBits<ta::DevWave, NA, TRANS, STATIC>;
+    using LB = ta::LevBits<ta::DevWave, NA, TRANS, MODE == 1, false, MODE == 2>;
     typename LB::State st;
-    unsigned M[LB::NW];
     unsigned x = (threadIdx.x + 1u) * 2654435761u ^ seed, y = x * 40503u + 7u;
 #pragma unroll
-    for (int q = 0; q < LB::NW; q++) { st.VP[q] = x >> q; st.VN[q] = ~st.VP[q] & (y << q); st.PMp[q] = 0; st.D0p[q] = ~0u; M[q] = q == 0 ? 1u << (threadIdx.x & 31) : 0u; }
+    for (int q = 0; q < LB::NW; q++) { st.VP[q] = x >> q; st.VN[q] = ~st.VP[q] & (y << q); st.PMp[q] = 0; st.D0p[q] = ~0u; }
 #pragma unroll
     for (int k = 0; k < NA; k++) st.AW[k] = x + 0x01010101u * k;
+    st.acc = 0;
     unsigned cnt = 0;
-    for (unsigned g = 0; g < groups; g++) {
+    for (unsigned g = 0; g < groups; g++) {             // a group = 4 columns (stride-8 form: every other trip closes a block of 8)
         x = (x >> 1) ^ y; y += 0x9E3779B9u;               // stands in for the two ds_read_b32 of a group (full-rate ops)
-        if (STATIC) {
+        if constexpr (MODE == 2) {
+            const unsigned ax = x ^ 0x0C0C0C0Cu;
+            if (g & 1u) {
+                LB::template step8<false, 4, true>(st, y, x, ax, true); LB::template step8<false, 5, true>(st, y, x, ax, true);
+                LB::template step8<false, 6, true>(st, y, x, ax, true); LB::template step8<false, 7, true>(st, y, x, ax, true);
+            } else {
+                LB::template step8<false, 0, true>(st, y, x, ax, true); LB::template step8<false, 1, true>(st, y, x, ax, true);
+                LB::template step8<false, 2, true>(st, y, x, ax, true); LB::template step8<false, 3, true>(st, y, x, ax, true);
+            }
+        } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int k2 = 0; k2 < NA - 1; k2++) st.AW[k2] = st.AW[k2 + 1];
             st.AW[NA - 1] = x ^ 0x0C0C0C0Cu;
-            LB::template column<false, 0>(st, y, M, cnt, true);
-            LB::template column<false, 1>(st, y, M, cnt, true);
-            LB::template column<false, 2>(st, y, M, cnt, true);
-            LB::template column<false, 3>(st, y, M, cnt, true);
+            LB::template column<false, 0>(st, y, true);
+            LB::template column<false, 1>(st, y, true);
+            LB::template column<false, 2>(st, y, true);
+            LB::template column<false, 3>(st, y, true);
         } else {
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 LB::advance_a(st, (x >> (8 * s4)) & 0xFFu);
-                LB::template column<false>(st, (y >> (8 * s4)) & 0xFFu, M, cnt, true);
+                LB::template column<false>(st, (y >> (8 * s4)) & 0xFFu, true);
             }
         }
+        if ((g & 7u) == 7u) { cnt += __builtin_popcount(st.acc); }      // the zero-step register: 32 columns
     }
     unsigned acc = cnt;
 #pragma unroll
-    for (int q = 0; q < LB::NW; q++) acc += st.VP[q] ^ st.VN[q];
+    for (int q = 0; q < LB::NWF; q++) acc += st.VP[q] ^ st.VN[q];
     out[blockIdx.x * 256 + threadIdx.x] = acc;
     if (lds_dummy[0] == 77 && groups == 0xFFFFFFFFu) out[0] = lds_dummy[threadIdx.x];
 }
@@ -128,8 +138,9 @@ int main() {
     }
     // part 2: blocks of 4 waves; dynamic LDS picks the occupancy: 53000 B -> 3 blocks = 12 waves per CU (cfg2's launch), 38912 -> 16
     struct Col { const char *name; void (*k)(unsigned *, unsigned, unsigned); int vgpr_note; };
-    Col cols[] = {{"cfg2 column code: NA=9, static window, LEVENSHTEIN", k_columns<9, false, true>, 0},
-                  {"cfg4 column code: NA=3, sliding window, RDAMERAU", k_columns<3, true, false>, 0}};
+    Col cols[] = {{"cfg2 column code: stride-8 window, LEVENSHTEIN", k_columns<8, false, 2>, 0},
+                  {"33 diagonals, static window (NA=9), LEVENSHTEIN", k_columns<9, false, 1>, 0},
+                  {"cfg4 column code: NA=3, sliding window, RDAMERAU", k_columns<3, true, 0>, 0}};
     const unsigned groups = 2048;     // 8192 columns per wavefront
     for (auto &c : cols) {
         for (unsigned lds : {80000u, 53000u, 38912u}) {
@@ -148,7 +159,7 @@ int main() {
             // every SIMD runs blocks_per_cu waves side by side, each 4 * groups columns; time per column per SIMD:
             const double cols_per_simd = 3.0 * blocks_per_cu * 4.0 * groups;
             const double ns = ms * 1e6 / cols_per_simd;
-            printf("%-52s %2d waves/CU  %8.3f ms  %.1f ns per wave-column per SIMD = %.0f cycles at %.2f GHz\n", c.name,
+            printf("%-56s %2d waves/CU  %8.3f ms  %.1f ns per wave-column per SIMD = %.0f cycles at %.2f GHz\n", c.name,
                    blocks_per_cu * 4, ms, ns, ns * ghz, ghz);
         }
     }

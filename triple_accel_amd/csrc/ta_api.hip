@@ -207,7 +207,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits_launch(P, bp, trans, max_len, st, &grid, &lds));
-        li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
+        li.kernel = 3; li.diags_per_lane = bp.s8 ? 33u : 4u * (uint32_t)bp.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 64;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else if (ch.kernel == LEV_K_WIDEBITS && (n_work == 1 || (n_work <= 16 && !subset)) && !a->off && !b->off &&
                a->len <= 0xFFFFFFF0ull && b->len <= 0xFFFFFFF0ull &&
