@@ -41,6 +41,37 @@ def test_bits_every_window_width(monkeypatch):
                 assert np.array_equal(got, want), (na, mode, k, costs, np.flatnonzero(got != want)[:10])
 
 
+@pytest.mark.parametrize("costs", [LEV, RDAM])
+def test_bits_stride8_window_form(monkeypatch, costs):
+    """The stride-8 form (bands of 25..33 diagonals by the planner's choice, narrower ones when forced) on ragged CSR batches -- the
+    chunk form of the fetch, pairs ending inside a block of 8 columns while others run on -- and on fixed-length batches of 300-byte
+    strings -- the line form -- against the oracle and against the sliding form."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    trans = costs[3] is not None
+    a, b = ragged_pairs(23, 5000, 300, 28, trans)
+    fa, fb = Dg.pairs_mutated_fixed(0x58, 3000, 300, 30, trans)
+    ec = T.EditCosts(*costs)
+    kmax = 32 - (2 if trans else 0)
+    for k in (kmax, kmax - 1, 26, 24 - (2 if trans else 0)):              # 33, 32, 27 / 29, 25 diagonals: the planner's own choice
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert kernel_id() == 3 and T.last_launch_info()["diags_per_lane"] == 33
+        assert np.array_equal(got, want), ("csr", k, costs, np.flatnonzero(got != want)[:10])
+        got = B.levenshtein_k_batch(B.Strings.from_fixed(fa), B.Strings.from_fixed(fb), k, ec).cpu().numpy().view(np.uint32)
+        assert kernel_id() == 3 and T.last_launch_info()["diags_per_lane"] == 33
+        want = O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), k, costs)
+        assert np.array_equal(got, want), ("fixed", k, costs, np.flatnonzero(got != want)[:10])
+        assert (want != 0xFFFFFFFF).mean() > 0.1
+    for k in (0, 3, 11, kmax):
+        monkeypatch.setenv("TA_BITS_STATIC", "3")
+        s8 = gpu_k(a, b, k, costs)
+        assert T.last_launch_info()["diags_per_lane"] == 33
+        monkeypatch.setenv("TA_BITS_STATIC", "1")
+        sl = gpu_k(a, b, k, costs)
+        monkeypatch.delenv("TA_BITS_STATIC")
+        assert np.array_equal(s8, sl) and np.array_equal(s8, oracle_k(a, b, k, costs)), (k, costs)
+
+
 def test_bits_static_equals_sliding_on_long_ragged_strings(monkeypatch):
     g = Dg.rng(0x57A7)
     a, b = [], []
