@@ -29,6 +29,13 @@ s0a = B.Strings(sa.blob, None, stride=0, length=L, n=n)
 s0b = B.Strings(sb.blob, None, stride=0, length=L, n=n)
 print("real batch           %.4f ms" % dev_ms(sa, sb), T.last_launch_info())
 print("stride 0 (no HBM)    %.4f ms" % dev_ms(s0a, s0b))
+# EXP_STRIDES=16,128,...: pair i reads its strings at byte i * stride of the same blobs (overlapping strings: a smaller footprint --
+# 16 B: 16 MB per string set, L2-resident, 8 lines per load instruction; 128 B: 128 MB, one line per lane as in the real batch)
+for st in [int(x) for x in os.environ.get("EXP_STRIDES", "").split(",") if x]:
+    xa = B.Strings(sa.blob, None, stride=st, length=L, n=n)
+    xb = B.Strings(sb.blob, None, stride=st, length=L, n=n)
+    print("stride %-5d         %.4f ms" % (st, dev_ms(xa, xb)))
+print("real batch again     %.4f ms" % dev_ms(sa, sb))
 for env in sys.argv[1:]:
     kv = dict(x.split("=") for x in env.split(",")) if env else {}
     os.environ.update(kv)
