@@ -105,6 +105,7 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     // as many waves as the LDS holds.  TA_BITS_WPB pins the waves per block, TA_BITS_BLOCK_LDS the block's LDS request
     // (= the resident blocks per CU), for the occupancy sweeps of profiles/.
     uint32_t wpb = P.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
+    if (pl.s8 && line_form) wpb = 1u;          // finer grains at the launch's tail: 0.3138-0.3147 against 0.3159-0.3171 ms on cfg2
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t grid = (waves + wpb - 1) / wpb;
     // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
