@@ -383,7 +383,9 @@ struct LevBits {
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int32_t off = 128 * m + 16 * c;
-                    const Bool ok = (off >= 0 && (uint32_t)off < alen_u) ? valid : W::bfalse();
+                    // (every lane loads: a lane without a pair points at the batch's first pair -- load_str -- and its bytes go nowhere;
+                    // a per-lane predicate would have every register zeroed before every burst)
+                    const Bool ok = (off >= 0 && (uint32_t)off < alen_u) ? active : W::bfalse();
                     SA[c] = W::gload16(W::ptr_add(aptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
                 }
             };
@@ -391,7 +393,7 @@ struct LevBits {
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int32_t off = 128 * m + 16 * c;
-                    const Bool ok = (off >= 0 && (uint32_t)off < blen_u) ? valid : W::bfalse();
+                    const Bool ok = (off >= 0 && (uint32_t)off < blen_u) ? active : W::bfalse();
                     SB[c] = W::gload16(W::ptr_add(bptr, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
                 }
             };
