@@ -11,6 +11,8 @@
 using namespace ta;
 
 extern int g_emu_force_ch;
+static int g_emu_bits_fixed_chunk = 0;      // 1: fixed-length batches take the chunk form (as the launcher does up to one line per string)
+extern "C" void emu_bits_set_fixed_chunk(int on) { g_emu_bits_fixed_chunk = on; }
 
 // ---- bit-parallel band kernel (lev_bits_body.h)
 #include "lev_bits_body.h"
@@ -59,7 +61,7 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     // string -- a speed choice; the emulation covers the line form on short strings too)
     if (pl.s8) {
         uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
-        const bool line = !a_off && !b_off;
+        const bool line = !a_off && !b_off && !g_emu_bits_fixed_chunk;
         for (uint32_t w = 0; w < waves; w++) {
             if (has_t) { if (line) LevBits<EmuWave, 8, true, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, true, false, false, true>::run(P, w, lds); }
             else { if (line) LevBits<EmuWave, 8, false, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, false, true>::run(P, w, lds); }
@@ -68,7 +70,7 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
         return 0;
     }
     switch (pl.NA) {
-#define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, !a_off && !b_off, waves); break;
+#define CASE(d) case d: run_bits<d>(P, has_t != 0, pl.stat, !a_off && !b_off && !g_emu_bits_fixed_chunk, waves); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
         CASE(13) CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24) CASE(26) CASE(28) CASE(30) CASE(32)
 #undef CASE

@@ -105,6 +105,11 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
+def bits_fixed_chunk(on):
+    """Fixed-length batches through the CHUNK form of the fetch (what the launcher picks up to one 128-byte line per string)."""
+    lib().emu_bits_set_fixed_chunk(1 if on else 0)
+
+
 def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
     """The same body on a fixed-length (strided) batch -- (n, La) and (n, Lb) uint8 arrays -- which takes the COALESCED fetch
     form; subset: optional pair indices (results land at out[pair], other entries stay 0xDEADBEEF -> 'untouched')."""

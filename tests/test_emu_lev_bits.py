@@ -214,6 +214,25 @@ def test_emu_bits_fixed_length_coalesced(la, lb, k, trans):
     assert any(w is not None for w in want) or k == 0
 
 
+@pytest.mark.parametrize("la,lb,k,trans", [(128, 128, 8, True), (128, 128, 5, False), (100, 93, 12, False), (61, 70, 20, True), (17, 17, 3, False),
+                                           (1, 1, 1, False), (127, 120, 6, True), (64, 64, 0, False), (128, 128, 32, False), (96, 110, 30, True)])
+def test_emu_bits_fixed_length_chunk_form(la, lb, k, trans):
+    """Fixed-length batches of strings up to one line take the CHUNK form with wave-uniform load predicates (lanes without a pair
+    read the batch's first pair): n = 150 leaves 42 lanes of the last wavefront without a pair."""
+    a, b = _fixed_batch(la * 5 + lb + k, 150, la, lb, k, swaps=trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(150)]
+    E.bits_fixed_chunk(True)
+    try:
+        for static in (1, 2, 3):
+            if static == 3 and k + 1 + (2 if trans else 0) > 33:
+                continue
+            got, plan = E.lev_bits_fixed(a, b, k, trans, static=static)
+            assert got == want, (la, lb, k, trans, static, plan)
+    finally:
+        E.bits_fixed_chunk(False)
+
+
 def test_emu_bits_fixed_length_subset():
     """The levenshtein_exp rounds hand the kernel a subset list: helper lanes must follow the OWNER's pair index."""
     a, b = _fixed_batch(5, 200, 96, 96, 10)

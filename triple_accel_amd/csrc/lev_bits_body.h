@@ -443,7 +443,25 @@ struct LevBits {
         // waits in registers (8 x 16 bytes per lane, fetched a whole chunk ahead) and is committed when the current one is used up.
         // (`b` starts at iteration T0, a multiple of 64: its d is 0 and it needs no look-ahead bytes)
         Q S[8];
+        // fixed-length batches that take this form (strings of up to one line): the geometry is one number per wavefront, so whether a
+        // piece lies inside its string is a wave-uniform question and the loads need no per-lane predicate (which would have hipcc
+        // zero the eight registers before every fetch); a lane without a pair reads the batch's first pair (load_str)
+        const bool fixed = !P.a.off && !P.b.off;
+        const uint32_t fx_alen = (uint32_t)P.a.len, fx_blen = (uint32_t)P.b.len;
+        const uint32_t fx_diff = fx_blen >= fx_alen ? fx_blen - fx_alen : fx_alen - fx_blen;
+        const uint32_t fx_nlo = fx_diff <= P.u ? ((P.u - fx_diff) >> 1) + (fx_blen >= fx_alen ? 0u : fx_diff) + (TRANS ? 1u : 0u) : 0u;
+        const uint32_t fx_ca = T0 - fx_nlo, fx_ea = fx_ca + ((16u - (fx_ca & 15u)) & 15u), fx_eb = T0;
         auto fetch = [&](uint32_t kc) {
+            if (fixed) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t y0 = kc * 64u + 16u * (uint32_t)p;
+                    const bool ina = fx_ea <= y0 && y0 - fx_ea < fx_alen, inb = fx_eb <= y0 && y0 - fx_eb < fx_blen;
+                    S[p] = W::gload16(W::ptr_add(aptr, W::splat(ina ? y0 - fx_ea : 0u)), ina ? active : W::bfalse());
+                    S[4 + p] = W::gload16(W::ptr_add(bptr, W::splat(inb ? y0 - fx_eb : 0u)), inb ? active : W::bfalse());
+                }
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const uint32_t y0 = kc * 64u + 16u * (uint32_t)p;
