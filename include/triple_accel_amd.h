@@ -219,6 +219,18 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
                           const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
                           uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
 
+/* The Best-mode pass over one shard in a single call (what `levenshtein_search` with SearchType::Best needs from a shard,
+ * src/levenshtein.rs:1792-1835): ta_levenshtein_search_dev (unanchored) + ta_search_best_hits_dev fused.  The All-mode hits stay
+ * in hits_dev (*count_host of them); *out receives only the hits with the smallest k -- the only ones ta_search_fold_best can
+ * keep -- library-allocated (ta_free), sorted by end.  For unit-cost families and needles of up to 64 bytes the whole pass is
+ * one fill, two kernels and one stream synchronisation (the number of flagged blocks, the minimum and the selection never leave
+ * the device; the result arrives in host-mapped memory).  Synchronises the stream. */
+int ta_levenshtein_search_best_dev(const uint8_t *needle_host, size_t needle_len,
+                                   const uint8_t *haystack_dev, size_t haystack_len,
+                                   uint32_t k, const ta_edit_costs *costs, uint64_t base, uint64_t emit_from,
+                                   ta_match *hits_dev, size_t cap, uint64_t *count_host,
+                                   ta_match **out, size_t *n_out, void *stream);
+
 /* Best-mode shortcut for a shard whose All-mode hits sit in HBM (the hits_dev / count of ta_*_search_dev): only the hits
  * with the smallest k can survive ta_search_fold_best, so the minimum and the selection run on the device and only those
  * records come back -- library-allocated (ta_free), sorted by end, ready for ta_search_fold_best.  Synchronises. */

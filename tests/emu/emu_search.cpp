@@ -5,14 +5,32 @@
 
 #include <vector>
 
+#include "emu_wave.h"
 #include "lev_search_body.h"
+#include "lev_search_wave_body.h"
 
 using namespace ta;
 
 struct Hit { uint64_t start, end; uint32_t k, pad; };
 
-static bool g_packed = false;
-extern "C" void emu_search_set_packed(int on) { g_packed = on != 0; }
+static int g_packed = 0;          // 0: cost + length in two registers, 1: packed key, 2: packed key on a whole wavefront per tile
+extern "C" void emu_search_set_packed(int on) { g_packed = on; }
+
+// the wavefront-per-block form (lev_search_wave_body.h): tiles are the blocks, n <= 64, tile + halo <= 256 columns
+static int run_tiles_wave(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, const SearchCosts &C,
+                          bool trans, uint64_t tile, uint64_t halo, std::vector<Hit> &hits) {
+    if (n > 64 || tile + halo > SRCH_WAVE_MAX_COLS || C.anchored) return 3;
+    uint8_t nd[64 + 16] = {0};
+    for (uint32_t i = 0; i < n; i++) nd[i] = needle[i];
+    for (uint64_t eb = 0; eb < h; eb += tile) {
+        uint64_t ee = eb + tile < h ? eb + tile : h;
+        uint64_t cb = eb > halo ? eb - halo : 0;
+        auto emit = [&](uint64_t end, uint32_t len, uint32_t cost) { hits.push_back(Hit{end - len, end, cost, 0}); };
+        if (trans) lev_search_block_wave<EmuWave, true>(hay, nd, n, C, cb, eb, ee, emit);
+        else lev_search_block_wave<EmuWave, false>(hay, nd, n, C, cb, eb, ee, emit);
+    }
+    return 0;
+}
 
 template <int N>
 static void run_tiles(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, const SearchCosts &C,
@@ -21,7 +39,7 @@ static void run_tiles(const uint8_t *needle, uint32_t n, const uint8_t *hay, uin
         uint64_t ee = eb + tile < h ? eb + tile : h;
         uint64_t cb = eb > halo ? eb - halo : 0;
         auto emit = [&](uint64_t end, uint32_t len, uint32_t cost) { hits.push_back(Hit{end - len, end, cost, 0}); };
-        if (g_packed) {
+        if (g_packed == 1) {
             if (trans) lev_search_tile_packed<N, true>(hay, needle, n, C, cb, eb, ee, emit);
             else lev_search_tile_packed<N, false>(hay, needle, n, C, cb, eb, ee, emit);
         } else {
@@ -55,8 +73,11 @@ extern "C" int emu_lev_search(const uint8_t *needle, uint32_t n, const uint8_t *
     SearchCosts C{k, mc, gc, sg, tc, (uint32_t)(anchored ? 1 : 0)};
     std::vector<Hit> hits;
     if (n == 0) return 1;
-    if (n > 32) run_tiles_mem(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
-    else if (g_packed) {
+    if (g_packed == 2) {
+        int rc = run_tiles_wave(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
+        if (rc) return rc;
+    } else if (n > 32) run_tiles_mem(needle, n, hay, h, C, has_t != 0, tile, halo, hits);
+    else if (g_packed == 1) {
         switch (n) {
 #define TA_N(x) case x: run_tiles<x>(needle, n, hay, h, C, has_t != 0, tile, halo, hits); break;
             TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)

@@ -49,6 +49,7 @@ struct EmuWave {
     static U32 splat(uint32_t x) { return V32(x); }
     static Bool bfalse() { VB r; for (int i = 0; i < 64; i++) r.v[i] = false; return r; }
     static U32 sel(const Bool &c, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+    static Bool land(const Bool &a, const Bool &b) { return a & b; }
     static U32 umin(const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
     static U32 umin3(const U32 &a, const U32 &b, const U32 &c) { return umin(umin(a, b), c); }
     static U32 udiv(const U32 &a, uint32_t d) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] / d; return r; }

@@ -98,3 +98,33 @@ def test_anchored_large_k_packed_gate():
     assert not E.lib().emu_search_anchored_packed_ok(hmax + 1, 1, 1, 1, 0)
     hay = b"b" * hmax
     assert E.lev_search_tiled(needle, hay, 30000, costs, anchored=True, packed=True) == oracle_all(needle, hay, 30000, costs, anchored=True)
+
+
+@pytest.mark.parametrize("costs", COSTS)
+def test_wave_per_block_equals_monolithic(costs):
+    """lev_search_wave_body.h (one wavefront per block, lanes = needle rows, skewed columns, DPP hand-over) on the 64-lane
+    host emulation: blocks + halo == the monolithic scalar oracle, needles up to 64 bytes, every cost family."""
+    g = Dg.rng(77)
+    mc, gc, sg, tc = costs
+    for n in (1, 2, 3, 8, 13, 32, 33, 47, 64):
+        needle = Dg.rand_str(g, n)
+        for k in (0, 1, n // 4 + 1, (n + 1) // 2, max(0, n - 1)):
+            halo = n + max(0, k - sg) // gc + 2
+            hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 900, 60, max(1, k))
+            want = oracle_all(needle, hay, k, costs)
+            for tile in (64, 16, 37):
+                if tile + halo <= 256:
+                    assert E.lev_search_tiled(needle, hay, k, costs, tile=tile, packed=2) == want, (n, k, tile, costs)
+
+
+def test_wave_per_block_small_alphabet_ties():
+    g = Dg.rng(9)
+    for costs in COSTS:
+        for _ in range(40):
+            n = int(g.integers(1, 12))
+            needle = g.integers(97, 99, size=n, dtype=np.uint8).tobytes()
+            hay = g.integers(97, 99, size=int(g.integers(0, 120)), dtype=np.uint8).tobytes()
+            k = int(g.integers(0, n + 1))
+            want = oracle_all(needle, hay, k, costs)
+            for tile in (64, 16, 33):
+                assert E.lev_search_tiled(needle, hay, k, costs, tile=tile, packed=2) == want, (needle, hay, k, costs, tile)

@@ -311,3 +311,35 @@ def test_scalar_names_are_the_same_engine():
         T.levenshtein(5, b"abc")
     with pytest.raises(OverflowError):
         T.levenshtein_simd_k(b"a", b"b", 1 << 32)
+
+
+@pytest.mark.parametrize("costs", [(1, 1, 0, None), (1, 1, 0, 1)])
+def test_wavefront_per_block_kernel_lengths_and_edges(costs):
+    """The exact kernel behind the filter is one wavefront per flagged block (lev_search_wave_body.h, needles <= 64 bytes):
+    every needle length class, matches touching the first and the last byte of the haystack, a partial last block, k from 0
+    to n - 1, All and Best, against the oracle."""
+    g = Dg.rng(0x3A7E)
+    for n in (1, 2, 7, 31, 32, 33, 48, 63, 64):
+        needle = Dg.rand_str(g, n)
+        for k in sorted({0, n // 3, n // 2, n - 1}):
+            body = bytearray(Dg.planted_haystack(int(g.integers(1 << 30)), needle, 9000 + 13 * n, 700 + n, max(1, min(k, n // 2))))
+            hay = bytes(needle[1:] + body + needle[:-1] if n > 1 else needle + body + needle)
+            if k == n - 1 and n > 7:
+                hay = hay[:5000]                                      # nearly everything matches: keep the oracle quick
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (n, k, st, costs)
+
+
+def test_best_pass_with_more_best_hits_than_the_report_holds():
+    """The fused Best pass returns up to 680 best hits in its report; beyond that the selection falls back to
+    ta_search_best_hits_dev's path.  1,500 exact copies: the result is still the oracle's."""
+    from triple_accel_amd import batch as B, dist as TD
+    g = Dg.rng(0xB16)
+    needle = Dg.rand_str(g, 20)
+    hay = b"".join(needle + Dg.rand_str(g, 45) for _ in range(1500))
+    t = B.haystack_tensor(hay)
+    rows = B.levenshtein_search_best_dev(needle, t, 6)
+    assert len(rows) == 1500 and (rows[:, 2] == 0).all() and (np.diff(rows[:, 1]) > 0).all()
+    got = TD.fold_best([tuple(int(v) for v in r) for r in rows], 6, True)
+    assert got == O.levenshtein_search_naive_with_opts(needle, hay, 6, O.BEST, (1, 1, 0, None), False)

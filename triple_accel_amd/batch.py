@@ -135,12 +135,10 @@ def levenshtein_search_best_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, ba
     hits = _hit_buffer(hay.device, cap)
     count = _C.c_uint64()
     cc = _costs(costs)._c()
-    rc = _n.lib().ta_levenshtein_search_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), 0,
-                                            base, emit_from, hits.data_ptr(), cap, _C.byref(count), _stream())
-    _raise(rc)
     out = _C.POINTER(_n.MatchC)()
     n_out = _C.c_size_t()
-    rc = _n.lib().ta_search_best_hits_dev(hits.data_ptr(), int(count.value), _C.byref(out), _C.byref(n_out), _stream())
+    rc = _n.lib().ta_levenshtein_search_best_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), base, emit_from,
+                                                 hits.data_ptr(), cap, _C.byref(count), _C.byref(out), _C.byref(n_out), _stream())
     _raise(rc)
     rows = np.empty((n_out.value, 3), dtype=np.int64)
     for i in range(n_out.value):

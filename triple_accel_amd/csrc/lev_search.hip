@@ -1,10 +1,12 @@
 // lev_search.hip -- gfx950 kernels for levenshtein_search / hamming_search over a haystack shard in HBM.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "ham_search_body.h"
 #include "lev_filter_body.h"
 #include "lev_search_body.h"
+#include "lev_search_wave_body.h"
 #include "ta_internal.h"
 
 namespace ta {
@@ -94,11 +96,33 @@ hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hip
 // One lane scans P.tile end positions (a multiple of 64) after P.halo bytes of left context and appends the index of
 // every 64-column block that holds a cost <= k to `list` (lev_filter_body.h).  The 256-entry match table of the
 // needle lives in LDS; the haystack is read 16 bytes per lane per load.
-template <bool TRANS>
+// REPL: the match table is kept 64 times -- row c (256 bytes) holds peq[c] once per lane of a wavefront, lane l reads dword l of
+// the row -- so the 64 lookups of a wavefront fall on 64 different addresses of which no two in a 32-lane group share a bank
+// (ds_read_b32: bank = dword index mod 32), whatever the haystack bytes are; one flat 256-entry table indexed by a random byte
+// per lane costs ~4.3 extra LDS cycles per lookup (SQ_LDS_BANK_CONFLICT 72.6 M per GiB, profiles/r02).  The address is built
+// by ONE v_perm_b32 per byte -- [lane*4 | c << 8] -- where the flat table needs one SDWA shift: the VALU count is unchanged.
+template <bool TRANS, bool REPL>
 __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
-    __shared__ uint32_t peq[256];
-    peq[threadIdx.x] = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
+    __shared__ __attribute__((aligned(16))) uint32_t peq[REPL ? 256 * 64 : 256];
+    if (REPL) {
+        const uint32_t m = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *row = (u32x4 *)(peq + threadIdx.x * 64);
+#pragma unroll
+        for (int q = 0; q < 16; q++) row[q] = u32x4{m, m, m, m};
+    } else {
+        peq[threadIdx.x] = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
+    }
     __syncthreads();
+    const uint32_t lane_off = (threadIdx.x & 63u) * 4u;
+    // table entry of byte b (0..3) of dword v
+    auto lookup = [&](uint32_t v, int b) -> uint32_t {
+        if (REPL) {
+            const uint32_t a = __builtin_amdgcn_perm(v, lane_off, 0x0C0C0000u | ((4u + (uint32_t)b) << 8));   // lane*4 | byte b << 8
+            return *(const uint32_t *)((const uint8_t *)peq + a);
+        }
+        return peq[(v >> (8 * b)) & 0xffu];
+    };
     const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t emit_begin = tile * P.tile;
     if (emit_begin >= P.hay_len) return;
@@ -109,7 +133,7 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
     const uint8_t *hay = P.hay;
     FilterState st;
     lev_filter_reset(st, P.needle_len);
-    for (uint64_t i = col_begin; i < emit_begin; i++) lev_filter_step<TRANS>(st, peq[hay[i]]);   // left context
+    for (uint64_t i = col_begin; i < emit_begin; i++) lev_filter_step<TRANS>(st, lookup(hay[i], 0));   // left context
     auto flag = [&](uint64_t col) {
         const unsigned int idx = atomicAdd(list_count, 1u);
         if (idx < list_cap) list[idx] = (uint32_t)(col / FILTER_BLOCK);
@@ -139,8 +163,7 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
                 const u32x4u v = blk == 0 ? cur[q] : cur[4 + q];
 #pragma unroll
                 for (int b = 0; b < 16; b++) {
-                    const uint32_t c = (v[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    any |= lev_filter_step<TRANS>(st, peq[c]) <= k;
+                    any |= lev_filter_step<TRANS>(st, lookup(v[b >> 2], b & 3)) <= k;
                 }
             }
             if (any) flag(i);
@@ -149,7 +172,7 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
     }
     if (i < emit_end) {                                           // the shard's last, partial block
         bool any = false;
-        for (uint64_t j = i; j < emit_end; j++) any |= lev_filter_step<TRANS>(st, peq[hay[j]]) <= k;
+        for (uint64_t j = i; j < emit_end; j++) any |= lev_filter_step<TRANS>(st, lookup(hay[j], 0)) <= k;
         if (any) flag(i);
     }
 }
@@ -225,8 +248,13 @@ hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, 
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
     switch ((P.needle_len + 31u) / 32u) {
         case 1:
-            if (trans) hipLaunchKernelGGL(lev_filter_kernel<true>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-            else hipLaunchKernelGGL(lev_filter_kernel<false>, dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            if (env_str("TA_FILTER_FLAT")) {            // A/B: the flat 256-entry table (bank conflicts on random bytes)
+                if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, false>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+                else hipLaunchKernelGGL((lev_filter_kernel<false, false>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            } else {
+                if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+                else hipLaunchKernelGGL((lev_filter_kernel<false, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            }
             return hipGetLastError();
         case 2: return launch_filter_n<2>(P, trans, grid, list, list_cap, list_count, s);
         case 3: return launch_filter_n<3>(P, trans, grid, list, list_cap, list_count, s);
@@ -260,50 +288,111 @@ __global__ __launch_bounds__(64) void lev_search_mem_list_kernel(SearchParams P,
                         });
 }
 
-// the exact (cost, length) kernel on the flagged 64-column blocks only
-template <int N, bool TRANS>
-__global__ __launch_bounds__(64) void lev_search_list_kernel(SearchParams P, const uint32_t *list, uint32_t n_list) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_list) return;
-    const uint64_t emit_begin = (uint64_t)list[t] * FILTER_BLOCK;
-    uint64_t emit_end = emit_begin + FILTER_BLOCK;
-    if (emit_end > P.hay_len) emit_end = P.hay_len;
-    const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
-    SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, P.anchored};
-    ta_match *hits = P.hits;
-    unsigned long long *count = P.count;
-    const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
-    lev_search_tile_packed<N, TRANS>(P.hay, P.needle, P.needle_len, C, col_begin, emit_begin, emit_end,
-                                     [=](uint64_t end, uint32_t len, uint32_t cost) {
-                                         const uint64_t gend = base + end;
-                                         if (gend <= emit_from) return;
-                                         unsigned long long idx = atomicAdd(count, 1ull);
-                                         if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
-                                     });
+// ---- the exact (cost, length) kernel on the flagged 64-column blocks: ONE WAVEFRONT per block (lev_search_wave_body.h)
+//
+// Persistent grid (SRCH_WAVE_GRID workgroups of 4 wavefronts): the number of flagged blocks is read ON THE DEVICE -- the
+// host never waits between the filter and this kernel.  The last workgroup to finish writes the report (hit count, and for
+// a Best pass the hits with the smallest k) into host-mapped pinned memory: one stream synchronisation tells the host
+// everything, no copy.  When the filter flagged so many blocks that the lane-per-tile kernel over everything is cheaper,
+// nothing is searched and the report says so.
+constexpr uint32_t SRCH_WAVE_GRID = 512;
+constexpr uint32_t SRCH_WAVE_DENSE_MUL = 5;          // a block costs ~5x its columns in the lane-per-tile kernel's currency
+constexpr uint64_t SRCH_SEL_SCAN_MAX = 1u << 20;     // Best: hits one wavefront may scan for the smallest k
+
+template <bool TRANS, bool BEST>
+__global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, const uint32_t *list, uint32_t cap_list, SearchCtl *ctl,
+                                                              uint8_t *report) {
+    __shared__ uint32_t s_last;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;   // wave-uniform: scalar loop control
+    const uint32_t n_list = ctl->n_list;                                   // written by the filter kernel before this launch
+    const uint64_t per_block = (uint64_t)FILTER_BLOCK + P.halo + P.needle_len;
+    const bool dense = n_list > cap_list || (uint64_t)n_list * per_block * SRCH_WAVE_DENSE_MUL >= P.hay_len;
+    if (!dense) {
+        // the needle, one byte per lane, straight from the kernarg segment (P is the first argument)
+        const uint8_t *needle = (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SearchParams, needle);
+        const SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, 0u};
+        ta_match *hits = P.hits;
+        unsigned long long *count = &ctl->count;
+        const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
+        for (uint32_t t = wave; t < n_list; t += n_waves) {
+            const uint64_t emit_begin = (uint64_t)list[t] * FILTER_BLOCK;
+            uint64_t emit_end = emit_begin + FILTER_BLOCK;
+            if (emit_end > P.hay_len) emit_end = P.hay_len;
+            const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+            lev_search_block_wave<DevWave, TRANS>(P.hay, needle, P.needle_len, C, col_begin, emit_begin, emit_end,
+                                                  [=](uint64_t end, uint32_t len, uint32_t cost) {
+                                                      const uint64_t gend = base + end;
+                                                      if (gend <= emit_from || lane != 0) return;
+                                                      const unsigned long long idx = atomicAdd(count, 1ull);
+                                                      if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
+                                                      if (BEST) atomicMax(&ctl->best_inv, 0xFFFFFFFFu - cost);
+                                                  });
+        }
+    }
+    // last workgroup out writes the report
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ctl->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    __threadfence();
+    const unsigned long long count = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SearchReport *rep = (SearchReport *)report;
+    uint32_t sel_count = 0, sel_state = 0, min_k = 0xFFFFFFFFu;
+    if (BEST && !dense) {
+        min_k = 0xFFFFFFFFu - __hip_atomic_load(&ctl->best_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (count <= P.cap && count <= SRCH_SEL_SCAN_MAX) {
+            ta_match *sel = (ta_match *)(report + sizeof(SearchReport));
+            const unsigned long long *hw = (const unsigned long long *)P.hits;
+            for (uint64_t i0 = 0; i0 < count; i0 += 64) {
+                const uint64_t i = i0 + lane;
+                bool take = false;
+                unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                if (i < count) {                                           // other workgroups wrote these: read past the L1
+                    w0 = __hip_atomic_load(hw + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1 = __hip_atomic_load(hw + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w2 = __hip_atomic_load(hw + 3 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    take = (uint32_t)w2 == min_k;
+                }
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+                if (take) {
+                    const uint32_t pos = sel_count + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (pos < SEARCH_REPORT_SEL) sel[pos] = ta_match{w0, w1, (uint32_t)w2, 0u};
+                }
+                sel_count += (uint32_t)__builtin_popcountll(mask);
+            }
+            sel_state = sel_count <= SEARCH_REPORT_SEL ? 1u : 2u;
+        } else {
+            sel_state = 2u;
+        }
+    }
+    if (lane == 0) {
+        rep->count = count; rep->n_list = n_list; rep->dense = dense ? 1u : 0u;
+        rep->sel_count = sel_count; rep->sel_state = sel_state; rep->min_k = min_k;
+    }
 }
 
-template <int N>
-static hipError_t launch_list_n(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s) {
-    const uint32_t grid = (n_list + 63) / 64;
-    if (trans) hipLaunchKernelGGL((lev_search_list_kernel<N, true>), dim3(grid), dim3(64), 0, s, P, list, n_list);
-    else hipLaunchKernelGGL((lev_search_list_kernel<N, false>), dim3(grid), dim3(64), 0, s, P, list, n_list);
+hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
+                                  SearchCtl *ctl, uint8_t *report_dev, hipStream_t s) {
+    if (P.needle_len == 0 || P.needle_len > 64 || FILTER_BLOCK + P.halo > SRCH_WAVE_MAX_COLS) return hipErrorInvalidValue;
+    const dim3 grid(SRCH_WAVE_GRID), block(256);
+    if (trans) {
+        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<true, true>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+        else hipLaunchKernelGGL((lev_search_wave_kernel<true, false>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+    } else {
+        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<false, true>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+        else hipLaunchKernelGGL((lev_search_wave_kernel<false, false>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+    }
     return hipGetLastError();
 }
 
-hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s) {
+// needles beyond the wavefront kernel's 64 rows: the memory-backed column, one lane per flagged block
+hipError_t lev_search_list_launch(const SearchParams &P, bool /*trans*/, const uint32_t *list, uint32_t n_list, hipStream_t s) {
     if (n_list == 0) return hipSuccess;
-    if (P.needle_len > 32) {
-        hipLaunchKernelGGL(lev_search_mem_list_kernel, dim3((n_list + 63) / 64), dim3(64), 0, s, P, list, n_list);
-        return hipGetLastError();
-    }
-    switch (P.needle_len) {
-#define TA_N(x) case x: return launch_list_n<x>(P, trans, list, n_list, s);
-        TA_N(1) TA_N(2) TA_N(3) TA_N(4) TA_N(5) TA_N(6) TA_N(7) TA_N(8) TA_N(9) TA_N(10) TA_N(11) TA_N(12)
-        TA_N(13) TA_N(14) TA_N(15) TA_N(16) TA_N(17) TA_N(18) TA_N(19) TA_N(20) TA_N(21) TA_N(22) TA_N(23) TA_N(24)
-        TA_N(25) TA_N(26) TA_N(27) TA_N(28) TA_N(29) TA_N(30) TA_N(31) TA_N(32)
-#undef TA_N
-        default: return hipErrorInvalidValue;
-    }
+    if (P.needle_len <= 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lev_search_mem_list_kernel, dim3((n_list + 63) / 64), dim3(64), 0, s, P, list, n_list);
+    return hipGetLastError();
 }
 
 // hamming_search: one lane per aligned group of 4 consecutive haystack offsets.  The lane loads the aligned dwords

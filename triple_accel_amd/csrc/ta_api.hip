@@ -74,6 +74,23 @@ CallCtx &call_ctx() {
     return c;
 }
 
+int PinBox::ensure() {
+    if (host) return TA_OK;
+    void *h = nullptr, *d = nullptr;
+    TA_HIP(hipHostMalloc(&h, SEARCH_REPORT_BYTES, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) d = h;
+    host = (uint8_t *)h; dev = (uint8_t *)d;
+    return TA_OK;
+}
+void PinBox::release() {
+    if (host) (void)hipHostFree(host);
+    host = dev = nullptr;
+}
+PinBox &search_report_box() {
+    static thread_local PinBox b;
+    return b;
+}
+
 struct LastUse { hipStream_t st = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
 static LastUse &last_use() {
     static thread_local LastUse u;
@@ -360,6 +377,10 @@ void ta_thread_release(void) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < TA_SCRATCH_SLOTS; i++) tls_scratch(i).release();
     call_ctx().release();
+    search_report_box().release();
+    LastUse &u = last_use();                     // the event that orders this thread's calls across streams
+    if (u.ev) (void)hipEventDestroy(u.ev);
+    u = LastUse{};
 }
 
 /* ---------------------------------------------------------------- batch API */

@@ -99,7 +99,8 @@ hipError_t iota_launch(uint32_t *p, uint32_t n, hipStream_t st);
 struct SearchParams {
     const uint8_t *hay;       // device
     uint64_t hay_len;
-    uint8_t needle[32];       // by value (kernarg) for the register kernel (needles <= 32)
+    uint8_t needle[64];       // by value (kernarg): the lane-per-tile register kernels read it as scalars (needles <= 32), the
+                              // wavefront-per-block kernel one byte per lane straight from the kernarg segment (needles <= 64)
     const uint8_t *needle_dev;   // device copy (any length)
     uint32_t *col_scratch;    // memory-backed column (long needles)
     uint32_t needle_len;
@@ -116,6 +117,38 @@ hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hip
 hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, uint32_t list_cap, unsigned int *list_count,
                              hipStream_t s);
 hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint32_t *list, uint32_t n_list, hipStream_t s);
+
+// Device-side control block of one filtered search pass (zeroed by ONE memset) and the report its last wavefront writes
+// into host-mapped pinned memory: the host learns everything it needs from one stream synchronisation, with no copy and
+// no round trip between the filter and the exact kernel.
+struct SearchCtl {
+    unsigned long long count;     // hits emitted (may exceed the caller's cap)
+    uint32_t n_list;              // 64-column blocks the filter flagged
+    uint32_t best_inv;            // 0xFFFFFFFF - the smallest k emitted (atomicMax; 0 = none)
+    uint32_t done;                // workgroups that have finished (the last one writes the report)
+    uint32_t pad[11];
+};
+struct SearchReport {             // 64 bytes, followed by up to SEARCH_REPORT_SEL selected ta_match records (Best passes)
+    uint64_t count;
+    uint32_t n_list;
+    uint32_t dense;               // 1: too many flagged blocks -- nothing was searched, the lane-per-tile kernel must run over everything
+    uint32_t sel_count;           // Best: hits with the smallest k ...
+    uint32_t sel_state;           // ... 1: all of them follow this header, 2: too many to select here (use ta_search_best_hits_dev)
+    uint32_t min_k;
+    uint32_t pad[9];
+};
+constexpr uint32_t SEARCH_REPORT_SEL = 680;                                         // 64 + 680 * 24 = 16 KiB
+constexpr size_t SEARCH_REPORT_BYTES = 64 + (size_t)SEARCH_REPORT_SEL * sizeof(ta_match);
+// thread-local pinned, device-mapped landing zone of the report
+struct PinBox {
+    uint8_t *host = nullptr, *dev = nullptr;
+    int ensure();                 // TA_OK / TA_ERR_HIP
+    void release();
+};
+PinBox &search_report_box();
+// one wavefront per flagged block (lev_search_wave_body.h), persistent grid reading n_list on the device; needles <= 64 bytes
+hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
+                                  SearchCtl *ctl, uint8_t *report_dev, hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
 
 }  // namespace ta

@@ -55,25 +55,58 @@ static void fill_params(SearchParams &P, const uint8_t *needle, size_t n, const 
 
 using namespace ta;
 
-extern "C" {
+// The hits of a device-resident All-mode result that can survive the Best fold -- those with the smallest k -- sorted by end.
+static int best_hits_of(const ta_match *hits_dev, uint64_t count, std::vector<ta_match> &v, hipStream_t st) {
+    v.clear();
+    if (count == 0) return TA_OK;
+    const uint32_t cap = 1u << 16;                                // best hits kept on the first try (rarely more than a handful)
+    Scratch &sel = tls_scratch(12), &cnt = tls_scratch(2);
+    int rc;
+    if ((rc = sel.ensure((size_t)cap * sizeof(ta_match))) || (rc = cnt.ensure(64))) return rc;
+    uint32_t *ctr = (uint32_t *)cnt.dev;                          // [0] count, [1] min k
+    TA_HIP(hipMemsetAsync(ctr, 0, 4, st));
+    TA_HIP(hipMemsetAsync(ctr + 1, 0xFF, 4, st));
+    TA_HIP(hits_best_launch(hits_dev, count, ctr + 1, (ta_match *)sel.dev, cap, ctr, st));
+    uint32_t host[2] = {0, 0};
+    TA_HIP(hipMemcpyAsync(host, ctr, 8, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    if (host[0] <= cap) {
+        v.resize(host[0]);
+        if (host[0]) TA_HIP(hipMemcpyAsync(v.data(), sel.dev, (size_t)host[0] * sizeof(ta_match), hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+    } else {                                                      // a flood of equally good hits: take everything and filter here
+        std::vector<ta_match> all(count);
+        TA_HIP(hipMemcpyAsync(all.data(), hits_dev, (size_t)count * sizeof(ta_match), hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+        for (const ta_match &h : all)
+            if (h.k == host[1]) v.push_back(h);
+    }
+    return TA_OK;
+}
 
-int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
-                              const uint8_t *haystack_dev, size_t haystack_len,
-                              uint32_t k, const ta_edit_costs *costs, int anchored,
-                              uint64_t base, uint64_t emit_from,
-                              ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
-    if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+static void sort_by_end(std::vector<ta_match> &v) {
+    std::sort(v.begin(), v.end(), [](const ta_match &x, const ta_match &y) { return x.end != y.end ? x.end < y.end : x.start < y.start; });
+}
+
+// One search pass over a shard resident in HBM.  best == nullptr: All-mode hits into hits_dev, their number into *count_host.
+// best != nullptr: additionally the hits with the smallest k (the only ones the Best fold can keep), sorted by end.
+//
+// Unit-cost families with a short needle: a bit-parallel scan (lev_filter_body.h) flags the 64-column blocks that hold a cost
+// <= k and only those go through the exact kernel.  For needles of up to 64 bytes the whole pass is ONE fill, TWO kernels and
+// ONE stream synchronisation: the exact kernel (one wavefront per flagged block, lev_search_wave_body.h) reads the number of
+// flagged blocks on the device, its last workgroup selects the best hits and writes the report into host-mapped memory.
+static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const uint8_t *haystack_dev, size_t haystack_len,
+                           uint32_t k, const ta_edit_costs *costs, int anchored, uint64_t base, uint64_t emit_from,
+                           ta_match *hits_dev, size_t cap, uint64_t *count_host, std::vector<ta_match> *best, hipStream_t st) {
     if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
     if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;         // :1965
     if (needle_len == 0) { set_last_error_msg("empty needle is handled by the host entry point"); return TA_ERR_ARG; }
     if (needle_len > 0xFFFFu) { set_last_error_msg("needle longer than 65535 bytes"); return TA_ERR_ARG; }
     if (!device_ready()) return TA_ERR_HIP;
-    hipStream_t st = (hipStream_t)stream;
     StreamGuard guard(st);
     Scratch &cnt = tls_scratch(2);
-    int rc = cnt.ensure(16);
+    int rc = cnt.ensure(64);
     if (rc) return rc;
-    TA_HIP(hipMemsetAsync(cnt.dev, 0, 8, st));
     SearchParams P;
     size_t h = haystack_len;
     const uint32_t unit_k = lev_sat_sub(k, costs->start_gap_cost) / costs->gap_cost;
@@ -90,10 +123,13 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     if (anchored) P.halo = 0;
     if (needle_len > 32) {
         // memory-backed column: needle on the device, 6 arrays of (n+1) u32 per tile; keep the scratch <= ~256 MB
-        Scratch &nd = tls_scratch(7), &cs = tls_scratch(6);
+        Scratch &nd = tls_scratch(7);
         if ((rc = nd.ensure(needle_len + 16))) return rc;
         TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
         P.needle_dev = (const uint8_t *)nd.dev;
+    }
+    auto mem_column_scratch = [&]() -> int {           // the lane-per-tile kernel over everything, needle > 32 bytes
+        Scratch &cs = tls_scratch(6);
         const uint64_t per_tile = 6ull * (needle_len + 1) * 4ull;
         uint64_t max_tiles = (256ull << 20) / per_tile;
         if (max_tiles < 64) max_tiles = 64;
@@ -102,53 +138,122 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
             if (t > P.tile) P.tile = (uint32_t)(t > 0x7FFFFFFFull ? 0x7FFFFFFFull : t);
         }
         const uint64_t tiles = (h + P.tile - 1) / P.tile;
-        if ((rc = cs.ensure((size_t)(per_tile * (tiles ? tiles : 1))))) return rc;
+        int r = cs.ensure((size_t)(per_tile * (tiles ? tiles : 1)));
+        if (r) return r;
         P.col_scratch = (uint32_t *)cs.dev;
-    }
+        return TA_OK;
+    };
     // packed cost/length kernel whenever every cost and length provably fits 16 bits
     bool packed = needle_len <= 32 && k <= 30000u && (uint64_t)P.tile + P.halo <= 60000u && !env_str("TA_SEARCH_UNPACKED");
     if (anchored)           // every cost must stay below the packed form's "no gap yet" marker (lev_search_body.h)
         packed = needle_len <= 32 && k <= 30000u && h <= 60000u && !env_str("TA_SEARCH_UNPACKED") &&
                  srch_anchored_packed_ok(h, (uint32_t)needle_len, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost);
-    // Unit-cost families with a short needle: a bit-parallel scan (lev_filter_body.h) finds the 64-column blocks that hold
-    // a cost <= k, and only those go through the exact kernel.  With k >= needle_len every position matches: skip it.
     const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 &&
                       (!costs->has_transpose || costs->transpose_cost == 1);
-    bool filtered = false;
-    const bool exact_ok = needle_len <= 32 ? packed : true;           // the block-list form exists for the packed and the memory-backed kernel
-    if (unit && !anchored && exact_ok && needle_len <= 256 && k < needle_len && h >= 4096 && !env_str("TA_SEARCH_NOFILTER")) {
-        Scratch &ls = tls_scratch(5), &lc = tls_scratch(4);
+    const bool trans = costs->has_transpose != 0;
+    // With k >= needle_len every position matches: no filter.
+    const bool filter_ok = unit && !anchored && needle_len <= 256 && k < needle_len && h >= 4096 && !env_str("TA_SEARCH_NOFILTER");
+    bool searched = false;
+    unsigned long long c = 0;
+    if (filter_ok) {
+        Scratch &ls = tls_scratch(5);
         uint64_t cap_list = h / FILTER_BLOCK + 2;
         if (cap_list > (4u << 20)) cap_list = 4u << 20;
-        if ((rc = ls.ensure((size_t)cap_list * 4)) || (rc = lc.ensure(16))) return rc;
-        TA_HIP(hipMemsetAsync(lc.dev, 0, 4, st));
+        if ((rc = ls.ensure((size_t)cap_list * 4))) return rc;
+        SearchCtl *ctl = (SearchCtl *)cnt.dev;
+        TA_HIP(hipMemsetAsync(ctl, 0, sizeof(SearchCtl), st));           // the pass's one fill
+        P.count = &ctl->count;
         SearchParams F = P;
         uint64_t ft = (h + 131071) / 131072;                          // one set of resident lanes (256 CUs x 8 waves x 64)
         if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
         ft = (ft + 2 * FILTER_BLOCK - 1) / (2 * FILTER_BLOCK) * (2 * FILTER_BLOCK);      // whole 128-byte lines per lane
         if (const char *e = env_str("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
         F.tile = (uint32_t)(ft > 0x7FFFFFC0ull ? 0x7FFFFFC0ull : ft);
-        TA_HIP(lev_filter_launch(F, costs->has_transpose != 0, (uint32_t *)ls.dev, (uint32_t)cap_list, (unsigned int *)lc.dev, st));
-        unsigned int n_list = 0;
-        TA_HIP(hipMemcpyAsync(&n_list, lc.dev, 4, hipMemcpyDeviceToHost, st));
-        TA_HIP(hipStreamSynchronize(st));
-        // dense matches: the exact kernel over everything is cheaper than (64 + halo) columns per flagged block
-        if (n_list <= cap_list && (uint64_t)n_list * (FILTER_BLOCK + P.halo) < h / 2) {
-            if (needle_len > 32 && n_list) {                          // memory-backed column: one per flagged block
-                Scratch &cs = tls_scratch(6);
-                if ((rc = cs.ensure((size_t)(6ull * (needle_len + 1) * 4ull * n_list)))) return rc;
-                P.col_scratch = (uint32_t *)cs.dev;
+        TA_HIP(lev_filter_launch(F, trans, (uint32_t *)ls.dev, (uint32_t)cap_list, &ctl->n_list, st));
+        if (needle_len <= 64 && k <= 30000u) {
+            // one wavefront per flagged block; no host round trip: the report arrives with the stream synchronisation
+            PinBox &box = search_report_box();
+            if ((rc = box.ensure())) return rc;
+            TA_HIP(lev_search_wave_launch(P, trans, best != nullptr, (const uint32_t *)ls.dev, (uint32_t)cap_list, ctl, box.dev, st));
+            TA_HIP(hipStreamSynchronize(st));
+            const SearchReport *rep = (const SearchReport *)box.host;
+            if (!rep->dense) {
+                searched = true;
+                c = rep->count;
+                if (best && c <= cap && rep->sel_state == 1) {
+                    const ta_match *sel = (const ta_match *)(box.host + sizeof(SearchReport));
+                    best->assign(sel, sel + rep->sel_count);
+                    sort_by_end(*best);
+                    *count_host = c;
+                    return TA_OK;
+                }
             }
-            TA_HIP(lev_search_list_launch(P, costs->has_transpose != 0, (const uint32_t *)ls.dev, n_list, st));
-            filtered = true;
+        } else {
+            // needles beyond the wavefront kernel: the memory-backed column, one lane per flagged block (needs the count here)
+            unsigned int n_list = 0;
+            TA_HIP(hipMemcpyAsync(&n_list, &ctl->n_list, 4, hipMemcpyDeviceToHost, st));
+            TA_HIP(hipStreamSynchronize(st));
+            // dense matches: the exact kernel over everything is cheaper than (64 + halo) columns per flagged block
+            if (n_list <= cap_list && (uint64_t)n_list * (FILTER_BLOCK + P.halo) < h / 2) {
+                if (n_list) {                                            // one memory-backed column per flagged block
+                    Scratch &cs = tls_scratch(6);
+                    if ((rc = cs.ensure((size_t)(6ull * (needle_len + 1) * 4ull * n_list)))) return rc;
+                    P.col_scratch = (uint32_t *)cs.dev;
+                }
+                TA_HIP(lev_search_list_launch(P, trans, (const uint32_t *)ls.dev, n_list, st));
+                TA_HIP(hipMemcpyAsync(&c, &ctl->count, 8, hipMemcpyDeviceToHost, st));
+                TA_HIP(hipStreamSynchronize(st));
+                searched = true;
+            }
         }
     }
-    if (!filtered) TA_HIP(lev_search_launch(P, packed, costs->has_transpose != 0, st));
-    unsigned long long c = 0;
-    TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
-    TA_HIP(hipStreamSynchronize(st));
+    if (!searched) {                                                      // the lane-per-tile kernel over everything
+        if (needle_len > 32 && (rc = mem_column_scratch())) return rc;
+        P.count = (unsigned long long *)cnt.dev;
+        TA_HIP(hipMemsetAsync(cnt.dev, 0, 8, st));
+        TA_HIP(lev_search_launch(P, packed, trans, st));
+        TA_HIP(hipMemcpyAsync(&c, cnt.dev, 8, hipMemcpyDeviceToHost, st));
+        TA_HIP(hipStreamSynchronize(st));
+    }
     *count_host = c;
-    return c > cap ? TA_ERR_CAPACITY : TA_OK;
+    if (c > cap) return TA_ERR_CAPACITY;
+    if (best) {
+        if ((rc = best_hits_of(hits_dev, c, *best, st))) return rc;
+        sort_by_end(*best);
+    }
+    return TA_OK;
+}
+
+extern "C" {
+
+int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
+                              const uint8_t *haystack_dev, size_t haystack_len,
+                              uint32_t k, const ta_edit_costs *costs, int anchored,
+                              uint64_t base, uint64_t emit_from,
+                              ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+    if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+    return search_dev_core(needle_host, needle_len, haystack_dev, haystack_len, k, costs, anchored, base, emit_from, hits_dev, cap,
+                           count_host, nullptr, (hipStream_t)stream);
+}
+
+// The Best-mode pass over a shard: the All-mode hits stay in hits_dev, only the ones with the smallest k come back.
+int ta_levenshtein_search_best_dev(const uint8_t *needle_host, size_t needle_len,
+                                   const uint8_t *haystack_dev, size_t haystack_len,
+                                   uint32_t k, const ta_edit_costs *costs, uint64_t base, uint64_t emit_from,
+                                   ta_match *hits_dev, size_t cap, uint64_t *count_host, ta_match **out, size_t *n_out, void *stream) {
+    if (!out || !n_out || !count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    std::vector<ta_match> v;
+    int rc = search_dev_core(needle_host, needle_len, haystack_dev, haystack_len, k, costs, 0, base, emit_from, hits_dev, cap,
+                             count_host, &v, (hipStream_t)stream);
+    if (rc) return rc;
+    *n_out = v.size();
+    if (!v.empty()) {
+        *out = (ta_match *)malloc(v.size() * sizeof(ta_match));
+        if (!*out) return TA_ERR_ARG;
+        memcpy(*out, v.data(), v.size() * sizeof(ta_match));
+    }
+    return TA_OK;
 }
 
 }  // extern "C"
@@ -200,30 +305,10 @@ int ta_search_best_hits_dev(const ta_match *hits_dev, uint64_t count, ta_match *
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     StreamGuard guard(st);
-    const uint32_t cap = 1u << 16;                                // best hits kept on the first try (rarely more than a handful)
-    Scratch &sel = tls_scratch(12), &cnt = tls_scratch(2);
-    int rc;
-    if ((rc = sel.ensure((size_t)cap * sizeof(ta_match))) || (rc = cnt.ensure(16))) return rc;
-    uint32_t *ctr = (uint32_t *)cnt.dev;                          // [0] count, [1] min k
-    TA_HIP(hipMemsetAsync(ctr, 0, 4, st));
-    TA_HIP(hipMemsetAsync(ctr + 1, 0xFF, 4, st));
-    TA_HIP(hits_best_launch(hits_dev, count, ctr + 1, (ta_match *)sel.dev, cap, ctr, st));
-    uint32_t host[2] = {0, 0};
-    TA_HIP(hipMemcpyAsync(host, ctr, 8, hipMemcpyDeviceToHost, st));
-    TA_HIP(hipStreamSynchronize(st));
     std::vector<ta_match> v;
-    if (host[0] <= cap) {
-        v.resize(host[0]);
-        if (host[0]) TA_HIP(hipMemcpyAsync(v.data(), sel.dev, (size_t)host[0] * sizeof(ta_match), hipMemcpyDeviceToHost, st));
-        TA_HIP(hipStreamSynchronize(st));
-    } else {                                                      // a flood of equally good hits: take everything and filter here
-        std::vector<ta_match> all(count);
-        TA_HIP(hipMemcpyAsync(all.data(), hits_dev, (size_t)count * sizeof(ta_match), hipMemcpyDeviceToHost, st));
-        TA_HIP(hipStreamSynchronize(st));
-        for (const ta_match &h : all)
-            if (h.k == host[1]) v.push_back(h);
-    }
-    std::sort(v.begin(), v.end(), [](const ta_match &x, const ta_match &y) { return x.end != y.end ? x.end < y.end : x.start < y.start; });
+    int rc = best_hits_of(hits_dev, count, v, st);
+    if (rc) return rc;
+    sort_by_end(v);
     *n_out = v.size();
     if (!v.empty()) {
         *out = (ta_match *)malloc(v.size() * sizeof(ta_match));

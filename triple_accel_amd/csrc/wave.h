@@ -39,6 +39,7 @@ struct DevWave {
     static __device__ __forceinline__ U32 splat(uint32_t x) { return x; }
     static __device__ __forceinline__ Bool bfalse() { return false; }
     static __device__ __forceinline__ U32 sel(Bool c, U32 a, U32 b) { return c ? a : b; }
+    static __device__ __forceinline__ Bool land(Bool a, Bool b) { return a && b; }   // per-lane AND of two predicates (s_and_b64)
     static __device__ __forceinline__ U32 umin(U32 a, U32 b) { return a < b ? a : b; }
     static __device__ __forceinline__ U32 umin3(U32 a, U32 b, U32 c) { return umin(umin(a, b), c); }
     static __device__ __forceinline__ U32 udiv(U32 a, uint32_t d) { return a / d; }
