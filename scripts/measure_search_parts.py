@@ -38,3 +38,15 @@ print("search_best_dev (C call + on-device selection): %.3f ms, %d rows" % (ms_b
 ms_a, _ = t(lambda: TD.fold_best(B.levenshtein_search_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS), 16, True))
 ms_n, _ = t(lambda: TD.fold_best(B.levenshtein_search_best_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS), 16, True))
 print("whole pass: all hits to the host %.3f ms, best-k hits only %.3f ms" % (ms_a, ms_n))
+# the exact kernel's own clock (100 MHz timestamps in the report of the last pass)
+rep = (C.c_uint32 * 16)()
+N.lib().ta_debug_last_search_report.argtypes = [C.c_void_p]
+for name, f in (("best", lambda: B.levenshtein_search_best_dev(needle, hay, 16, T.LEVENSHTEIN_COSTS)), ("all", ccall)):
+    for _ in range(3):
+        f(); torch.cuda.synchronize()
+        N.lib().ta_debug_last_search_report(rep)
+        tt = [int(rep[8 + i]) for i in range(4)]
+        d = lambda a, b: ((b - a) & 0xFFFFFFFF) / 100.0
+        print("%s pass: count %d  n_list %d  dense %d  sel %d (state %d)  min_k %d  n_cand %d | wavefront 0: %.1f us in its blocks; report starts "
+              "%.1f us after wavefront 0 entered, takes %.1f us" % (name, rep[0] | (rep[1] << 32), rep[2], rep[3], rep[4], rep[5], rep[6], rep[7],
+                                                                   d(tt[0], tt[1]), d(tt[0], tt[2]), d(tt[2], tt[3])))

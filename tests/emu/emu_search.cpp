@@ -25,9 +25,14 @@ static int run_tiles_wave(const uint8_t *needle, uint32_t n, const uint8_t *hay,
     for (uint64_t eb = 0; eb < h; eb += tile) {
         uint64_t ee = eb + tile < h ? eb + tile : h;
         uint64_t cb = eb > halo ? eb - halo : 0;
-        auto emit = [&](uint64_t end, uint32_t len, uint32_t cost) { hits.push_back(Hit{end - len, end, cost, 0}); };
-        if (trans) lev_search_block_wave<EmuWave, true>(hay, nd, n, C, cb, eb, ee, emit);
-        else lev_search_block_wave<EmuWave, false>(hay, nd, n, C, cb, eb, ee, emit);
+        auto flush = [&](uint32_t nh, const V32 &keys, const V32 &cols) {
+            for (uint32_t q = 0; q < nh; q++) {
+                const uint64_t end = cb + cols.v[q] + 1;
+                hits.push_back(Hit{end - (0xFFFFu - (keys.v[q] & 0xFFFFu)), end, keys.v[q] >> 16, 0});
+            }
+        };
+        if (trans) lev_search_block_wave<EmuWave, true>(hay, nd, n, C, cb, eb, ee, flush);
+        else lev_search_block_wave<EmuWave, false>(hay, nd, n, C, cb, eb, ee, flush);
     }
     return 0;
 }
@@ -116,6 +121,7 @@ extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *
     if (n == 0 || n > 256 || tile == 0 || tile % FILTER_BLOCK) return 1;
     std::vector<uint64_t> blocks;
     uint32_t nwf = (n + 31) / 32;
+    const bool lower_bound = force_words == -1;       // lev_filter_tile_lb: the score settled per 32 columns (needles <= 32 bytes)
     if (force_words > (int)nwf) nwf = (uint32_t)force_words;
     if (nwf == 1) {
         uint32_t peq[256];
@@ -124,7 +130,10 @@ extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *
             const uint64_t ee = eb + tile < h ? eb + tile : h, cb = eb > halo ? eb - halo : 0;
             auto pq = [&](uint32_t c) { return peq[c]; };
             auto mk = [&](uint64_t b) { blocks.push_back(b); };
-            if (has_t) lev_filter_tile<true>(hay, pq, n, k, cb, eb, ee, mk);
+            if (lower_bound) {
+                if (has_t) lev_filter_tile_lb<true>(hay, pq, n, k, cb, eb, ee, mk);
+                else lev_filter_tile_lb<false>(hay, pq, n, k, cb, eb, ee, mk);
+            } else if (has_t) lev_filter_tile<true>(hay, pq, n, k, cb, eb, ee, mk);
             else lev_filter_tile<false>(hay, pq, n, k, cb, eb, ee, mk);
         }
     } else {

@@ -178,6 +178,7 @@ struct EmuWave {
     }
     static void mem_fence() {}
     static uint32_t readlane(const U32 &x, uint32_t l) { return x.v[l & 63]; }
+    static U32 writelane(const U32 &x, uint32_t v, uint32_t l) { V32 r = x; r.v[l & 63] = v; return r; }
     static U32 gload_u8(const Ptr &p, const Bool &pred) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = pred.v[i] ? *p.v[i] : 0u; return r; }
     static uint32_t wave_sum(const U32 &x) { uint32_t t = 0; for (int i = 0; i < 64; i++) t += x.v[i]; return t; }
     static void lds_wave_sync() {}

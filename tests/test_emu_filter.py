@@ -58,3 +58,28 @@ def test_filter_long_needles(trans):
     hay = Dg.planted_haystack(77, needle, 5000, 400, 6)
     for words in (2, 3):
         assert E.lev_filter_blocks(needle, hay, 7, trans, tile=256, words=words) == oracle_blocks(needle, hay, 7, costs)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_filter_lower_bound_form_is_a_superset(trans):
+    """The product's scan settles the score once per 32 columns (lev_filter_step_h / lev_filter_fold32) and flags a block when
+    a LOWER BOUND of its smallest cost is <= k: every oracle block must be flagged; on large-alphabet text the extra blocks
+    are rare (here: only around the planted near-copies), on a binary alphabet they may be many -- never fewer."""
+    g = Dg.rng(44)
+    costs = RDAM if trans else LEV
+    for n in (1, 2, 5, 16, 31, 32):
+        needle = Dg.rand_str(g, n)
+        hay = Dg.planted_haystack(300 + n, needle, 9000, 300 + 7 * n, max(1, n // 3))
+        for k in sorted({0, 1, n // 4, n // 2, max(0, n - 1)}):
+            want = oracle_blocks(needle, hay, k, costs)
+            for tile in (64, 256, 1024):
+                got = E.lev_filter_blocks(needle, hay, k, trans, tile=tile, words=-1)
+                assert set(want) <= set(got), (n, k, tile, trans)
+                if n >= 16 and k <= n // 2:          # extras only where the score dips: around the planted (mutated) copies
+                    planted = len(hay) // (300 + 7 * n) + 1
+                    assert len(got) <= len(want) + 2 * planted, (n, k, tile, len(got), len(want))
+    for n in (3, 8, 20, 32):
+        needle = bytes(g.integers(0, 2, size=n).astype(np.uint8))
+        hay = bytes(g.integers(0, 2, size=4000).astype(np.uint8))
+        for k in (0, 1, n // 3):
+            assert set(oracle_blocks(needle, hay, k, costs)) <= set(E.lev_filter_blocks(needle, hay, k, trans, tile=128, words=-1))

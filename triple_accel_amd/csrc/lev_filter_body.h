@@ -56,6 +56,40 @@ TA_HD inline __attribute__((always_inline)) uint32_t lev_filter_step(FilterState
     return s.score;
 }
 
+// The same step without the score: the last row's horizontal +1 / -1 bits are shifted into two 32-column registers (one
+// v_alignbit_b32 each) and the score is settled once per 32 columns by lev_filter_fold32.
+template <bool TRANS>
+TA_HD inline __attribute__((always_inline)) void lev_filter_step_h(FilterState &s, uint32_t Eq, uint32_t &PH, uint32_t &MH) {
+    uint32_t D0 = (((Eq & s.Pv) + s.Pv) ^ s.Pv) | Eq | s.Mv;
+    if (TRANS) {
+        D0 |= ((~s.D0p & Eq) << 1) & s.Eqp;
+        s.D0p = D0; s.Eqp = Eq;
+    }
+    const uint32_t Ph = s.Mv | ~(D0 | s.Pv);
+    const uint32_t Mh = D0 & s.Pv;
+#if defined(__HIP_DEVICE_COMPILE__)
+    PH = __builtin_amdgcn_alignbit(PH, Ph, 31);                      // (PH << 1) | (Ph >> 31)
+    MH = __builtin_amdgcn_alignbit(MH, Mh, 31);
+#else
+    PH = (PH << 1) | (Ph >> 31);
+    MH = (MH << 1) | (Mh >> 31);
+#endif
+    const uint32_t Phs = Ph << 1, Mhs = Mh << 1;
+    s.Pv = Mhs | ~(D0 | Phs);
+    s.Mv = Phs & D0;
+}
+
+// After exactly 32 lev_filter_step_h: could one of those 32 columns have cost <= k?  The cost moves by one per column, so it
+// never went below (score before) - (number of -1 steps): a LOWER BOUND -- the answer may be yes for a block without a hit
+// (the exact kernel then finds nothing there), never no for a block with one.  On text where matches are rare the -1 steps
+// are rare too and the bound is as good as the exact minimum; it saves 1.3 of the scan's 16 instructions per byte.
+TA_HD inline __attribute__((always_inline)) bool lev_filter_fold32(FilterState &s, uint32_t PH, uint32_t MH, uint32_t k) {
+    const uint32_t down = (uint32_t)__builtin_popcount(MH);
+    const bool any = s.score <= k + down;
+    s.score = s.score + (uint32_t)__builtin_popcount(PH) - down;
+    return any;
+}
+
 // Scan columns [col_begin, col_end) of `hay`; for every FILTER_BLOCK-aligned block of columns >= emit_begin that
 // holds a column of cost <= k, call mark(block_index) once.  emit_begin must be a multiple of FILTER_BLOCK.
 template <bool TRANS, class Peq, class Mark>
@@ -73,6 +107,33 @@ TA_HD inline void lev_filter_tile(const uint8_t *hay, Peq peq, uint32_t n, uint3
                 any = false;
             }
         }
+    }
+}
+
+// as lev_filter_tile with the score settled per 32 columns (lev_filter_step_h / lev_filter_fold32) on whole blocks: marks a
+// SUPERSET of lev_filter_tile's blocks.  emit_begin must be a multiple of FILTER_BLOCK.
+template <bool TRANS, class Peq, class Mark>
+TA_HD inline void lev_filter_tile_lb(const uint8_t *hay, Peq peq, uint32_t n, uint32_t k, uint64_t col_begin,
+                                     uint64_t emit_begin, uint64_t col_end, Mark mark) {
+    FilterState s;
+    lev_filter_reset(s, n);
+    uint64_t i = col_begin;
+    for (; i < emit_begin && i < col_end; i++) lev_filter_step<TRANS>(s, peq(hay[i]));     // left context: exact score
+    while (i + FILTER_BLOCK <= col_end) {
+        bool any = false;
+        for (int half = 0; half < 2; half++) {
+            uint32_t PH = 0, MH = 0;
+            for (int b = 0; b < 32; b++) lev_filter_step_h<TRANS>(s, peq(hay[i + 32 * half + b]), PH, MH);
+            any |= lev_filter_fold32(s, PH, MH, k);
+        }
+        if (any) mark(i / FILTER_BLOCK);
+        i += FILTER_BLOCK;
+    }
+    if (i < col_end) {                                               // the partial last block: exact
+        bool any = false;
+        const uint64_t blk = i / FILTER_BLOCK;
+        for (; i < col_end; i++) any |= lev_filter_step<TRANS>(s, peq(hay[i])) <= k;
+        if (any) mark(blk);
     }
 }
 

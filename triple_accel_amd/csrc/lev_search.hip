@@ -101,15 +101,15 @@ hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hip
 // (ds_read_b32: bank = dword index mod 32), whatever the haystack bytes are; one flat 256-entry table indexed by a random byte
 // per lane costs ~4.3 extra LDS cycles per lookup (SQ_LDS_BANK_CONFLICT 72.6 M per GiB, profiles/r02).  The address is built
 // by ONE v_perm_b32 per byte -- [lane*4 | c << 8] -- where the flat table needs one SDWA shift: the VALU count is unchanged.
-template <bool TRANS, bool REPL>
-__global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
+template <bool TRANS, bool REPL, bool EXACT = false>
+__global__ __launch_bounds__(REPL ? 512 : 256) void lev_filter_kernel(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
     __shared__ __attribute__((aligned(16))) uint32_t peq[REPL ? 256 * 64 : 256];
-    if (REPL) {
-        const uint32_t m = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
+    if (REPL) {                                    // 512 threads: two per row, half a row each (two workgroups = 16 wavefronts per CU)
+        const uint32_t m = lev_filter_peq(P.needle, P.needle_len, threadIdx.x >> 1);
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 *row = (u32x4 *)(peq + threadIdx.x * 64);
+        u32x4 *row = (u32x4 *)(peq + (threadIdx.x >> 1) * 64 + (threadIdx.x & 1u) * 32);
 #pragma unroll
-        for (int q = 0; q < 16; q++) row[q] = u32x4{m, m, m, m};
+        for (int q = 0; q < 8; q++) row[q] = u32x4{m, m, m, m};
     } else {
         peq[threadIdx.x] = lev_filter_peq(P.needle, P.needle_len, threadIdx.x);
     }
@@ -158,12 +158,24 @@ __global__ __launch_bounds__(256) void lev_filter_kernel(SearchParams P, uint32_
 #pragma unroll 1
         for (int blk = 0; blk < 2 && i < full_end; blk++) {
             bool any = false;
+            if (EXACT) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32x4u v = blk == 0 ? cur[q] : cur[4 + q];
+                for (int q = 0; q < 4; q++) {
+                    const u32x4u v = blk == 0 ? cur[q] : cur[4 + q];
 #pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    any |= lev_filter_step<TRANS>(st, lookup(v[b >> 2], b & 3)) <= k;
+                    for (int b = 0; b < 16; b++) any |= lev_filter_step<TRANS>(st, lookup(v[b >> 2], b & 3)) <= k;
+                }
+            } else {            // the score settled per 32 columns: a lower bound of the block's smallest cost (lev_filter_fold32)
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    uint32_t PH = 0, MH = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const u32x4u v = blk == 0 ? cur[2 * half + q] : cur[4 + 2 * half + q];
+#pragma unroll
+                        for (int b = 0; b < 16; b++) lev_filter_step_h<TRANS>(st, lookup(v[b >> 2], b & 3), PH, MH);
+                    }
+                    any |= lev_filter_fold32(st, PH, MH, k);
                 }
             }
             if (any) flag(i);
@@ -248,13 +260,20 @@ hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, 
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
     switch ((P.needle_len + 31u) / 32u) {
         case 1:
-            if (env_str("TA_FILTER_FLAT")) {            // A/B: the flat 256-entry table (bank conflicts on random bytes)
-                if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, false>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-                else hipLaunchKernelGGL((lev_filter_kernel<false, false>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-            } else {
-                if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
-                else hipLaunchKernelGGL((lev_filter_kernel<false, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            if (!env_str("TA_FILTER_FLAT")) {
+                const uint32_t g2 = (uint32_t)((tiles + 511) / 512);
+                if (env_str("TA_FILTER_EXACT")) {   // A/B: the score per column (flags exactly the blocks that hold a hit)
+                    if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, true, true>), dim3(g2), dim3(512), 0, s, P, list, list_cap, list_count);
+                    else hipLaunchKernelGGL((lev_filter_kernel<false, true, true>), dim3(g2), dim3(512), 0, s, P, list, list_cap, list_count);
+                    return hipGetLastError();
+                }
+                if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, true>), dim3(g2), dim3(512), 0, s, P, list, list_cap, list_count);
+                else hipLaunchKernelGGL((lev_filter_kernel<false, true>), dim3(g2), dim3(512), 0, s, P, list, list_cap, list_count);
+                return hipGetLastError();
             }
+            // A/B (TA_FILTER_FLAT=1): the flat 256-entry table (bank conflicts on random bytes), 256 threads per workgroup
+            if (trans) hipLaunchKernelGGL((lev_filter_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
+            else hipLaunchKernelGGL((lev_filter_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, P, list, list_cap, list_count);
             return hipGetLastError();
         case 2: return launch_filter_n<2>(P, trans, grid, list, list_cap, list_count, s);
         case 3: return launch_filter_n<3>(P, trans, grid, list, list_cap, list_count, s);
@@ -295,16 +314,33 @@ __global__ __launch_bounds__(64) void lev_search_mem_list_kernel(SearchParams P,
 // a Best pass the hits with the smallest k) into host-mapped pinned memory: one stream synchronisation tells the host
 // everything, no copy.  When the filter flagged so many blocks that the lane-per-tile kernel over everything is cheaper,
 // nothing is searched and the report says so.
+//
+// No device-wide fence anywhere: an agent-scope release on gfx950 is an L2 write-back (buffer_wbl2), and one per wavefront
+// made this kernel 300 us long.  What crosses workgroups goes through agent-scope atomics instead: the hit cursor, the
+// Best passes' hit records and block slots (stored with agent-scope atomic stores = write-through), the done counter.
+// Best passes (only the hits with the smallest k can survive the Best fold): no running minimum, no second cursor -- a block
+// leaves ONE 16-byte slot {its best cost, its hit count, where its hits start} (agent-scope atomic stores = write-through, like
+// its hit records), the last workgroup takes the minimum over the n_list slots and picks the hits of that cost out of the few
+// blocks that reach it.  (A running atomicMax plus a candidate cursor cost every block two more serial round trips: 45 us
+// against 31 us for the All-mode kernel, profiles/r03/ab_search.md.)
 constexpr uint32_t SRCH_WAVE_GRID = 512;
 constexpr uint32_t SRCH_WAVE_DENSE_MUL = 5;          // a block costs ~5x its columns in the lane-per-tile kernel's currency
-constexpr uint64_t SRCH_SEL_SCAN_MAX = 1u << 20;     // Best: hits one wavefront may scan for the smallest k
+
+static __device__ __forceinline__ void store_match_agent(ta_match *dst, uint64_t start, uint64_t end, uint32_t k) {
+    unsigned long long *w = (unsigned long long *)dst;
+    __hip_atomic_store(w, (unsigned long long)start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, (unsigned long long)end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, (unsigned long long)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool TRANS, bool BEST>
 __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, const uint32_t *list, uint32_t cap_list, SearchCtl *ctl,
-                                                              uint8_t *report) {
-    __shared__ uint32_t s_last;
+                                                              SearchSlot *slots, uint8_t *report, uint32_t done_groups) {
+    __shared__ uint32_t s_last, s_sel;
+    (void)store_match_agent;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;   // wave-uniform: scalar loop control
+    const uint32_t t_enter = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const uint32_t n_list = ctl->n_list;                                   // written by the filter kernel before this launch
     const uint64_t per_block = (uint64_t)FILTER_BLOCK + P.halo + P.needle_len;
     const bool dense = n_list > cap_list || (uint64_t)n_list * per_block * SRCH_WAVE_DENSE_MUL >= P.hay_len;
@@ -313,76 +349,133 @@ __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, co
         const uint8_t *needle = (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SearchParams, needle);
         const SearchCosts C{P.k, P.mc, P.gc, P.sg, P.tc, 0u};
         ta_match *hits = P.hits;
-        unsigned long long *count = &ctl->count;
         const uint64_t base = P.base, emit_from = P.emit_from, cap = P.cap;
         for (uint32_t t = wave; t < n_list; t += n_waves) {
             const uint64_t emit_begin = (uint64_t)list[t] * FILTER_BLOCK;
             uint64_t emit_end = emit_begin + FILTER_BLOCK;
             if (emit_end > P.hay_len) emit_end = P.hay_len;
             const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
+            if (BEST && t < SEARCH_SLOT_CAP && lane == 0)                  // "no hits" until the block says otherwise (no fill needed)
+                __hip_atomic_store((unsigned long long *)(slots + t), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lev_search_block_wave<DevWave, TRANS>(P.hay, needle, P.needle_len, C, col_begin, emit_begin, emit_end,
-                                                  [=](uint64_t end, uint32_t len, uint32_t cost) {
-                                                      const uint64_t gend = base + end;
-                                                      if (gend <= emit_from || lane != 0) return;
-                                                      const unsigned long long idx = atomicAdd(count, 1ull);
-                                                      if (idx < cap) hits[idx] = ta_match{gend - len, gend, cost, 0u};
-                                                      if (BEST) atomicMax(&ctl->best_inv, 0xFFFFFFFFu - cost);
-                                                  });
+                [=](uint32_t nh, uint32_t key, uint32_t col) {            // lane h < nh holds hit h
+                    const uint64_t gend = base + col_begin + col + 1;
+                    const uint32_t cost = key >> 16, len = 0xFFFFu - (key & 0xFFFFu);
+                    const bool mine = lane < nh && gend > emit_from;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+                    if (m == 0) return;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(m), rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+                    unsigned long long idx0 = 0;
+                    if (lane == leader) idx0 = atomicAdd(&ctl->count, (unsigned long long)cnt);
+                    idx0 = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(idx0 >> 32), leader) << 32) |
+                           (unsigned long long)__builtin_amdgcn_readlane((uint32_t)idx0, leader);
+                    if (mine && idx0 + rank < cap) {
+                        if (BEST) store_match_agent(hits + idx0 + rank, gend - len, gend, cost);     // the last workgroup may read it
+                        else hits[idx0 + rank] = ta_match{gend - len, gend, cost, 0u};
+                    }
+                    if (BEST && t < SEARCH_SLOT_CAP) {
+                        const uint32_t inv = DevWave::wave_max(mine ? 0xFFFFFFFFu - cost : 0u);      // 0xFFFFFFFF - the block's best cost
+                        if (lane == leader) {
+                            unsigned long long *sw = (unsigned long long *)(slots + t);
+                            __hip_atomic_store(sw, ((unsigned long long)cnt << 32) | (0xFFFFFFFFu - inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(sw + 1, idx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                });
         }
     }
-    // last workgroup out writes the report
-    __threadfence();
+    if (wave == 0 && lane == 0) {
+        __hip_atomic_store(&ctl->pad[0], t_enter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->pad[1], (uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // last workgroup out writes the report.  Every store that another workgroup reads later was an agent-scope atomic store:
+    // waiting for this wavefront's own memory operations (s_waitcnt 0) is all the ordering the done counter needs.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&ctl->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) {       // two levels: the last workgroup of a group bumps the groups' counter
+        const uint32_t g = blockIdx.x % done_groups, members = gridDim.x / done_groups + (g < gridDim.x % done_groups ? 1u : 0u);
+        uint32_t last = 0;
+        if (__hip_atomic_fetch_add(&ctl->done[g * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)
+            last = __hip_atomic_fetch_add(&ctl->done2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == done_groups - 1u ? 1u : 0u;
+        s_last = last;
+    }
+    s_sel = 0;
     __syncthreads();
-    if (!s_last || threadIdx.x >= 64) return;
-    __threadfence();
+    if (!s_last) return;
+    const uint32_t t_report = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const unsigned long long count = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SearchReport *rep = (SearchReport *)report;
-    uint32_t sel_count = 0, sel_state = 0, min_k = 0xFFFFFFFFu;
+    uint32_t sel_state = 0, min_k = 0xFFFFFFFFu, n_cand_seen = 0;
     if (BEST && !dense) {
-        min_k = 0xFFFFFFFFu - __hip_atomic_load(&ctl->best_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (count <= P.cap && count <= SRCH_SEL_SCAN_MAX) {
+        if (count <= P.cap && n_list <= SEARCH_SLOT_CAP) {
+            __shared__ uint32_t s_min;
+            if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
+            __syncthreads();
+            const unsigned long long *sw = (const unsigned long long *)slots;
+            uint32_t mine_min = 0xFFFFFFFFu;
+            for (uint32_t i0 = 0; i0 < n_list; i0 += 1024u) {          // four loads in flight per thread: other workgroups wrote the
+                unsigned long long w[4];                                 // slots, they are read past the L1 / this XCD's L2
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = i0 + 256u * (uint32_t)j + threadIdx.x;
+                    w[j] = i < n_list ? __hip_atomic_load(sw + 2 * (uint64_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((uint32_t)(w[j] >> 32) != 0u && (uint32_t)w[j] < mine_min) mine_min = (uint32_t)w[j];
+            }
+            if (mine_min != 0xFFFFFFFFu) atomicMin(&s_min, mine_min);
+            __syncthreads();
+            min_k = s_min;
             ta_match *sel = (ta_match *)(report + sizeof(SearchReport));
             const unsigned long long *hw = (const unsigned long long *)P.hits;
-            for (uint64_t i0 = 0; i0 < count; i0 += 64) {
-                const uint64_t i = i0 + lane;
-                bool take = false;
-                unsigned long long w0 = 0, w1 = 0, w2 = 0;
-                if (i < count) {                                           // other workgroups wrote these: read past the L1
-                    w0 = __hip_atomic_load(hw + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w1 = __hip_atomic_load(hw + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w2 = __hip_atomic_load(hw + 3 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    take = (uint32_t)w2 == min_k;
+            if (min_k != 0xFFFFFFFFu) {
+                for (uint32_t i = threadIdx.x; i < n_list; i += 256u) {
+                    const unsigned long long w = __hip_atomic_load(sw + 2 * (uint64_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t cnt = (uint32_t)(w >> 32);
+                    if (cnt == 0u || (uint32_t)w != min_k) continue;
+                    const unsigned long long idx0 = __hip_atomic_load(sw + 2 * (uint64_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t q = 0; q < cnt; q++) {
+                        const unsigned long long w2 = __hip_atomic_load(hw + 3 * (idx0 + q) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)w2 != min_k) continue;
+                        const unsigned long long w0 = __hip_atomic_load(hw + 3 * (idx0 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long w1 = __hip_atomic_load(hw + 3 * (idx0 + q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t pos = atomicAdd(&s_sel, 1u);
+                        if (pos < SEARCH_REPORT_SEL) sel[pos] = ta_match{w0, w1, (uint32_t)w2, 0u};
+                    }
                 }
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
-                if (take) {
-                    const uint32_t pos = sel_count + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                    if (pos < SEARCH_REPORT_SEL) sel[pos] = ta_match{w0, w1, (uint32_t)w2, 0u};
-                }
-                sel_count += (uint32_t)__builtin_popcountll(mask);
             }
-            sel_state = sel_count <= SEARCH_REPORT_SEL ? 1u : 2u;
+            __syncthreads();
+            sel_state = s_sel <= SEARCH_REPORT_SEL ? 1u : 2u;
+            n_cand_seen = n_list;
         } else {
             sel_state = 2u;
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         rep->count = count; rep->n_list = n_list; rep->dense = dense ? 1u : 0u;
-        rep->sel_count = sel_count; rep->sel_state = sel_state; rep->min_k = min_k;
+        rep->sel_count = s_sel; rep->sel_state = sel_state; rep->min_k = min_k; rep->n_slots = n_cand_seen;
+        rep->t[0] = __hip_atomic_load(&ctl->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rep->t[1] = __hip_atomic_load(&ctl->pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rep->t[2] = t_report; rep->t[3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     }
 }
 
 hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
-                                  SearchCtl *ctl, uint8_t *report_dev, hipStream_t s) {
+                                  SearchCtl *ctl, SearchSlot *slots, uint8_t *report_dev, hipStream_t s) {
     if (P.needle_len == 0 || P.needle_len > 64 || FILTER_BLOCK + P.halo > SRCH_WAVE_MAX_COLS) return hipErrorInvalidValue;
-    const dim3 grid(SRCH_WAVE_GRID), block(256);
+    uint32_t g = SRCH_WAVE_GRID, done_groups = SEARCH_DONE_GROUPS;
+    if (const char *e = env_str("TA_SRCH_GRID")) { const int v = atoi(e); if (v >= 1 && v <= 4096) g = (uint32_t)v; }
+    if (const char *e = env_str("TA_SRCH_DONE_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= (int)SEARCH_DONE_GROUPS) done_groups = (uint32_t)v; }
+    if (done_groups > g) done_groups = g;
+    const dim3 grid(g), block(256);
     if (trans) {
-        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<true, true>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
-        else hipLaunchKernelGGL((lev_search_wave_kernel<true, false>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<true, true>), grid, block, 0, s, P, list, cap_list, ctl, slots, report_dev, done_groups);
+        else hipLaunchKernelGGL((lev_search_wave_kernel<true, false>), grid, block, 0, s, P, list, cap_list, ctl, slots, report_dev, done_groups);
     } else {
-        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<false, true>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
-        else hipLaunchKernelGGL((lev_search_wave_kernel<false, false>), grid, block, 0, s, P, list, cap_list, ctl, report_dev);
+        if (best) hipLaunchKernelGGL((lev_search_wave_kernel<false, true>), grid, block, 0, s, P, list, cap_list, ctl, slots, report_dev, done_groups);
+        else hipLaunchKernelGGL((lev_search_wave_kernel<false, false>), grid, block, 0, s, P, list, cap_list, ctl, slots, report_dev, done_groups);
     }
     return hipGetLastError();
 }

@@ -29,11 +29,15 @@ namespace ta {
 
 constexpr uint32_t SRCH_WAVE_MAX_COLS = 256;    // bytes a block may span (emitted columns + left context): 4 registers of 64
 
-// Emit(end_local_index_plus_1, length, cost): called wave-uniformly (every lane, same arguments), in increasing end order.
+// The block's hits are collected in two registers -- hit number h (in increasing end order) sits in LANE h: its packed key and
+// its column (a block emits at most SRCH_WAVE_MAX_HITS = 64 end positions) -- and handed over ONCE, after the
+// last step: flush(nh, keys, cols), hit h = (cost = keys[h] >> 16, length = 0xFFFF - (keys[h] & 0xFFFF), end = col_begin +
+// cols[h] + 1).  (One atomic cursor bump per block instead of one round trip to memory per hit inside the dependent chain.)
 // `needle` must be readable per lane (global / kernarg memory on the device).
-template <class W, bool TRANS, class Emit>
+constexpr uint32_t SRCH_WAVE_MAX_HITS = 64;
+template <class W, bool TRANS, class Flush>
 TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needle, uint32_t n, const SearchCosts &C,
-                                        uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Emit emit) {
+                                        uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Flush flush) {
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     if (col_begin >= col_end || n == 0) return;
@@ -59,6 +63,8 @@ TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needl
     U32 oldp = v;                              // this lane's value before its last update
     U32 dcur = W::splat(ROW0), dprev = W::splat(ROW0);   // the diag this lane used one / two steps ago
     U32 c = W::splat(0u);                     // the byte this lane used one step ago = hay[i-1]
+    U32 hit_key = W::splat(0u), hit_col = W::splat(0u);
+    uint32_t nh = 0;
     const uint32_t steps = ncols + n - 1;
     const uint32_t first_emit = e0 + n - 1;    // lane n-1 reaches column e0 at this step
     uint32_t s = 0;
@@ -93,10 +99,15 @@ TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needl
             hg = h; oldp = old; c = cn;
             if (s >= first_emit) {                                         // lane n-1 has just finished column s - (n-1)
                 const uint32_t key = W::readlane(v, n - 1);
-                if ((key >> 16) <= C.k) emit(col_begin + (s - (n - 1)) + 1, 0xFFFFu - (key & 0xFFFFu), key >> 16);
+                if ((key >> 16) <= C.k && nh < SRCH_WAVE_MAX_HITS) {      // :1792-1806
+                    hit_key = W::writelane(hit_key, key, nh);
+                    hit_col = W::writelane(hit_col, s - (n - 1), nh);
+                    nh++;
+                }
             }
         }
     }
+    if (nh) flush(nh, hit_key, hit_col);
 }
 
 }  // namespace ta

@@ -121,12 +121,16 @@ hipError_t lev_search_list_launch(const SearchParams &P, bool trans, const uint3
 // Device-side control block of one filtered search pass (zeroed by ONE memset) and the report its last wavefront writes
 // into host-mapped pinned memory: the host learns everything it needs from one stream synchronisation, with no copy and
 // no round trip between the filter and the exact kernel.
+constexpr uint32_t SEARCH_DONE_GROUPS = 16;
 struct SearchCtl {
     unsigned long long count;     // hits emitted (may exceed the caller's cap)
     uint32_t n_list;              // 64-column blocks the filter flagged
-    uint32_t best_inv;            // 0xFFFFFFFF - the smallest k emitted (atomicMax; 0 = none)
-    uint32_t done;                // workgroups that have finished (the last one writes the report)
-    uint32_t pad[11];
+    uint32_t pad0;
+    uint32_t done2;               // groups of workgroups that have finished (the last one writes the report)
+    uint32_t pad1;
+    uint32_t pad[10];             // [0], [1]: timestamps of wavefront 0
+    uint32_t done[SEARCH_DONE_GROUPS * 16];   // finished workgroups per group, one counter per 64-byte line: 512 bumps of ONE address
+                                  // serialise at the memory side (~70 ns each); 16 lines of 32 run side by side
 };
 struct SearchReport {             // 64 bytes, followed by up to SEARCH_REPORT_SEL selected ta_match records (Best passes)
     uint64_t count;
@@ -135,8 +139,16 @@ struct SearchReport {             // 64 bytes, followed by up to SEARCH_REPORT_S
     uint32_t sel_count;           // Best: hits with the smallest k ...
     uint32_t sel_state;           // ... 1: all of them follow this header, 2: too many to select here (use ta_search_best_hits_dev)
     uint32_t min_k;
-    uint32_t pad[9];
+    uint32_t n_slots;
+    uint32_t t[8];                // 100 MHz timestamps (s_memrealtime, low dword): [0] wavefront 0 enters, [1] it has finished its blocks,
+                                  // [2] the last workgroup starts the report, [3] ... has written it   (scripts/measure_search_parts.py)
 };
+// Best passes: one slot per flagged block
+struct SearchSlot {
+    uint32_t min_cost, cnt;       // the block's best cost and its number of hits (0: none -- the slot is as the fill left it)
+    uint64_t idx0;                // its hits are hits[idx0 .. idx0 + cnt)
+};
+constexpr uint32_t SEARCH_SLOT_CAP = 1u << 18;                                      // flagged blocks a fused Best pass handles (4 MiB of slots)
 constexpr uint32_t SEARCH_REPORT_SEL = 680;                                         // 64 + 680 * 24 = 16 KiB
 constexpr size_t SEARCH_REPORT_BYTES = 64 + (size_t)SEARCH_REPORT_SEL * sizeof(ta_match);
 // thread-local pinned, device-mapped landing zone of the report
@@ -148,7 +160,8 @@ struct PinBox {
 PinBox &search_report_box();
 // one wavefront per flagged block (lev_search_wave_body.h), persistent grid reading n_list on the device; needles <= 64 bytes
 hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
-                                  SearchCtl *ctl, uint8_t *report_dev, hipStream_t s);
+                                  SearchCtl *ctl, SearchSlot *slots /* SEARCH_SLOT_CAP of them; Best passes */, uint8_t *report_dev,
+                                  hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
 
 }  // namespace ta

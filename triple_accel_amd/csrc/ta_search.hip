@@ -105,7 +105,7 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
     if (!device_ready()) return TA_ERR_HIP;
     StreamGuard guard(st);
     Scratch &cnt = tls_scratch(2);
-    int rc = cnt.ensure(64);
+    int rc = cnt.ensure(sizeof(SearchCtl) + 64);
     if (rc) return rc;
     SearchParams P;
     size_t h = haystack_len;
@@ -164,7 +164,8 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
         TA_HIP(hipMemsetAsync(ctl, 0, sizeof(SearchCtl), st));           // the pass's one fill
         P.count = &ctl->count;
         SearchParams F = P;
-        uint64_t ft = (h + 131071) / 131072;                          // one set of resident lanes (256 CUs x 8 waves x 64)
+        uint64_t ft = (h + 524287) / 524288;                          // two sets of resident lanes (256 CUs x 16 waves x 64): 0.557 against 0.601 ms
+                                                                      // per GiB with one set of 8 waves per CU (profiles/r03/ab_search.md)
         if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
         ft = (ft + 2 * FILTER_BLOCK - 1) / (2 * FILTER_BLOCK) * (2 * FILTER_BLOCK);      // whole 128-byte lines per lane
         if (const char *e = env_str("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
@@ -173,8 +174,10 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
         if (needle_len <= 64 && k <= 30000u) {
             // one wavefront per flagged block; no host round trip: the report arrives with the stream synchronisation
             PinBox &box = search_report_box();
-            if ((rc = box.ensure())) return rc;
-            TA_HIP(lev_search_wave_launch(P, trans, best != nullptr, (const uint32_t *)ls.dev, (uint32_t)cap_list, ctl, box.dev, st));
+            Scratch &cd = tls_scratch(12);
+            if ((rc = box.ensure()) || (best && (rc = cd.ensure((size_t)SEARCH_SLOT_CAP * sizeof(SearchSlot))))) return rc;
+            TA_HIP(lev_search_wave_launch(P, trans, best != nullptr, (const uint32_t *)ls.dev, (uint32_t)cap_list, ctl, (SearchSlot *)cd.dev,
+                                          box.dev, st));
             TA_HIP(hipStreamSynchronize(st));
             const SearchReport *rep = (const SearchReport *)box.host;
             if (!rep->dense) {
@@ -234,6 +237,14 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
     if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
     return search_dev_core(needle_host, needle_len, haystack_dev, haystack_len, k, costs, anchored, base, emit_from, hits_dev, cap,
                            count_host, nullptr, (hipStream_t)stream);
+}
+
+// (measurement aid, not part of the ABI header) the report of this thread's last filtered search pass, as 16 dwords
+int ta_debug_last_search_report(uint32_t *out16) {
+    PinBox &box = search_report_box();
+    if (!box.host || !out16) return TA_ERR_ARG;
+    memcpy(out16, box.host, 64);
+    return TA_OK;
 }
 
 // The Best-mode pass over a shard: the All-mode hits stay in hits_dev, only the ones with the smallest k come back.

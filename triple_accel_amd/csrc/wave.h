@@ -209,6 +209,8 @@ struct DevWave {
     static __device__ __forceinline__ void mem_fence() { __threadfence(); }
     // value of x in lane l (l wave-uniform) -> v_readlane_b32
     static __device__ __forceinline__ uint32_t readlane(U32 x, uint32_t l) { return __builtin_amdgcn_readlane(x, l); }
+    // x with lane l (wave-uniform) replaced by the wave-uniform value v (v_cmp + v_cndmask; hipcc has no writelane builtin)
+    static __device__ __forceinline__ U32 writelane(U32 x, uint32_t v, uint32_t l) { return lane() == l ? v : x; }
     static __device__ __forceinline__ U32 gload_u8(Ptr p, Bool pred) { return pred ? (U32)*p : 0u; }
     static __device__ __forceinline__ uint32_t wave_sum(U32 x) {
         for (int m = 32; m >= 1; m >>= 1) x += shfl(x, lane() ^ (uint32_t)m);
