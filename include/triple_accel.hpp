@@ -28,6 +28,7 @@ inline void check_(int rc) {
         case TA_ERR_LEN_MISMATCH: throw panic_error("assertion failed: a.len() == b.len()");
         case TA_ERR_NULL_BYTE: throw panic_error("No zero/null bytes allowed in the string!");
         case TA_ERR_BAD_COSTS: throw panic_error("invalid EditCosts");
+        case TA_ERR_DIV_ZERO: throw panic_error("attempt to divide by zero");
         case TA_ERR_UNSUPPORTED: throw unsupported_error(ta_status_str(rc));
         default: throw device_error(std::string(ta_status_str(rc)) + ": " + ta_last_error());
     }

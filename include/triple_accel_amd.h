@@ -41,7 +41,8 @@ typedef enum {
     TA_ERR_HIP = 4,          /* HIP runtime failure / no device (no CPU fallback) */
     TA_ERR_ARG = 5,          /* null pointer, size over the documented limit */
     TA_ERR_UNSUPPORTED = 6,  /* outside what the GPU path covers (e.g. a traceback needing more than 8 GB of records) */
-    TA_ERR_CAPACITY = 7      /* caller-provided match buffer too small; *n_out holds the need */
+    TA_ERR_CAPACITY = 7,     /* caller-provided match buffer too small; *n_out holds the need */
+    TA_ERR_DIV_ZERO = 8      /* "attempt to divide by zero": hamming_search_naive*, empty needle, Best  src/hamming.rs:136 */
 } ta_status;
 
 /* EditCosts, src/levenshtein.rs:20-26 (fields are private there; built via new / the consts) */

@@ -11,7 +11,7 @@
 //!   is an unconditional blend (src/levenshtein.rs:2384-2388) where the scalar path tests `<=` (:517-525), and whose
 //!   tracebacks / match starts can differ from the scalar ones on ties.  Where the two disagree this crate returns the
 //!   scalar answer under both names (INTEGRATION.md section 5 lists the cases);
-//! * the generic `T: PartialEq` entry points map their items onto bytes: more than 256 distinct items panic.
+//! * the generic `T: PartialEq` entry points map their items onto bytes: more than 254 distinct items COMMON to both strings panic.
 use std::os::raw::{c_int, c_void};
 
 #[derive(Debug, PartialEq)]
@@ -59,6 +59,7 @@ mod ffi {
             1 => panic!("assertion failed: a.len() == b.len()"),
             2 => panic!("No zero/null bytes allowed in the string!"),
             3 => panic!("invalid EditCosts"),
+            8 => panic!("attempt to divide by zero"),
             _ => panic!("triple_accel_amd: status {} (no CPU fallback below the C ABI)", rc),
         }
     }
@@ -208,22 +209,19 @@ pub mod levenshtein {
 
     // ---- the scalar entry points: the kernels implement the scalar rules, so these are the same calls under the other names
 
-    /// items of any `T: PartialEq` -> bytes over one code table shared by both strings (at most 256 distinct items)
+    /// items of any `T: PartialEq` -> bytes.  The recurrence only ever compares an item of `a` with an item of `b`, so the items
+    /// that occur on ONE side only share one code per side (254: only in `a`, 255: only in `b`): any pair with at most 254
+    /// distinct items COMMON to both strings rides the byte kernels.
     fn symbols<'x, T: PartialEq>(a: &'x [T], b: &'x [T]) -> (Vec<u8>, Vec<u8>) {
-        fn code<'x, T: PartialEq>(table: &mut Vec<&'x T>, x: &'x T) -> u8 {
-            match table.iter().position(|d| **d == *x) {
-                Some(i) => i as u8,
-                None => {
-                    assert!(table.len() < 256, "triple_accel_amd: more than 256 distinct symbols cannot be mapped onto the byte kernels");
-                    table.push(x);
-                    (table.len() - 1) as u8
-                }
+        let mut common: Vec<&'x T> = Vec::new();
+        for x in a {
+            if b.iter().any(|y| *y == *x) && !common.iter().any(|d| **d == *x) {
+                assert!(common.len() < 254, "triple_accel_amd: more than 254 distinct symbols common to both strings cannot be mapped onto the byte kernels");
+                common.push(x);
             }
         }
-        let mut table: Vec<&'x T> = Vec::with_capacity(256);
-        let ta: Vec<u8> = a.iter().map(|x| code(&mut table, x)).collect();
-        let tb: Vec<u8> = b.iter().map(|x| code(&mut table, x)).collect();
-        (ta, tb)
+        let code = |x: &T, other: u8| common.iter().position(|d| **d == *x).map(|i| i as u8).unwrap_or(other);
+        (a.iter().map(|x| code(x, 254)).collect(), b.iter().map(|x| code(x, 255)).collect())
     }
     /// src/levenshtein.rs:148
     pub fn levenshtein_naive_with_opts<T: PartialEq>(a: &[T], b: &[T], trace_on: bool, costs: EditCosts) -> (u32, Option<Vec<Edit>>) {

@@ -111,3 +111,18 @@ def test_every_reference_pub_fn_has_a_mirror():
         assert re.search(r"pub fn %s\b" % n, rs), n
     for t in ("Match", "Edit", "EditType", "SearchType", "EditCosts", "LEVENSHTEIN_COSTS", "RDAMERAU_COSTS"):
         assert hasattr(T, t) and re.search(r"pub (struct|enum|const) %s\b" % t, rs), t
+
+
+def test_experimental_build_of_the_dispatch_parses():
+    """`make EXPERIMENTAL=1` compiles ta_api.hip with -DTA_EXPERIMENTAL: the dispatch must at least parse that way
+    (round 2 shipped an `else` + `#endif` that left a variable undeclared)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "triple_accel_amd", "csrc")
+    for tu in ("ta_api.hip",):
+        r = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "--cuda-host-only", "-DTA_EXPERIMENTAL", "-fsyntax-only", tu],
+                           cwd=src, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]

@@ -88,3 +88,39 @@ def test_first_call_before_any_torch_use_in_a_fresh_process():
             "assert (out == 0).all() and torch.cuda.is_available(); print('fresh ok')" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fresh ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_generic_items_beyond_256_symbols_and_buffer_inputs():
+    """levenshtein_naive<T: PartialEq> (src/levenshtein.rs:105-148) on sequences with far more than 256 distinct items: only the
+    items common to both sides need codes of their own.  Inputs with the buffer protocol (array.array, ctypes arrays) are bytes."""
+    import array
+    import ctypes
+    import triple_accel_amd as T
+    g = Dg.rng(77)
+    for trial in range(8):
+        n = int(g.integers(300, 600))
+        a = [int(v) for v in g.integers(0, 1 << 20, size=n)]            # ~n distinct items
+        b = list(a)
+        for _ in range(int(g.integers(0, 40))):                          # edits with items from a disjoint range
+            p = int(g.integers(0, len(b)))
+            r = int(g.integers(0, 3))
+            if r == 0: b[p] = (1 << 21) + p
+            elif r == 1: b.insert(p, (1 << 22) + p)
+            else: del b[p]
+        # reference value: a plain two-row DP over the items themselves
+        prev = list(range(len(a) + 1))
+        for j in range(1, len(b) + 1):
+            cur = [j] + [0] * len(a)
+            for i in range(1, len(a) + 1):
+                cur[i] = min(prev[i - 1] + (a[i - 1] != b[j - 1]), prev[i] + 1, cur[i - 1] + 1)
+            prev = cur
+        assert T.levenshtein_naive(a, b) == prev[len(a)]
+        assert T.levenshtein_naive_k_with_opts(a, b, 100, False, T.LEVENSHTEIN_COSTS)[0] == prev[len(a)]      # (<= 40 edits)
+    assert T.levenstein_naive_str("".join(chr(0x400 + i) for i in range(600)), "".join(chr(0x400 + i) for i in range(1, 601))) == 2
+    assert T.hamming(array.array("B", [1, 2, 3]), (ctypes.c_uint8 * 3)(1, 9, 3)) == 1
+    with pytest.raises(TypeError):
+        T.hamming(5, b"abcde")
+    with pytest.raises(T.PanicError):                                    # src/hamming.rs:136: haystack_len / 0
+        list(T.hamming_search_naive_with_opts(b"", b"abc", 2, T.SearchType.Best))
+    with pytest.raises(T.PanicError):
+        list(T.hamming_search_naive(b"", b"abc"))

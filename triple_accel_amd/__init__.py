@@ -74,6 +74,8 @@ def _raise(rc):
         raise PanicError("No zero/null bytes allowed in the string!")
     if rc == _n.TA_ERR_BAD_COSTS:
         raise PanicError("invalid EditCosts")
+    if rc == _n.TA_ERR_DIV_ZERO:
+        raise PanicError("attempt to divide by zero")
     if rc == _n.TA_ERR_UNSUPPORTED:
         raise NotImplementedError("triple_accel_amd: not on the GPU path (" + _n.lib().ta_last_error().decode() + ")")
     _n.check(rc)
@@ -89,9 +91,12 @@ def _b(x):
     """bytes-like only: `bytes(5)` would silently turn an int into five NUL bytes."""
     if isinstance(x, bytes):
         return x
-    if isinstance(x, (bytearray, memoryview)) or type(x).__name__ == "ndarray":
-        return bytes(x)
-    raise TypeError("expected a bytes-like string, got %s" % type(x).__name__)
+    if isinstance(x, (int, str)):
+        raise TypeError("expected a bytes-like string, got %s" % type(x).__name__)
+    try:                                   # anything with the buffer protocol: bytearray, memoryview, ndarray, array.array, mmap, ctypes arrays
+        return bytes(memoryview(x))
+    except TypeError:
+        raise TypeError("expected a bytes-like string, got %s" % type(x).__name__) from None
 
 
 def _k(k):
@@ -301,28 +306,28 @@ def rdamerau_simd_k(a, b, k):
 hamming_naive = hamming                                   # src/hamming.rs:36
 
 
-def _symbols(*seqs):
-    """Sequences of arbitrary equality-comparable items -> byte strings over a shared code table (the generic `T: PartialEq`
-    entry points, src/levenshtein.rs:105, :148, :376).  More than 256 distinct items cannot ride the byte path."""
-    table, outs = [], []
-    for s in seqs:
-        if isinstance(s, (bytes, bytearray)):
-            outs.append(None)
-            continue
-        o = bytearray()
-        for x in s:
-            try:
-                i = table.index(x)
-            except ValueError:
-                if len(table) >= 256:
-                    raise NotImplementedError("triple_accel_amd: more than 256 distinct symbols cannot be mapped onto the byte kernels")
-                table.append(x)
-                i = len(table) - 1
-            o.append(i)
-        outs.append(bytes(o))
-    if any(o is None for o in outs):                      # byte strings go through unchanged (all of them must then be bytes)
-        return [bytes(s) for s in seqs]
-    return outs
+def _symbols(a, b):
+    """Two sequences of arbitrary equality-comparable items -> byte strings over a shared code table (the generic
+    `T: PartialEq` entry points, src/levenshtein.rs:105, :148, :376).  The recurrence only ever compares an item of `a` with an
+    item of `b`, so every item that occurs in ONE of the two sequences only can share a single code per side (it never equals
+    anything on the other side): the byte kernels serve any pair with at most 254 distinct items COMMON to both.  Byte strings
+    go through unchanged when both are; a byte string next to a general sequence is a sequence of ints."""
+    if all(isinstance(s, (bytes, bytearray, memoryview)) for s in (a, b)):
+        return [bytes(a), bytes(b)]
+    a, b = list(a), list(b)
+    try:                                   # hashable items: O(n)
+        common = set(a) & set(b)
+        code = {x: i for i, x in enumerate(common)}
+        enc = lambda x: code.get(x)
+    except TypeError:                      # only `==` is promised
+        common = [x for n, x in enumerate(a) if x in b and x not in a[:n]]
+        enc = lambda x: common.index(x) if x in common else None
+    if len(common) > 254:
+        raise NotImplementedError("triple_accel_amd: more than 254 distinct symbols common to both sequences cannot be mapped "
+                                  "onto the byte kernels")
+    ea = bytes(254 if (c := enc(x)) is None else c for x in a)      # 254: only in a, 255: only in b
+    eb = bytes(255 if (c := enc(x)) is None else c for x in b)
+    return [ea, eb]
 
 
 def levenshtein_naive_with_opts(a, b, trace_on, costs):

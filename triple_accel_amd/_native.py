@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libtriple_accel_amd.so")
 
 NONE = 0xFFFFFFFF
 TA_OK, TA_ERR_LEN_MISMATCH, TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS, TA_ERR_HIP, TA_ERR_ARG, TA_ERR_UNSUPPORTED, \
-    TA_ERR_CAPACITY = range(8)
+    TA_ERR_CAPACITY, TA_ERR_DIV_ZERO = range(9)
 
 # every symbol include/triple_accel_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

@@ -16,6 +16,9 @@ namespace ta {
 
 static thread_local std::string g_last_error;
 static thread_local ta_launch_info g_last_launch = {};
+// true when the last distance pass of this thread was ONE kernel whose only store to its result slot is the answer: the
+// single-call entry points may then watch the pinned result word instead of synchronising the stream (fetch_u32)
+static thread_local bool g_answer_single_store = false;
 
 void set_last_error(const char *what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -158,6 +161,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     const bool affine = sg > 0 || env_int("TA_FORCE_AFFINE"), trans = c->has_transpose != 0;
     ta_launch_info li = {};
     li.band_offset = pl.o; li.affine = affine; li.transpose = trans;
+    g_answer_single_store = true;                     // every branch below is one launch except the tiled row-blocked form
     ta_lev_select sel;
     ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
     li.cell_bits = sel.cell_bits;
@@ -194,7 +198,10 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         TA_HIP(lev_sliced_launch(P.a, P.b, n_work, k, bp.u, out_dev, st, &grid, &lds, &ppw));
         li.kernel = 5; li.diags_per_lane = 3; li.lanes_per_pair = sl_strips; li.pairs_per_wave = ppw;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
-    } else
+        if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=%u k=%u u=%u kernel=5 (pair-sliced) grid=%u lds=%u\n", n_work, k, bp.u, grid, lds);
+        g_last_launch = li;
+        return TA_OK;                                  // (like the single-pair branch below: nothing else may write `out`)
+    }
 #endif
     uint32_t u_one = 0;
     if (n_work == 1 && !dp_forced && !pinned && !env_int("TA_FORCE_WIDEBITS") && !env_int("TA_NO_ONE") &&
@@ -233,6 +240,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         // ONE long pair (the single-call API) or a handful of them (fixed-length batch): a pair's stripe sweeps are cut into
         // tiles and spread over many wavefronts, pair after pair
         uint32_t launches = 0;
+        g_answer_single_store = false;                 // many launches per pair; only the last tile stores the answer
         for (uint32_t p = 0; p < n_work; p++)
             TA_HIP(lev_widebits_huge_launch(a->blob + (uint64_t)p * a->stride, (uint32_t)a->len, b->blob + (uint64_t)p * b->stride,
                                             (uint32_t)b->len, bp.u, k, ch.rows_per_lane, trans, out_dev + p, st, &launches));
@@ -309,6 +317,7 @@ const char *ta_status_str(int s) {
         case TA_ERR_ARG: return "bad argument";
         case TA_ERR_UNSUPPORTED: return "unsupported on the GPU path";
         case TA_ERR_CAPACITY: return "output capacity exceeded";
+        case TA_ERR_DIV_ZERO: return "attempt to divide by zero";
         default: return "unknown";
     }
 }
@@ -523,13 +532,24 @@ static int stage_pair(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b
 // value no answer can take, and the host watches the pinned word instead of going through the runtime's completion
 // machinery (the store becomes visible no later than the kernel's end-of-kernel release); after 20 ms without an answer the
 // ordinary stream synchronisation takes over (and reports a fault, if that is what happened).
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 static int fetch_u32(const Staged &S, uint32_t *out, bool single_store = false) {
     if (S.out_host) {
         if (single_store) {
+            // a short spin (the answer of a short pair arrives within ~10-25 us), then the runtime's own wait: a host core is
+            // never held for longer than 200 us per call
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spin = 0; *S.out_host == TA_SLOT_EMPTY; spin++) {
-                __builtin_ia32_pause();
-                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                cpu_relax();
+                if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
             }
             const uint32_t v = *S.out_host;
             if (v != TA_SLOT_EMPTY) { *out = v; return TA_OK; }
@@ -551,7 +571,7 @@ int ta_hamming(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, u
     if (rc) return rc;
     rc = ta_hamming_batch(&S.sa, &S.sb, 1, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(S, out, true);
+    return fetch_u32(S, out, true);                          // one kernel, one store
 }
 
 int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
@@ -566,7 +586,7 @@ int ta_levenshtein_simd_k_with_opts(const uint8_t *a, size_t a_len, const uint8_
     if (rc) return rc;
     rc = ta_levenshtein_k_batch(&S.sa, &S.sb, 1, k, costs, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(S, out, true);      // (pairs that fit the pinned buffer are always a single kernel)
+    return fetch_u32(S, out, g_answer_single_store);         // lev_pass says whether the pass was one kernel with one store
 }
 
 }  // extern "C"

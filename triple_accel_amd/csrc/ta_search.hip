@@ -475,7 +475,8 @@ int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
 }
 
 /* hamming_search_naive_with_opts (src/hamming.rs:96-146): the same scan under the scalar routine's contract -- NUL bytes in the
- * haystack are fine, and an empty needle matches (with k = 0) at every offset 0..=haystack_len. */
+ * haystack are fine, and an empty needle matches (with k = 0) at every offset 0..=haystack_len in All mode; in Best mode the
+ * reference divides by the needle length (:136) and panics: TA_ERR_DIV_ZERO. */
 int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
                                       const uint8_t *haystack, size_t haystack_len,
                                       uint32_t k, int search_type, ta_match **out, size_t *n_out) {
@@ -484,8 +485,9 @@ int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
     if (needle_len > haystack_len) return TA_OK;                                // :100-102
     std::vector<ta_match> hits;
     if (needle_len == 0) {                                                      // the loop body never runs: final_res = 0 everywhere
-        if (!device_ready()) return TA_ERR_HIP;
-        hits.reserve(haystack_len + 1);
+        // Best collects into Vec::with_capacity(haystack_len / needle_len) (:136): the reference panics on the division
+        if (search_type == TA_SEARCH_BEST) return TA_ERR_DIV_ZERO;
+        hits.reserve(haystack_len + 1);                                         // (no kernel: this answer needs no device)
         for (size_t i = 0; i <= haystack_len; i++) hits.push_back(ta_match{i, i, 0u, 0u});
         return give(hits, out, n_out);
     }
