@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse_args():
@@ -42,9 +42,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w"],
+                    help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
+                         "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
-    ap.add_argument("--dist", default="random", choices=["random", "mutated"])
+    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged"],
+                    help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -121,10 +124,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+        except Exception as e:                     # a clear message instead of a hang or a bare stack trace
+            sys.exit("bench.py: rank %d could not join the %s process group (%s: %s).  RCCL needs one visible GPU per rank and "
+                     "HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment; TA_BENCH_BACKEND=gloo runs the control plane without it."
+                     % (rank, backend, type(e).__name__, e))
 
     wl = args.workload
     evaluated_unit = None
@@ -137,10 +146,13 @@ def main():
 
     # ------------------------------------------------------------------ workload set-up
     # make(seed, lo, hi) -> (run, units, parity, extra): one rank's share of a batch
-    if wl in ("cfg2", "cfg4", "cfg3", "cfg1"):
+    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w"):
         n_cfg, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
-                              "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM)}[wl]
+                              "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM),
+                              "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3))}[wl]
         n_cfg = args.pairs or n_cfg
+        ragged = args.dist == "ragged"
+        assert not ragged or wl in ("cfg2", "cfg4", "cfg2w", "cfg4w"), "--dist ragged is a k-bounded batch distribution"
         bytes_unit = 2 * L + 4
         if wl == "cfg1":
             cells_unit = L
@@ -151,43 +163,84 @@ def main():
         else:
             cells_unit = O.band_cells(L, L, k, costs)              # cells the scalar banded path visits
             desc = {"cfg2": "levenshtein_simd_k k=32, 1M random 256B pairs, u8 cells",
-                    "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)"}[wl]
+                    "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)",
+                    "cfg2w": "levenshtein_simd_k_with_opts EditCosts(2,3,1,None) k=32, 1M 256B pairs (general costs: DP band-wavefront kernel)",
+                    "cfg4w": "levenshtein_simd_k_with_opts EditCosts(2,2,1,Some(3)) k=8, 1M 128B pairs (general costs + transposition)"}[wl]
             unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select); the kernel computes on 1-bit cells in u32 lanes
             # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
             #  -- about half of the credited reference band; reported beside the credited figure
-            uk = min((min(k, L * max(costs[0], costs[1])) - costs[2]) // costs[1], 2 * L)
+            uk = min(max(min(k, L * max(costs[0], costs[1])) - costs[2], 0) // costs[1], 2 * L)
             evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
 
+        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14}[wl]
+
         def gen(seed, n):
-            if args.dist == "random":
-                return Dg.pairs_random(seed, n, L)
+            """-> ((blob_a, off_a), (blob_b, off_b)) as numpy CSR; fixed-length distributions also carry their (n, L) arrays"""
             g = Dg.rng(seed)
-            a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
-            b = a.copy()
-            pos = g.integers(0, L, size=(n, max(1, (k or 64) // 2)))
-            b[np.arange(n)[:, None], pos] = 32
-            return a, b
+            if ragged:                      # lengths uniform on 32..L, b within +-4 of a; random bytes
+                la = g.integers(min(32, L), L + 1, size=n).astype(np.int64)
+                lb = np.clip(la + g.integers(-4, 5, size=n), 1, L).astype(np.int64)
+                csr = []
+                for ln in (la, lb):
+                    off = np.zeros(n + 1, dtype=np.int64)
+                    np.cumsum(ln, out=off[1:])
+                    blob = np.zeros(int(off[-1]) + 16, dtype=np.uint8)
+                    blob[:int(off[-1])] = Dg.random_bytes(g, int(off[-1]))
+                    csr.append((blob, off))
+                return csr[0], csr[1], None
+            if args.dist == "random":
+                a, b = Dg.pairs_random(seed, n, L)
+            else:
+                a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
+                b = a.copy()
+                pos = g.integers(0, L, size=(n, max(1, (k or 64) // 2)))
+                b[np.arange(n)[:, None], pos] = 32
+            return None, None, (a, b)
+
+        def csr_cut(c, lo, hi):
+            blob, off = c
+            out = np.zeros(int(off[hi] - off[lo]) + 16, dtype=np.uint8)
+            out[:-16] = blob[int(off[lo]):int(off[hi])]
+            return out, (off[lo:hi + 1] - off[lo]).astype(np.uint64)
 
         def make(share_of_common_batch):
             """One rank's pairs: its own batch (weak) or its contiguous share of the common one (strong)."""
-            if share_of_common_batch:
-                a, b = gen(0x7A00 + int(wl[3:]), n_cfg)
-                lo, hi = TD.shard_range(n_cfg, rank, world)
-                a, b = a[lo:hi], b[lo:hi]
+            ca, cb, fixed = gen(seed0 + (0 if share_of_common_batch else 1000 * rank), n_cfg)
+            lo, hi = TD.shard_range(n_cfg, rank, world) if share_of_common_batch else (0, n_cfg)
+            n = hi - lo
+            if fixed is not None:
+                a, b = fixed[0][lo:hi], fixed[1][lo:hi]
+                sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+                csr = lambda l, h: (O.csr_from_fixed(a[l:h]), O.csr_from_fixed(b[l:h]))
+                cells_total, bytes_total = cells_unit * n, bytes_unit * n
+                host_blobs = [(sa.blob, a), (sb.blob, b)]
             else:
-                a, b = gen(0x7A00 + int(wl[3:]) + 1000 * rank, n_cfg)
-            n = a.shape[0]
-            sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+                ca, cb = csr_cut(ca, lo, hi), csr_cut(cb, lo, hi)
+                la, lb = np.diff(ca[1].astype(np.int64)), np.diff(cb[1].astype(np.int64))
+                dev = lambda c, ln: B.Strings(torch.from_numpy(c[0]).cuda(), torch.from_numpy(c[1].astype(np.int64)).cuda(),
+                                              max_len=int(ln.max()) if n else 0)
+                sa, sb = dev(ca, la), dev(cb, lb)
+                csr = lambda l, h: (csr_cut(ca, l, h), csr_cut(cb, l, h))
+                # credited pair by pair: the cells the scalar banded loop visits (SURVEY.md 8d); a pair whose length
+                # difference exceeds unit_k returns None before any cell (src/levenshtein.rs:426-428)
+                memo = {}
+                keys, counts = np.unique(la * 100000 + lb, return_counts=True)
+                for key, cnt in zip(keys.tolist(), counts.tolist()):
+                    x, y = key // 100000, key % 100000
+                    uk_xy = O.levenshtein_select(x, y, k, costs)[1]          # (max_k, unit_k, cell bits, lanes)
+                    memo[key] = (0 if abs(x - y) > uk_xy else O.band_cells(x, y, k, costs)) * cnt
+                cells_total, bytes_total = int(sum(memo.values())), int(la.sum() + lb.sum() + 4 * n)
+                host_blobs = [(sa.blob, ca[0]), (sb.blob, cb[0]), (sa.off, ca[1].astype(np.int64)), (sb.off, cb[1].astype(np.int64))]
             out = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
             if wl == "cfg1":
                 run = lambda: B.hamming_batch(sa, sb, out=out)
-                oracle = lambda lo, hi, th: O.hamming_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), threads=th)
+                oracle = lambda l, h, th: O.hamming_batch(*csr(l, h), threads=th)
             elif wl == "cfg3":
                 run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
-                oracle = lambda lo, hi, th: O.levenshtein_exp_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), costs, threads=th)
+                oracle = lambda l, h, th: O.levenshtein_exp_batch(*csr(l, h), costs, threads=th)
             else:
                 run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out)
-                oracle = lambda lo, hi, th: O.levenshtein_k_batch(O.csr_from_fixed(a[lo:hi]), O.csr_from_fixed(b[lo:hi]), k, costs, threads=th)
+                oracle = lambda l, h, th: O.levenshtein_k_batch(*csr(l, h), k, costs, threads=th)
             if n == 0:
                 run = lambda: None
 
@@ -197,7 +250,23 @@ def main():
                 got = out[:ns].cpu().numpy().view(np.uint32)
                 assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
                 return ns
-            return run, n, parity, {"a": a, "b": b, "oracle": oracle}
+
+            def end_to_end(reps=3):
+                """host buffers in, answers out: pinned H2D of the batch + the pass + D2H of the results; ms"""
+                pins = [(dst, torch.from_numpy(np.ascontiguousarray(src).reshape(-1)).pin_memory()) for dst, src in host_blobs]
+                out_h = torch.empty(max(n, 1), dtype=torch.int32).pin_memory()
+                ts = []
+                for _ in range(reps + 1):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for dst, src in pins:
+                        dst[: src.numel()].copy_(src, non_blocking=True)
+                    run()
+                    out_h[:n].copy_(out, non_blocking=True)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                return float(np.mean(ts[1:]))
+            return run, n, parity, {"csr": csr, "oracle": oracle, "cells_total": cells_total, "bytes_total": bytes_total, "end_to_end": end_to_end}
     else:   # cfg5: levenshtein_search, 32 B needle over a 1 GiB random shard per GPU
         mib = args.pairs or 1024
         needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()     # same needle on every rank
@@ -243,7 +312,20 @@ def main():
                     dist.all_gather(allv, mine)
                     assert len({int(v[0].item()) for v in allv}) == 1, "sharded search: ranks disagree"
                 return ns
-            return run, hay_np.size, parity, {"hay_np": hay_np}
+            def end_to_end(reps=2):
+                """host haystack in, Best matches out: pinned H2D of the shard + the pass (its report comes back by itself); ms"""
+                pin = torch.from_numpy(hay_np).pin_memory()
+                ts = []
+                for _ in range(reps + 1):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    hay[0][: pin.numel()].copy_(pin, non_blocking=True)
+                    run()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                return float(np.mean(ts[1:]))
+            return run, hay_np.size, parity, {"hay_np": hay_np, "cells_total": cells_unit * hay_np.size, "bytes_total": bytes_unit * hay_np.size,
+                                              "end_to_end": end_to_end}
 
     # ------------------------------------------------------------------ timing helpers
     def barrier():
@@ -259,7 +341,8 @@ def main():
 
     def timed_region(run, steps, warmup):
         """clock ramp (untimed, --prewarm-ms), W untimed warm-ups, then EXACTLY `steps` passes between barrier + synchronize;
-        max over ranks.  -> (wall seconds, mean device ms per pass from HIP events on the launch stream)"""
+        max over ranks.  -> (wall seconds, mean device ms per pass from HIP events on the launch stream, ramp passes run)"""
+        n_ramp = 0
         if args.prewarm_ms > 0:
             # the number of ramp passes is agreed between the ranks (a pass may hold collectives): one timed pass, the maximum over ranks
             torch.cuda.synchronize()
@@ -273,6 +356,7 @@ def main():
                 n_ramp = int(tn.item())
             for _ in range(n_ramp):
                 run()
+            n_ramp += 1                                       # (the pass that sized the ramp)
             torch.cuda.synchronize()
         for _ in range(warmup):
             run()
@@ -290,42 +374,46 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, dev_ms
+        return elapsed, dev_ms, n_ramp
 
-    def total_units(units):
+    def totals(*vals):
+        """sums over the ranks"""
         if world == 1:
-            return units
-        tt = torch.tensor([units], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            return [int(v) for v in vals]
+        tt = torch.tensor([int(v) for v in vals], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt)
-        return int(tt.item())
+        return [int(v) for v in tt.tolist()]
 
     # ------------------------------------------------------------------ parity gate, warm-up, timed region
     run, units, parity, extra = make(strong and world > 1)
     parity_n = parity()
     info = T.last_launch_info()
-    elapsed, dev_ms = timed_region(run, args.steps, args.warmup)
-    all_units = total_units(units)
+    kernel_name = T.last_kernel_name()
+    elapsed, dev_ms, n_ramp = timed_region(run, args.steps, args.warmup)
+    all_units, all_cells = totals(units, extra["cells_total"])
+    e2e_ms = extra["end_to_end"]() if world == 1 else None
 
     strong_fig = None
+    extra_bytes = extra["bytes_total"]
     if world > 1 and not strong:        # the second figure of a multi-rank weak run: the same batch partitioned over the ranks
         del run, parity, extra
         torch.cuda.empty_cache()
-        run_s, units_s, parity_s, _ = make(True)
+        run_s, units_s, parity_s, extra_s = make(True)
         parity_s()
-        el_s, dev_s_ms = timed_region(run_s, args.steps, args.warmup)
-        tot_s = total_units(units_s)
+        el_s, dev_s_ms, _ = timed_region(run_s, args.steps, args.warmup)
+        tot_s, cells_s = totals(units_s, extra_s["cells_total"])
         if rank == 0:
-            strong_fig = {"value": cells_unit * tot_s * args.steps / el_s / 1e9, "unit": "GCUPS", "ms_per_step": el_s / args.steps * 1e3,
+            strong_fig = {"value": cells_s * args.steps / el_s / 1e9, "unit": "GCUPS", "ms_per_step": el_s / args.steps * 1e3,
                           "units_total": tot_s, "units_this_rank": units_s, "device_ms_per_pass": dev_s_ms}
-        extra = {}
+        extra = {"bytes_total": extra_bytes}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    value = cells_unit * all_units * args.steps / elapsed / 1e9
+    value = all_cells * args.steps / elapsed / 1e9
     dev_s = dev_ms / 1e3                                   # device time of one pass (HIP events on the launch stream)
-    achieved = bytes_unit * units / dev_s / 1e9
+    achieved = extra["bytes_total"] / dev_s / 1e9
 
     # committed counter passes of the same command (profiles/<round>/): HBM-side traffic and the VALU-issue roofline
     def load_json(*parts):
@@ -335,11 +423,20 @@ def main():
         except Exception:
             return None
     traffic = None
+    traffic_source = None
     valu_issue = None
-    pmc = load_json(PROFILE_ROUND, "bench_%s_pmc.json" % wl)
+    pmc = load_json(PROFILE_ROUND, "bench_%s%s_pmc.json" % (wl, "_ragged" if args.dist == "ragged" else ""))
+    # a committed counter pass is only spliced into the line when it was recorded for the kernel this run launched
+    # (T.last_kernel_name(): the dominant kernel of the pass, as rocprofv3 prints it) -- never for another build's kernel
+    if pmc and kernel_name and kernel_name not in str(pmc.get("_dominant", "")):
+        print("bench.py: profiles/%s counter pass was recorded for %r, this run launched %r: not spliced"
+              % (PROFILE_ROUND, pmc.get("_dominant"), kernel_name), file=sys.stderr)
+        pmc = None
     if pmc:
         try:
             traffic = int(pmc["_traffic"]["bytes_per_pass"])      # size-resolved L2 fabric-side requests, all kernels of one pass
+            traffic_source = ("replayed from the committed counter pass profiles/%s/bench_%s_pmc.json (rocprofv3 --pmc, separate passes, "
+                              "same command, kernel %s); not measured in this run" % (PROFILE_ROUND, wl, pmc.get("_dominant")))
         except Exception:
             traffic = None
         try:
@@ -387,29 +484,30 @@ def main():
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread (the scalar search is one serial scan), oracle/ta_oracle.c "
                              "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt), "host": facts}
-        elif wl in ("cfg2", "cfg4"):
+        elif wl in ("cfg2", "cfg4", "cfg2w", "cfg4w"):
             # Inputs staged once (CSR blobs), outside the timed loops.  Three restatements: the hand-written AVX2 one with
             # saturating u8 cells (oracle/ta_oracle_avx2.c: 64 / 32 u8 lanes per anti-diagonal for cfg2 / cfg4 -- the reference's
             # own Avx2x32x8 / Avx1x32x8 classes), the compiler-vectorised u16 anti-diagonal one (ta_oracle_simd.c) and the scalar
             # one (ta_oracle.c).  `value` is the best all-thread figure; `cores` the EFFECTIVE parallelism it reached
             # (all-thread rate / one-thread rate), with the thread-scaling line that shows where it saturates.
-            a, b = extra["a"], extra["b"]
             ns = min(units, 1_000_000)
-            ca, cb = O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns])
+            ca, cb = extra["csr"](0, ns)
             n1 = min(ns, 20_000)
-            c1a, c1b = O.csr_from_fixed(a[:n1]), O.csr_from_fixed(b[:n1])
+            c1a, c1b = extra["csr"](0, n1)
             ref = O.levenshtein_k_batch(c1a, c1b, k, costs, threads=cores)
             variants = [("scalar u32 (oracle/ta_oracle.c)", O.levenshtein_k_batch)]
-            got = O.levenshtein_k_batch_antidiag(c1a, c1b, k, costs, threads=cores)
-            assert got is not None and np.array_equal(got, ref), "the CPU restatements differ (u16 anti-diagonal)"
-            variants.append(("anti-diagonal u16, compiler-vectorised (oracle/ta_oracle_simd.c)", O.levenshtein_k_batch_antidiag))
+            got = O.levenshtein_k_batch_antidiag(c1a, c1b, k, costs, threads=cores)       # (None: affine gaps are not restated there)
+            if got is not None:
+                assert np.array_equal(got, ref), "the CPU restatements differ (u16 anti-diagonal)"
+                variants.append(("anti-diagonal u16, compiler-vectorised (oracle/ta_oracle_simd.c)", O.levenshtein_k_batch_antidiag))
             have_u8 = O.have_avx2()
             if have_u8:
                 got, hist = O.levenshtein_k_batch_ladder(c1a, c1b, k, costs, threads=cores, hist=True)
-                assert np.array_equal(got, ref), "the CPU restatements differ (AVX2 u8 anti-diagonal)"
-                lanes = [0, 32, 64, 128, 256, -1][int(np.argmax(hist))]
-                variants.append(("anti-diagonal AVX2, %d saturating u8 lanes (oracle/ta_oracle_avx2.c)" % lanes, O.levenshtein_k_batch_ladder))
-            gcups = lambda nu, sec: cells_unit * nu / sec / 1e9
+                if got is not None:
+                    assert np.array_equal(got, ref), "the CPU restatements differ (AVX2 u8 anti-diagonal)"
+                    lanes = [0, 32, 64, 128, 256, -1][int(np.argmax(hist))]
+                    variants.append(("anti-diagonal AVX2, %d saturating u8 lanes (oracle/ta_oracle_avx2.c)" % lanes, O.levenshtein_k_batch_ladder))
+            gcups = lambda nu, sec: extra["cells_total"] / units * nu / sec / 1e9
             res = {}
             for name, fn in variants:
                 s_all, _ = timed(lambda: fn(ca, cb, k, costs, threads=cores), min_s=2.5)
@@ -451,23 +549,28 @@ def main():
 
     if info.get("kernel") == 3:
         dtype = "u32 bit-vectors, 1 bit per band cell (reference width class u%d)" % info.get("cell_bits", 8)
+    if args.dist == "ragged":
+        evaluated_unit = None                              # per-pair geometry: only the credited figure is reported
     evaluated_value = value * evaluated_unit / cells_unit if evaluated_unit else None
     line = {
         "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
         "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
+        "prewarm_passes": n_ramp,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "units_total": all_units,
-                   "unit": unit_name, "credited_cells_per_unit": cells_unit, "evaluated_band_cells_per_unit": evaluated_unit,
+                   "unit": unit_name, "credited_cells_per_unit": all_cells / max(all_units, 1), "evaluated_band_cells_per_unit": evaluated_unit,
                    "parallelism": "independent units sharded x%d (%s), %s" % (
                        world, args.scaling, "no collective" if wl != "cfg5" or world == 1 else
                        "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
                    "backend": backend if world > 1 else None},
         "value_evaluated_cells": evaluated_value,
+        "end_to_end_ms": e2e_ms,          # host buffers in, answers out (pinned H2D + pass + D2H); never the headline
         "strong_scaling": strong_fig,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "device_ms_per_pass": dev_s * 1e3, "algorithmic_bytes_per_pass": bytes_unit * units,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_name": kernel_name,
+                     "device_ms_per_pass": dev_s * 1e3, "algorithmic_bytes_per_pass": extra["bytes_total"],
                      "valu_issue": valu_issue,
                      "note": "integer VALU-issue-bound path (DESIGN.md section 5); the HBM fraction is reported because north_star asks for it"},
         "cpu_baseline": cpu,

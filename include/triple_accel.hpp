@@ -107,6 +107,13 @@ inline std::vector<Match> levenshtein_search_simd_with_opts(bytes needle, bytes 
     check_(ta_levenshtein_search_simd_with_opts(needle.data(), needle.size(), haystack.data(), haystack.size(), k, (int)st, costs.raw(), anchored, &m, &n));
     return take_(m, n);
 }
+// `.next()` on the reference's lazy All-mode iterator (src/levenshtein.rs:2282-2420): the first match, found without scanning the rest
+inline std::optional<Match> levenshtein_search_first(bytes needle, bytes haystack, std::uint32_t k, const EditCosts &costs, bool anchored) {
+    ta_match m; int found = 0;
+    check_(ta_levenshtein_search_first(needle.data(), needle.size(), haystack.data(), haystack.size(), k, costs.raw(), anchored, &m, &found));
+    if (!found) return std::nullopt;
+    return Match{(std::size_t)m.start, (std::size_t)m.end, m.k};
+}
 inline std::vector<Match> levenshtein_search(bytes needle, bytes haystack) {             // :2508
     ta_match *m; std::size_t n;
     check_(ta_levenshtein_search(needle.data(), needle.size(), haystack.data(), haystack.size(), &m, &n));

@@ -89,6 +89,8 @@ const char *ta_status_str(int status);
 int ta_device_count(void);
 /* text of the last HIP error seen on this thread ("" if none) */
 const char *ta_last_error(void);
+/* the dominant kernel of the calling thread's last pass, as a profiler prints it (no "void ta::", no parameter list); "" before the first pass */
+const char *ta_last_kernel_name(void);
 
 /* The dispatcher arithmetic of levenshtein_simd_k_with_opts, src/levenshtein.rs:731-791:
  * clamped max_k, unit_k, and the cell width (8/16/32 bits) the reference would pick.
@@ -168,6 +170,19 @@ int ta_hamming_search(const uint8_t *needle, size_t needle_len, const uint8_t *h
 int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
                                       const uint8_t *haystack, size_t haystack_len,
                                       uint32_t k, int search_type, ta_match **out, size_t *n_out);
+/* The FIRST element of levenshtein_search_simd_with_opts(.., SearchType::All, ..): what `.next()` on the reference's lazy
+ * iterator returns (src/levenshtein.rs:2282-2420; tests/basic_tests.rs:628-632) without scanning the rest of the haystack.
+ * The haystack is searched window by window (64 KiB, then four times as much each time, each window behind needle_len +
+ * unit_k + 2 bytes of left context -- exact for every cost <= k) and the scan stops at the first window that holds a hit;
+ * the host form also uploads only that far.  *found = 0 when there is no match at all.  The bindings' All-mode iterators
+ * call this for their first element and run the full search only when a second one is asked for. */
+int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                                uint32_t k, const ta_edit_costs *costs, int anchored, ta_match *out, int *found);
+/* the same over a haystack shard resident in HBM (positions + base; the end == 0 match is the caller's, as with *_search_dev) */
+int ta_levenshtein_search_first_dev(const uint8_t *needle_host, size_t needle_len,
+                                    const uint8_t *haystack_dev, size_t haystack_len,
+                                    uint32_t k, const ta_edit_costs *costs, uint64_t base,
+                                    ta_match *out, int *found, void *stream);
 /* Limits of the host search forms: needles up to 65,535 bytes (TA_ERR_ARG beyond); the result list is bounded only by memory
  * (a pass that overflows its first hit buffer is repeated once with room for the count it reported). */
 void ta_free(void *p);

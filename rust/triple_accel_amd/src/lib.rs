@@ -46,6 +46,8 @@ mod ffi {
         pub fn ta_levenshtein_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                     search_type: c_int, costs: *const TaEditCosts, anchored: c_int,
                                                     out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
+        pub fn ta_levenshtein_search_first(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
+                                           costs: *const TaEditCosts, anchored: c_int, out: *mut TaMatch, found: *mut c_int) -> c_int;
         pub fn ta_hamming_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                 search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
@@ -188,9 +190,42 @@ pub mod levenshtein {
     /// src/levenshtein.rs:1516
     pub fn rdamerau_exp(a: &[u8], b: &[u8]) -> u32 { levenshtein_exp_with_opts(a, b, false, RDAMERAU_COSTS).0 }
 
+    /// All-mode result over a long haystack, lazily (the reference's iterator is lazy too, src/levenshtein.rs:2282-2420): the
+    /// first element comes from `ta_levenshtein_search_first`, which stops scanning (and uploading) at the first window that
+    /// holds a hit; the full search runs when a second element is asked for.  Element for element the eager sequence.
+    struct LazyAll<'a> { needle: &'a [u8], haystack: &'a [u8], k: u32, costs: EditCosts, anchored: bool, state: u8,
+                         rest: std::vec::IntoIter<Match> }
+    impl<'a> Iterator for LazyAll<'a> {
+        type Item = Match;
+        fn next(&mut self) -> Option<Match> {
+            if self.state == 0 {
+                self.state = 1;
+                let (mut m, mut found, c) = (TaMatch { start: 0, end: 0, k: 0, pad_: 0 }, 0 as c_int, self.costs.raw());
+                check(unsafe { ta_levenshtein_search_first(self.needle.as_ptr(), self.needle.len(), self.haystack.as_ptr(),
+                                                           self.haystack.len(), self.k, &c, self.anchored as c_int, &mut m, &mut found) });
+                if found == 0 { self.state = 2; return None; }
+                return Some(Match { start: m.start as usize, end: m.end as usize, k: m.k });
+            }
+            if self.state == 1 {
+                self.state = 2;
+                let (mut p, mut n, c) = (std::ptr::null_mut::<TaMatch>(), 0usize, self.costs.raw());
+                check(unsafe { ta_levenshtein_search_simd_with_opts(self.needle.as_ptr(), self.needle.len(), self.haystack.as_ptr(),
+                                                                    self.haystack.len(), self.k, 0, &c, self.anchored as c_int, &mut p, &mut n) });
+                self.rest = unsafe { take_matches(p, n) }.into_iter();
+                self.rest.next();                              // the element already handed out
+            }
+            self.rest.next()
+        }
+    }
+    const LAZY_SEARCH_FROM: usize = 1 << 20;
+
     /// src/levenshtein.rs:1911
     pub fn levenshtein_search_simd_with_opts<'a>(needle: &'a [u8], haystack: &'a [u8], k: u32, search_type: SearchType,
                                                   costs: EditCosts, anchored: bool) -> Box<dyn Iterator<Item = Match> + 'a> {
+        if search_type == SearchType::All && haystack.len() >= LAZY_SEARCH_FROM && !needle.is_empty() {
+            check(unsafe { ta_edit_costs_check_search(&costs.raw()) });    // the call's own panic stays eager (:1965)
+            return Box::new(LazyAll { needle, haystack, k, costs, anchored, state: 0, rest: Vec::new().into_iter() });
+        }
         let (mut p, mut n, c) = (std::ptr::null_mut::<TaMatch>(), 0usize, costs.raw());
         check(unsafe { ta_levenshtein_search_simd_with_opts(needle.as_ptr(), needle.len(), haystack.as_ptr(), haystack.len(), k,
                                                             (search_type == SearchType::Best) as c_int, &c, anchored as c_int,

@@ -23,6 +23,49 @@ cfg5)
   python scripts/measure_search_parts.py 2>&1 | tee $O/search_parts.txt
   trace cfg5 --workload cfg5 --steps 10 --warmup 2
   python scripts/pmc_collect.py --out $O/cfg5_pmc.json --workload cfg5 --sets sq1,sq2 --steps 5 2>&1 | tail -2 ;;
+ragged)
+  timeout 1200 python -m pytest tests/test_gpu_lev_batch.py tests/test_gpu_edge.py tests/test_gpu_search.py -x -q -k "ragged or length_order or generic or naive_contract" 2>&1 | tail -5 | tee $O/pytest_ragged.txt
+  for rep in 1 2; do
+    for wl in cfg2 cfg4 cfg2w cfg4w; do
+      echo "$wl fixed: $(run --workload $wl --steps 30 --warmup 5)"
+      echo "$wl ragged, length-ordered: $(run --workload $wl --dist ragged --steps 30 --warmup 5)"
+      echo "$wl ragged, batch order: $(TA_TUNING=1 TA_NO_LENGTH_ORDER=1 run --workload $wl --dist ragged --steps 30 --warmup 5)"
+    done
+  done 2>&1 | tee $O/ragged.txt
+  python bench.py --workload cfg2 --dist ragged --steps 30 --no-cpu > $O/bench_cfg2_ragged.json 2>$O/bench_cfg2_ragged.err; cut -c1-600 $O/bench_cfg2_ragged.json; tail -3 $O/bench_cfg2_ragged.err ;;
+band)
+  for wl in cfg2w cfg4w; do
+    python bench.py --workload $wl --steps 30 > $O/bench_$wl.json 2>$O/bench_$wl.err; cut -c1-400 $O/bench_$wl.json; tail -3 $O/bench_$wl.err
+    trace $wl --workload $wl --steps 10 --warmup 2
+    python scripts/pmc_collect.py --out $O/${wl}_pmc.json --workload $wl --sets sq1,sq2,fetch,write,rd_b --steps 5 2>&1 | tail -2
+  done ;;
+raggedtrace)
+  trace cfg2_ragged --workload cfg2 --dist ragged --steps 10 --warmup 2
+  trace cfg2w_ragged --workload cfg2w --dist ragged --steps 10 --warmup 2 ;;
+newtests)
+  timeout 1800 python -m pytest tests/test_gpu_lev_batch.py tests/test_gpu_edge.py tests/test_gpu_search.py tests/test_gpu_bench.py tests/test_gpu_threads.py -x -q 2>&1 | tail -8 | tee $O/pytest_new.txt ;;
+persist)
+  for rep in 1 2; do
+    for g in "" 1024 2048 4096 8192; do
+      echo "cfg2 persist=$g: $(TA_TUNING=1 TA_BITS_PERSIST=$g run --workload cfg2 --steps 50 --warmup 5)"
+      echo "cfg4 persist=$g: $(TA_TUNING=1 TA_BITS_PERSIST=$g run --workload cfg4 --steps 50 --warmup 5)"
+    done
+    for l in "" 40000 32000; do
+      echo "cfg2 ragged block_lds=$l: $(TA_TUNING=1 TA_BITS_BLOCK_LDS=$l run --workload cfg2 --dist ragged --steps 30 --warmup 5)"
+    done
+    echo "cfg1: $(run --workload cfg1 --steps 200 --warmup 20)"
+  done 2>&1 | tee $O/persist.txt ;;
+bits2)
+  timeout 1800 python -m pytest tests/test_gpu_lev_bits.py tests/test_gpu_lev_batch.py -x -q -k "two_pairs or ragged or length_order" 2>&1 | tail -5 | tee $O/pytest_bits2.txt
+  for rep in 1 2 3; do
+    echo "cfg4 one pair per lane: $(run --workload cfg4 --steps 50 --warmup 5)"
+    echo "cfg4 two pairs per lane: $(TA_TUNING=1 TA_BITS2=1 run --workload cfg4 --steps 50 --warmup 5)"
+    echo "cfg4 two pairs per lane, 2 waves per block: $(TA_TUNING=1 TA_BITS2=1 TA_BITS_WPB=2 run --workload cfg4 --steps 50 --warmup 5)"
+    echo "cfg4 two pairs per lane, 4 waves per block: $(TA_TUNING=1 TA_BITS2=1 TA_BITS_WPB=4 run --workload cfg4 --steps 50 --warmup 5)"
+    echo "cfg2 ragged: $(run --workload cfg2 --dist ragged --steps 30 --warmup 5)"
+  done 2>&1 | tee $O/bits2.txt
+  TA_TUNING=1 TA_BITS2=1 trace cfg4_bits2 --workload cfg4 --steps 10 --warmup 2
+  TA_TUNING=1 TA_BITS2=1 python scripts/pmc_collect.py --out $O/cfg4_bits2_pmc.json --workload cfg4 --sets sq1,sq2,rd_b,write --steps 5 2>&1 | tail -2 ;;
 *) echo "unknown part $part" ;;
 esac
 done

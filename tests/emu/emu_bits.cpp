@@ -98,17 +98,8 @@ extern "C" int emu_lev_bits2(const uint8_t *a_blob, uint64_t a_len, const uint8_
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     const uint32_t waves = (n + 127) / 128;
     for (uint32_t w = 0; w < waves; w++) {
-        switch (pl.NA * 2 + (has_t ? 1 : 0)) {
-            case 2: LevBits2<EmuWave, 1, false>::run(P, w, lds); break;
-            case 3: LevBits2<EmuWave, 1, true>::run(P, w, lds); break;
-            case 4: LevBits2<EmuWave, 2, false>::run(P, w, lds); break;
-            case 5: LevBits2<EmuWave, 2, true>::run(P, w, lds); break;
-            case 6: LevBits2<EmuWave, 3, false>::run(P, w, lds); break;
-            case 7: LevBits2<EmuWave, 3, true>::run(P, w, lds); break;
-            case 8: LevBits2<EmuWave, 4, false>::run(P, w, lds); break;
-            case 9: LevBits2<EmuWave, 4, true>::run(P, w, lds); break;
-            default: free(lds); return 2;
-        }
+        if (has_t) LevBits2<EmuWave, true>::run(P, w, lds);
+        else LevBits2<EmuWave, false>::run(P, w, lds);
     }
     free(lds);
     return 0;

@@ -168,6 +168,20 @@ struct EmuWave {
     static U32 splat_byte_n(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) * 0x01010101u; return r; }
     template <int N>
     static U32 slide_in_byte(const U32 &hi, const U32 &lo) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (lo.v[i] >> 8) | (((hi.v[i] >> (8 * N)) & 0xffu) << 24); return r; }
+    template <uint32_t SEL>
+    static U32 perm(const U32 &hi, const U32 &lo) {            // selectors 0..7 (and 0x0C = the constant 0x00): all the bodies use
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            const uint64_t src = ((uint64_t)hi.v[i] << 32) | lo.v[i];
+            uint32_t o = 0;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t s = (SEL >> (8 * k)) & 0xffu;
+                o |= (s < 8u ? (uint32_t)((src >> (8 * s)) & 0xffu) : 0u) << (8 * k);
+            }
+            r.v[i] = o;
+        }
+        return r;
+    }
     static U32 and_or(const U32 &a, uint32_t m, const U32 &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m) | c.v[i]; return r; }
     template <int N>
     static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }

@@ -6,14 +6,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "emu", "libta_emu.so")
+_SAN = os.environ.get("TA_SANITIZED") == "1"        # scripts/run_sanitized.sh: the ASan + UBSan build
+_SO = os.path.join(_HERE, "emu", "libta_emu_san.so" if _SAN else "libta_emu.so")
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-j", str(os.cpu_count() or 4), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-j", str(os.cpu_count() or 4), "-s"] + (["SAN=1"] if _SAN else []))
         L = C.CDLL(_SO)
         L.emu_lev_band.restype = C.c_int
         L.emu_lev_band.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "libta_oracle.so")
+_SAN = os.environ.get("TA_SANITIZED") == "1"        # scripts/run_sanitized.sh: the ASan + UBSan builds (python needs LD_PRELOAD=libasan)
+_SO = os.path.join(_ROOT, "oracle", "libta_oracle_san.so" if _SAN else "libta_oracle.so")
 
 NONE = 0xFFFFFFFF
 ALL, BEST = 0, 1
@@ -31,7 +32,7 @@ class Edit(C.Structure):
 def build(force=False):
     src = os.path.join(_ROOT, "oracle", "ta_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"] + (["SAN=1"] if _SAN else []))
     return _SO
 
 

@@ -74,3 +74,48 @@ def test_sharded_search_equals_monolithic(world, costs):
         for r in range(world):
             key = 0 if st_name == "All" else 1
             assert res[r][key] == want, (st_name, r)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_search_world_8():
+    """The configuration's world size: 8 ranks, uneven cuts, two consecutive shards shorter than the halo followed by an
+    EMPTY one, a planted match spanning three shards, and the globally best match (k = 0) on the last rank only."""
+    import datagen as Dg
+    import oracle_lib as O
+    g = Dg.rng(808)
+    needle = Dg.rand_str(g, 12)
+    k, costs = 4, (1, 1, 0, None)                      # halo = 12 + 4 + 2 = 18
+    hay = bytearray(g.integers(97, 123, size=4000, dtype=np.uint8).tobytes())
+
+    def plant(pos, subs):
+        m = bytearray(needle)
+        for s in subs:
+            m[s] = 32
+        hay[pos:pos + len(m)] = m
+    plant(100, [3]); plant(698, [1, 7]); plant(1490, [0]); plant(2195, [5, 6]); plant(3090, [2]); plant(3500, [])
+    hay = bytes(hay)
+    cuts = [0, 700, 705, 712, 712, 1500, 2200, 3100, 4000]      # shards of 700, 5, 7, 0, 788, 700, 900, 900 bytes
+    res = _run(8, needle, hay, k, costs, cuts, _free_port())
+    want_all = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, False)
+    want_best = O.levenshtein_search_naive_with_opts(needle, hay, k, O.BEST, costs, False)
+    assert any(s < 700 and e > 705 for s, e, _ in want_all)     # a match that starts in shard 0 and ends in shard 2
+    assert [m for m in want_best] == [(3500, 3512, 0)]
+    for r in range(8):
+        assert res[r][0] == want_all, r
+        assert res[r][1] == want_best, r
+
+
+def test_shard_range_covers_everything():
+    from triple_accel_amd import dist as D
+    for n in (0, 1, 7, 8, 9, 1000, 1 << 30):
+        for world in (1, 2, 3, 8, 16):
+            cuts = [D.shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1

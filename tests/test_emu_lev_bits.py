@@ -260,7 +260,9 @@ def test_emu_bits_fixed_length_nul_and_high_bytes():
 # ---- two pairs per lane (lev_bits2_body.h): narrow bands of fixed-length batches
 @pytest.mark.parametrize("la,lb,k,trans", [(128, 128, 8, True), (128, 128, 8, False), (64, 64, 0, False), (64, 64, 1, True), (100, 97, 5, True),
                                            (100, 104, 12, False), (200, 200, 14, False), (200, 193, 12, True), (30, 30, 3, False),
-                                           (17, 19, 2, True), (1, 1, 1, False), (300, 300, 4, True), (70, 70, 13, False), (129, 120, 10, True)])
+                                           (17, 19, 2, True), (1, 1, 1, False), (300, 300, 4, True), (70, 70, 13, False), (129, 120, 10, True),
+                                           (1000, 1000, 7, True), (513, 520, 10, False), (64, 64, 14, False), (65, 60, 12, True), (16, 16, 14, False),
+                                           (2, 9, 12, True), (257, 255, 3, False)])
 def test_emu_bits2_two_pairs_per_lane(la, lb, k, trans):
     """n = 300: two full 128-pair wavefronts and one with 44 pairs (pair B absent in most of its lanes)."""
     a, b = _fixed_batch(la * 11 + lb + k, 300, la, lb, k, swaps=trans)

@@ -45,3 +45,37 @@ def test_two_ranks_search_is_one_haystack():
     r = _bench("--gpus", "2", "--workload", "cfg5", "--pairs", "8")
     assert r["n_gpus"] == 2 and r["config"]["units_total"] == 2 * (8 << 20)
     assert "all-gathered" in r["config"]["parallelism"]
+
+
+def test_eight_ranks_on_one_gpu():
+    """The configuration's world size through bench.py's own launcher: 8 ranks sharing the one GPU of the test box (gloo for the
+    control plane), pair batches under both scalings and the sharded search."""
+    w = _bench("--gpus", "8", "--pairs", "8000")
+    assert w["n_gpus"] == 8 and w["config"]["units_total"] == 64000 and w["strong_scaling"]["units_total"] == 8000
+    r = _bench("--gpus", "8", "--workload", "cfg5", "--pairs", "4")
+    assert r["n_gpus"] == 8 and r["config"]["units_total"] == 8 * (4 << 20)
+    assert "all-gathered" in r["config"]["parallelism"]
+
+
+def test_one_rank_under_the_launcher_equals_plain_run():
+    """The N = 1 path of the multi-rank code (bench.py under torch.distributed.run with one rank) reports the figure of the
+    plain run (+- a few percent: the same kernels on the same data)."""
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    flags = ["--steps", "20", "--warmup", "3", "--no-cpu", "--pairs", "500000", "--prewarm-ms", "300"]
+    plain = _bench(*flags)                            # (argparse keeps the last --steps / --warmup)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", *flags],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["config"]["units_total"] == plain["config"]["units_total"]
+    assert abs(line["roofline"]["device_ms_per_pass"] / plain["roofline"]["device_ms_per_pass"] - 1.0) < 0.05
+
+
+def test_line_carries_the_round3_fields():
+    r = _bench("--pairs", "50000", "--dist", "ragged")
+    assert r["end_to_end_ms"] > r["ms_per_step"] and r["prewarm_passes"] >= 1
+    assert r["roofline"]["kernel_name"].startswith("lev_bits") and "traffic_source" in r["roofline"]
+    assert 2000 < r["config"]["credited_cells_per_unit"] < 15584

@@ -99,14 +99,18 @@ def test_generic_items_beyond_256_symbols_and_buffer_inputs():
     g = Dg.rng(77)
     for trial in range(8):
         n = int(g.integers(300, 600))
-        a = [int(v) for v in g.integers(0, 1 << 20, size=n)]            # ~n distinct items
-        b = list(a)
-        for _ in range(int(g.integers(0, 40))):                          # edits with items from a disjoint range
+        # ~n distinct items in a; b shares the items of a 150-symbol pool with it and replaces the rest with items of its own:
+        # far more than 256 distinct items in the pair, at most 150 of them common to both sides
+        pool = [int(v) for v in g.integers(0, 150, size=n)]
+        a = [pool[i] if i % 3 else (1 << 20) + i for i in range(n)]
+        b = [pool[i] if i % 3 else (1 << 21) + i for i in range(n)]
+        for _ in range(int(g.integers(0, 12))):
             p = int(g.integers(0, len(b)))
             r = int(g.integers(0, 3))
-            if r == 0: b[p] = (1 << 21) + p
-            elif r == 1: b.insert(p, (1 << 22) + p)
+            if r == 0: b[p] = (1 << 22) + p
+            elif r == 1: b.insert(p, pool[p % n])
             else: del b[p]
+        assert len(set(a) | set(b)) > 300
         # reference value: a plain two-row DP over the items themselves
         prev = list(range(len(a) + 1))
         for j in range(1, len(b) + 1):
@@ -115,8 +119,11 @@ def test_generic_items_beyond_256_symbols_and_buffer_inputs():
                 cur[i] = min(prev[i - 1] + (a[i - 1] != b[j - 1]), prev[i] + 1, cur[i - 1] + 1)
             prev = cur
         assert T.levenshtein_naive(a, b) == prev[len(a)]
-        assert T.levenshtein_naive_k_with_opts(a, b, 100, False, T.LEVENSHTEIN_COSTS)[0] == prev[len(a)]      # (<= 40 edits)
-    assert T.levenstein_naive_str("".join(chr(0x400 + i) for i in range(600)), "".join(chr(0x400 + i) for i in range(1, 601))) == 2
+        assert T.levenshtein_naive_k_with_opts(a, b, 1000, False, T.LEVENSHTEIN_COSTS)[0] == prev[len(a)]
+    with pytest.raises(NotImplementedError):                              # more than 254 distinct items COMMON to both sides
+        T.levenshtein_naive(list(range(400)), list(range(400)))
+    x = "".join(chr(0x400 + i) for i in range(200))
+    assert T.levenstein_naive_str(x + "".join(chr(0x1000 + i) for i in range(300)), x[1:] + "".join(chr(0x2000 + i) for i in range(300))) == 301
     assert T.hamming(array.array("B", [1, 2, 3]), (ctypes.c_uint8 * 3)(1, 9, 3)) == 1
     with pytest.raises(TypeError):
         T.hamming(5, b"abcde")

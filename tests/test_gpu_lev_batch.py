@@ -255,3 +255,44 @@ def test_u32_width_class_long_strings():
     want = O.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, False, costs)
     assert r[0] == want[0] and want[0] > 65535
     assert T.last_launch_info()["cell_bits"] == 32
+
+
+def _ragged_csr(seed, n, lo, hi, spread, mutated_share=0.5, kmut=24):
+    """CSR batch with lengths uniform on lo..hi, b within +-spread of a; half of the pairs mutated copies, half random."""
+    g = Dg.rng(seed)
+    la = g.integers(lo, hi + 1, size=n)
+    a_list, b_list = [], []
+    for i in range(n):
+        x = Dg.rand_str(g, int(la[i]))
+        if g.random() < mutated_share:
+            y = Dg.mutate(g, x, kmut)
+        else:
+            y = Dg.rand_str(g, int(np.clip(la[i] + g.integers(-spread, spread + 1), 0, hi)))
+        a_list.append(x); b_list.append(y)
+    return a_list, b_list
+
+
+@pytest.mark.parametrize("costs,k", [((1, 1, 0, None), 32), ((1, 1, 0, 1), 8), ((2, 3, 1, None), 32), ((2, 2, 1, 3), 8)])
+def test_ragged_100k_length_ordered(costs, k, monkeypatch):
+    """Ragged CSR batch (lengths 32..256): the pairs are taken in length order on the device -- same answers as
+    the oracle, and as the batch-order pass."""
+    a, b = _ragged_csr(0x7A60 + k, 100_000, 32, 256, 40 if k == 32 else 6, kmut=24 if k == 32 else 5)
+    want = oracle_k(a, b, k, costs)
+    got = gpu_k(a, b, k, costs)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert (want != 0xFFFFFFFF).mean() > 0.01 and (want == 0xFFFFFFFF).mean() > 0.1        # both answers occur
+    monkeypatch.setenv("TA_NO_LENGTH_ORDER", "1")
+    assert np.array_equal(gpu_k(a, b, k, costs), want)
+
+
+def test_length_order_edge_shapes():
+    """Length ordering on batches with empty strings, one giant string among short ones, and all pairs outside the band."""
+    g = Dg.rng(5)
+    n = 9000
+    a = [Dg.rand_str(g, int(g.integers(0, 40))) for _ in range(n)]
+    b = [Dg.mutate(g, x, 3) if i % 3 else b"" for i, x in enumerate(a)]
+    a[1234] = Dg.rand_str(g, 70_000); b[1234] = Dg.mutate(g, a[1234], 5)
+    for k in (0, 4, 100000):
+        assert np.array_equal(gpu_k(a, b, k, (1, 1, 0, None)), oracle_k(a, b, k, (1, 1, 0, None))), k
+    a2 = [Dg.rand_str(g, 10) for _ in range(5000)]; b2 = [Dg.rand_str(g, 30) for _ in range(5000)]
+    assert np.array_equal(gpu_k(a2, b2, 5, (1, 1, 0, 1)), oracle_k(a2, b2, 5, (1, 1, 0, 1)))

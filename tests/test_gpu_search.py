@@ -344,3 +344,34 @@ def test_best_pass_with_more_best_hits_than_the_report_holds():
     assert len(rows) == 1500 and (rows[:, 2] == 0).all() and (np.diff(rows[:, 1]) > 0).all()
     got = TD.fold_best([tuple(int(v) for v in r) for r in rows], 6, True)
     assert got == O.levenshtein_search_naive_with_opts(needle, hay, 6, O.BEST, (1, 1, 0, None), False)
+
+
+def test_search_first_is_the_head_of_the_all_mode_list():
+    """ta_levenshtein_search_first = `.next()` on the reference's lazy All-mode iterator (src/levenshtein.rs:2282-2420,
+    tests/basic_tests.rs:628-632): the first element of the full list -- whatever window it falls into -- or None."""
+    import triple_accel_amd as T
+    g = Dg.rng(4242)
+    assert T.levenshtein_search_first(b"tst", b"testing 123 tasting!", 1) == T.Match(0, 4, 1)          # the KAT's haystack
+    assert T.levenshtein_search_first(b"abc", b"", 5) == T.Match(0, 0, 3)                              # end == 0 match first
+    assert T.levenshtein_search_first(b"abc", b"xyzxyz", 0) is None
+    assert T.levenshtein_search_first(b"", b"abc", 1) is None and T.levenshtein_search_first(b"", b"abc", 1, anchored=True) == T.Match(0, 0, 0)
+    for trial in range(12):
+        n = int(g.integers(3, 40))
+        needle = Dg.rand_str(g, n)
+        k = int(g.integers(0, max(1, n // 3) + 1))
+        size = int(g.choice([300, 70_000, 400_000, 3_000_000]))
+        hay = bytearray(g.integers(33, 127, size=size, dtype=np.uint8).tobytes())
+        where = [None, 10, 65_530, 66_000, 330_000, size - n - 3][trial % 6]                           # window edges of 64 KiB / 256 KiB
+        if where is not None and where + n + 5 < size:
+            hay[where:where + n] = Dg.mutate(g, needle, k)[:n].ljust(n, b"x")
+        hay = bytes(hay)
+        costs = [T.LEVENSHTEIN_COSTS, T.RDAMERAU_COSTS, T.EditCosts(2, 1, 1, None)][trial % 3]
+        want = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, (costs.mismatch_cost, costs.gap_cost, costs.start_gap_cost, costs.transpose_cost), False)
+        got = T.levenshtein_search_first(needle, hay, k, costs)
+        assert (tuple(got) if got else None) == (want[0] if want else None), (trial, n, k, size, where)
+        # the lazy All-mode iterator hands out the same sequence as the eager list
+        it = T.levenshtein_search_simd_with_opts(needle, hay, k, T.SearchType.All, costs, False)
+        assert [tuple(m) for m in it] == want
+    # a dense result (k >= needle_len: every position matches) still has a first element
+    hay = bytes(g.integers(33, 127, size=2_000_000, dtype=np.uint8).tobytes())
+    assert tuple(T.levenshtein_search_first(b"abcd", hay, 3)) == O.levenshtein_search_naive_with_opts(b"abcd", hay[:5000], 3, O.ALL, (1, 1, 0, None), False)[0]

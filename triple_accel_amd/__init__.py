@@ -61,10 +61,19 @@ LEVENSHTEIN_COSTS = EditCosts(1, 1, 0, None)   # src/levenshtein.rs:76-81
 RDAMERAU_COSTS = EditCosts(1, 1, 0, 1)         # src/levenshtein.rs:84-89
 
 
+_costs_cache = {}
+
+
 def _costs(c):
     if isinstance(c, EditCosts):
         return c
-    return EditCosts(*c)
+    c = tuple(c)
+    e = _costs_cache.get(c)
+    if e is None:                          # validated once per distinct tuple
+        if len(_costs_cache) > 256:
+            _costs_cache.clear()
+        e = _costs_cache[c] = EditCosts(*c)
+    return e
 
 
 def _raise(rc):
@@ -211,9 +220,54 @@ def levenshtein_exp_with_opts(a, b, trace_on, costs):
     return (d, None)
 
 
+def levenshtein_search_first(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchored=False):
+    """The first element of the All-mode result -- `.next()` on the reference's lazy iterator (src/levenshtein.rs:2282-2420;
+    tests/basic_tests.rs:628-632) -- or None; scans (and uploads) the haystack only as far as that match."""
+    needle, haystack = _b(needle), _b(haystack)
+    m, found = _n.MatchC(), _C.c_int()
+    _raise(_n.lib().ta_levenshtein_search_first(needle, len(needle), haystack, len(haystack), _k(k), _C.byref(_costs(costs)._c()),
+                                               int(bool(anchored)), _C.byref(m), _C.byref(found)))
+    return Match(int(m.start), int(m.end), int(m.k)) if found.value else None
+
+
+_LAZY_SEARCH_FROM = 1 << 20     # All-mode searches over haystacks this long hand their first match out before scanning the rest
+
+
+class _LazyMatches:
+    """All-mode result whose first element comes from ta_levenshtein_search_first; the full search runs when a second one is
+    asked for (the same sequence as the eager list, element for element)."""
+
+    def __init__(self, needle, haystack, k, costs, anchored):
+        self._args, self._state, self._rest = (needle, haystack, k, costs, anchored), 0, None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        needle, haystack, k, costs, anchored = self._args
+        if self._state == 0:
+            self._state = 1
+            first = levenshtein_search_first(needle, haystack, k, costs, anchored)
+            if first is None:
+                self._state = 2
+                self._rest = iter(())
+                raise StopIteration
+            return first
+        if self._state == 1:
+            self._state = 2
+            self._rest = _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
+                                  SearchType.All, _C.byref(costs._c()), int(bool(anchored)))
+            next(self._rest)                                  # the element already handed out
+        return next(self._rest)
+
+
 def levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored):
     """src/levenshtein.rs:1911"""
     needle, haystack = _b(needle), _b(haystack)
+    if search_type == SearchType.All and len(haystack) >= _LAZY_SEARCH_FROM and len(needle):
+        cc = _costs(costs)
+        _raise(_n.lib().ta_edit_costs_check_search(_C.byref(cc._c())))     # the panics of the call itself stay eager (:1965)
+        return _LazyMatches(needle, haystack, _k(k), cc, anchored)
     return _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), _k(k),
                     search_type, _C.byref(_costs(costs)._c()), int(bool(anchored)))
 
@@ -238,6 +292,11 @@ def last_launch_info():
     li = _n.LaunchInfoC()
     _n.check(_n.lib().ta_last_launch_info(_C.byref(li)))
     return {n: int(getattr(li, n)) for n, _ in _n.LaunchInfoC._fields_}
+
+
+def last_kernel_name():
+    """The dominant kernel of this thread's last pass, as a profiler prints it (without `void ta::` and the parameter list)."""
+    return _n.lib().ta_last_kernel_name().decode()
 
 
 def device_count():

@@ -16,7 +16,7 @@ TA_OK, TA_ERR_LEN_MISMATCH, TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS, TA_ERR_HIP, TA_E
 # every symbol include/triple_accel_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ta_levenshtein_costs", "ta_rdamerau_costs", "ta_edit_costs_new", "ta_edit_costs_check_search",
-    "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_levenshtein_select",
+    "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_last_kernel_name", "ta_levenshtein_search_first", "ta_levenshtein_search_first_dev", "ta_levenshtein_select",
     "ta_last_launch_info", "ta_hamming", "ta_levenshtein_simd_k_with_opts", "ta_levenshtein_trace",
     "ta_levenshtein_exp_trace", "ta_levenshtein_simd_k",
     "ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_levenshtein_exp_with_opts", "ta_rdamerau_exp",
@@ -96,6 +96,7 @@ def lib():
     sig("ta_status_str", C.c_char_p, [i32])
     sig("ta_device_count", i32, [])
     sig("ta_last_error", C.c_char_p, [])
+    sig("ta_last_kernel_name", C.c_char_p, [])
     sig("ta_levenshtein_costs", EditCostsC, [])
     sig("ta_rdamerau_costs", EditCostsC, [])
     sig("ta_edit_costs_new", i32, [C.c_uint8, C.c_uint8, C.c_uint8, i32, C.c_uint8, cp])
@@ -113,6 +114,8 @@ def lib():
     sig("ta_levenshtein_exp_with_opts", i32, [u8p, sz, u8p, sz, i32, cp, u32p])
     sig("ta_levenshtein_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, cp, i32, mpp, szp])
     sig("ta_levenshtein_search", i32, [u8p, sz, u8p, sz, mpp, szp])
+    sig("ta_levenshtein_search_first", i32, [u8p, sz, u8p, sz, u32, cp, i32, C.POINTER(MatchC), C.POINTER(C.c_int)])
+    sig("ta_levenshtein_search_first_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, C.c_uint64, C.POINTER(MatchC), C.POINTER(C.c_int), C.c_void_p])
     sig("ta_hamming_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])
     sig("ta_hamming_search", i32, [u8p, sz, u8p, sz, mpp, szp])
     sig("ta_hamming_search_naive_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])

@@ -45,11 +45,26 @@ class Strings:
         return cls(blob, None, stride=length, length=length, n=n)
 
     def _c(self):
-        return _n.StringsC(self.blob.data_ptr(), 0 if self.off is None else self.off.data_ptr(),
-                           self.stride, self.length, self.max_len)
+        """the C view (built once: the tensors of a batch side do not change)"""
+        c = self.__dict__.get("_cview")
+        if c is None:
+            c = self._cview = _n.StringsC(self.blob.data_ptr(), 0 if self.off is None else self.off.data_ptr(),
+                                          self.stride, self.length, self.max_len)
+            self._cref = _C.byref(c)
+        return c
+
+    def _ref(self):
+        self._c()
+        return self._cref
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream():
+    """the current stream's handle (the raw getter skips building a torch.cuda.Stream object per call)"""
+    if _raw_stream is not None:
+        return _C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return _C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -61,8 +76,10 @@ def levenshtein_k_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, out=
     """out[i] = levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) as int32 (-1 == None)."""
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out
-    ca, cb, cc = a._c(), b._c(), _costs(costs)._c()
-    _raise(_n.lib().ta_levenshtein_k_batch(_C.byref(ca), _C.byref(cb), a.n, k, _C.byref(cc), out.data_ptr(), _stream()))
+    cc = _costs(costs)._c()
+    rc = _n.lib().ta_levenshtein_k_batch(a._ref(), b._ref(), a.n, k, _C.byref(cc), out.data_ptr(), _stream())
+    if rc:
+        _raise(rc)
     return out
 
 
@@ -77,8 +94,9 @@ def levenshtein_exp_batch(a: Strings, b: Strings, costs=LEVENSHTEIN_COSTS, out=N
 def hamming_batch(a: Strings, b: Strings, out=None):
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out
-    ca, cb = a._c(), b._c()
-    _raise(_n.lib().ta_hamming_batch(_C.byref(ca), _C.byref(cb), a.n, out.data_ptr(), _stream()))
+    rc = _n.lib().ta_hamming_batch(a._ref(), b._ref(), a.n, out.data_ptr(), _stream())
+    if rc:
+        _raise(rc)
     return out
 
 

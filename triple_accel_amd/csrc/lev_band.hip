@@ -3,6 +3,7 @@
 
 #include "lev_band_body.h"
 #include "lev_plan.h"
+#include "ta_internal.h"
 
 namespace ta {
 
@@ -34,6 +35,7 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
+    set_last_kernel_name("lev_band_kernel<%d, %s, %d>", pl.D, affine ? "true" : "false", trans);
     switch (pl.D) {
 #define TA_CASE(d) case d: return launch_d<d>(P, affine, trans, grid, lds, s);
         TA_CASE(2) TA_CASE(4) TA_CASE(6) TA_CASE(8) TA_CASE(10) TA_CASE(12) TA_CASE(16) TA_CASE(18) TA_CASE(20)

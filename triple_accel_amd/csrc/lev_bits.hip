@@ -15,51 +15,53 @@ constexpr int BITS_WAVES_PER_BLOCK = 4;
 template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, NA, TRANS, STATIC>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
+        LevBits<DevWave, NA, TRANS, STATIC>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 // line-form launches (fixed-length batches of strings longer than one line)
 template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_line_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, NA, TRANS, STATIC, true>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
+        LevBits<DevWave, NA, TRANS, STATIC, true>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 // stride-8 form (bands of up to 33 diagonals), either fetch form
 template <bool TRANS, bool LINE>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBits<DevWave, 8, TRANS, false, LINE, true>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
+        LevBits<DevWave, 8, TRANS, false, LINE, true>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
-template <int NA, bool TRANS>
+template <bool TRANS>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBits2<DevWave, NA, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    LevBits2<DevWave, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
-// two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront, 4 wavefronts per block, two blocks per CU
+// two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront, one wavefront per block (fine grains at the launch's tail)
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
-    const uint32_t waves = (P.n + 127u) / 128u, wpb = BITS_WAVES_PER_BLOCK, grid = (waves + wpb - 1) / wpb;
+    uint32_t wpb = 1;
+    if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
+    const uint32_t waves = (P.n + 127u) / 128u, grid = (waves + wpb - 1) / wpb;
     const size_t lds = (size_t)pl.lds_per_wave * wpb;
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
     dim3 g(grid), b(64 * wpb);
-    switch (pl.NA) {
-#define TA_CASE2(n) case n: { auto kt = lev_bits2_kernel<n, true>; auto kf = lev_bits2_kernel<n, false>; \
-        hipError_t e = hipFuncSetAttribute((const void *)(trans ? kt : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e; \
-        if (trans) hipLaunchKernelGGL(kt, g, b, lds, s, P); else hipLaunchKernelGGL(kf, g, b, lds, s, P); \
-        return hipGetLastError(); }
-        TA_CASE2(1) TA_CASE2(2) TA_CASE2(3) TA_CASE2(4)
-#undef TA_CASE2
-        default: return hipErrorInvalidValue;
-    }
+    set_last_kernel_name("lev_bits2_kernel<%s>", trans ? "true" : "false");
+    if (trans) hipLaunchKernelGGL(lev_bits2_kernel<true>, g, b, lds, s, P);
+    else hipLaunchKernelGGL(lev_bits2_kernel<false>, g, b, lds, s, P);
+    return hipGetLastError();
 }
 
 template <bool TRANS, bool WIDE>
@@ -73,6 +75,7 @@ hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipS
     const size_t lds = (LEV_ONE_PAD_LO + (size_t)max_len + LEV_ONE_PAD_HI + 15u) & ~(size_t)15;
     if (lds_out) *lds_out = (uint32_t)lds;
     const bool wide = P.u + 1u + (trans ? 2u : 0u) > 32u;
+    set_last_kernel_name("lev_one_kernel<%s, %s>", trans ? "true" : "false", wide ? "true" : "false");
     if (trans) { if (wide) hipLaunchKernelGGL((lev_one_kernel<true, true>), dim3(1), dim3(64), lds, s, P); else hipLaunchKernelGGL((lev_one_kernel<true, false>), dim3(1), dim3(64), lds, s, P); }
     else { if (wide) hipLaunchKernelGGL((lev_one_kernel<false, true>), dim3(1), dim3(64), lds, s, P); else hipLaunchKernelGGL((lev_one_kernel<false, false>), dim3(1), dim3(64), lds, s, P); }
     return hipGetLastError();
@@ -107,17 +110,22 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     uint32_t wpb = P.lds_per_wave * 16u <= 160u * 1024u ? BITS_WAVES_PER_BLOCK : 1u;
     if (pl.s8 && line_form) wpb = 1u;          // finer grains at the launch's tail: 0.3138-0.3147 against 0.3159-0.3171 ms on cfg2
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
-    const uint32_t grid = (waves + wpb - 1) / wpb;
+    uint32_t grid = (waves + wpb - 1) / wpb;
+    if (const char *e = env_str("TA_BITS_PERSIST")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < grid) grid = (uint32_t)v; }   // A/B: persistent grid
     // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
     // (12 waves) per CU instead of four -- a quarter fewer pairs in flight lets the 4 MB L2 keep more lines until their second
     // half is read.  Fixed-length batches (line form: every line requested once) run the four blocks the LDS allows: 16 waves
     // per CU measured 8 % faster than 12 once the refetches were gone (profiles/r02/ab_band_kernel.md).
     size_t lds = (size_t)P.lds_per_wave * wpb;
-    if (!line_form && wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u) lds = 53000u;
+    // (a length-ordered CSR batch -- P.subset set by ta_levenshtein_k_batch -- runs the four blocks: 0.265 against 0.281 ms on the
+    // ragged cfg2 batch, profiles/r03/ab_band_kernel.md)
+    if (!line_form && wpb == BITS_WAVES_PER_BLOCK && lds < 53000u && max_len > 128u && !(P.subset && (P.a.off || P.b.off))) lds = 53000u;
     if (const char *e = env_str("TA_BITS_BLOCK_LDS")) { const size_t want = (size_t)atoi(e); if (want >= (size_t)P.lds_per_wave * wpb && want <= 160u * 1024u) lds = want; }
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
+    if (pl.s8) set_last_kernel_name("lev_bits_s8_kernel<%s, %s>", trans ? "true" : "false", line_form ? "true" : "false");
+    else set_last_kernel_name("%s<%d, %s, %s>", line_form ? "lev_bits_line_kernel" : "lev_bits_kernel", pl.NA, trans ? "true" : "false", pl.stat ? "true" : "false");
     if (pl.s8) {
         dim3 g(grid), b(64 * wpb);
         if (trans) { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<true, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<true, false>), g, b, lds, s, P); }

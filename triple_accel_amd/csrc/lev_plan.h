@@ -138,7 +138,7 @@ static inline LevBitsPlan lev_bits_make_plan(uint32_t k, uint32_t mc, uint32_t g
 // rows) is at most 15 diagonals wide, and big enough that halving the number of wavefronts still leaves >= 2 per SIMD
 struct LevBits2Plan {
     bool ok;
-    int NA;                  // packed dwords of `a` under each pair's window (window = min(4 NA, 15) bits)
+    int NA;                  // window registers (8: the stride-8 layout, 15 diagonals per pair)
     uint32_t u, Tw, lds_per_wave;
 };
 constexpr uint32_t LEV_BITS2_MIN_PAIRS = 262144;     // 128 pairs per wavefront x 2 wavefronts x 1024 SIMDs
@@ -149,9 +149,9 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
     const uint64_t w = (uint64_t)p.u + 1u + (has_t ? 2u : 0u);
     p.ok = mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1) && fixed_length && w <= 15 && max_len <= 65000 && max_len >= 1 &&
            pairs >= LEV_BITS2_MIN_PAIRS;
-    p.NA = (int)((w + 3) / 4);
-    p.Tw = (p.u + (has_t ? 1u : 0u) + 63u) & ~63u;
-    p.lds_per_wave = 128u * (84u + 68u);
+    p.NA = 8;                                                  // the stride-8 window: 8 registers of 2 + 2 bytes
+    p.Tw = (p.u + (has_t ? 1u : 0u) + 2u + 63u) & ~63u;        // (the stream of `a` runs two iterations ahead of the window's last row)
+    p.lds_per_wave = 128u * (52u + 36u);                       // rings of 3 + 2 sixteen-byte pieces per pair (+ wrap copies)
     return p;
 }
 

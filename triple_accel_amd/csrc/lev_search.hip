@@ -71,6 +71,7 @@ static hipError_t launch_n(const SearchParams &P, bool trans, bool packed, uint3
 // packed: cost and length in one VGPR (see lev_search_tile_packed for the validity conditions, checked by the caller)
 hipError_t lev_search_launch(const SearchParams &P, bool packed, bool trans, hipStream_t s) {
     if (P.hay_len == 0) return hipSuccess;
+    set_last_kernel_name("lev_search%s_kernel", P.needle_len <= 32 ? "" : "_mem");
     const uint64_t tiles = (P.hay_len + P.tile - 1) / P.tile;
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
     const uint32_t n = P.needle_len;
@@ -258,6 +259,7 @@ hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, 
     if (P.hay_len == 0) return hipSuccess;
     const uint64_t tiles = (P.hay_len + P.tile - 1) / P.tile;
     const uint32_t grid = (uint32_t)((tiles + 255) / 256);
+    set_last_kernel_name("lev_filter_kernel%s", P.needle_len <= 32 ? "" : "_n");
     switch ((P.needle_len + 31u) / 32u) {
         case 1:
             if (!env_str("TA_FILTER_FLAT")) {

@@ -268,6 +268,7 @@ hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32
     if (sc.ensure((size_t)grid * 6 * S.line * sizeof(uint32_t)) != TA_OK) return hipErrorOutOfMemory;
     S.buf = (uint32_t *)sc.dev;
     const bool affine = P.sg > 0;
+    set_last_kernel_name("lev_wide_kernel<%s, %s, false>", affine ? "true" : "false", trans ? "true" : "false");
     if (affine && trans) hipLaunchKernelGGL((lev_wide_kernel<true, true>), dim3(grid), dim3(64), 0, s, P, S);
     else if (affine) hipLaunchKernelGGL((lev_wide_kernel<true, false>), dim3(grid), dim3(64), 0, s, P, S);
     else if (trans) hipLaunchKernelGGL((lev_wide_kernel<false, true>), dim3(grid), dim3(64), 0, s, P, S);

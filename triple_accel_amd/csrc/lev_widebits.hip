@@ -41,6 +41,7 @@ hipError_t lev_widebits_launch(const LevParams &P0, int rows_per_lane, uint64_t 
     if (lds_out) *lds_out = lds;
     if (grid == 0) return hipSuccess;
     dim3 g(grid), b(64);
+    set_last_kernel_name("lev_widebits_kernel<%d, %s>", nwl == 2 ? 2 : 1, trans ? "true" : "false");
     if (nwl == 2) { if (trans) hipLaunchKernelGGL((lev_widebits_kernel<2, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_widebits_kernel<2, false>), g, b, lds, s, P); }
     else { if (trans) hipLaunchKernelGGL((lev_widebits_kernel<1, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_widebits_kernel<1, false>), g, b, lds, s, P); }
     return hipGetLastError();

@@ -1,6 +1,7 @@
 // ta_api.hip -- the C ABI (include/triple_accel_amd.h): validation, launch planning, staging.
 // No CPU fallback lives here: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,6 +25,13 @@ void set_last_error(const char *what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 void set_last_error_msg(const char *msg) { g_last_error = msg; }
+static thread_local char g_last_kernel_name[96] = "";
+void set_last_kernel_name(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel_name, sizeof(g_last_kernel_name), fmt, ap);
+    va_end(ap);
+}
 
 bool device_ready() {
     static int state = -1;   // -1 unknown, 0 no, 1 yes
@@ -99,14 +107,20 @@ static LastUse &last_use() {
     static thread_local LastUse u;
     return u;
 }
+// Lazily: nothing is recorded while a thread stays on one stream (the normal case -- an event record per call was a fifth of
+// a small batch call's cost).  When a call arrives on ANOTHER stream, the event is recorded on the previous stream then --
+// behind everything this thread ever queued there, a superset of the last call's work -- and the new stream waits for it.
 StreamGuard::StreamGuard(hipStream_t s) : st(s) {
     LastUse &u = last_use();
-    if (u.pending && u.st != s && u.ev) (void)hipStreamWaitEvent(s, u.ev, 0);
+    if (u.pending && u.st != s) {
+        if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) u.ev = nullptr;
+        if (u.ev && hipEventRecord(u.ev, u.st) == hipSuccess) (void)hipStreamWaitEvent(s, u.ev, 0);
+        else (void)hipStreamSynchronize(u.st);                  // no event to be had: wait on the host
+    }
 }
 StreamGuard::~StreamGuard() {
     LastUse &u = last_use();
-    if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) { u.ev = nullptr; return; }
-    if (hipEventRecord(u.ev, st) == hipSuccess) { u.st = st; u.pending = true; }
+    u.st = st; u.pending = true;
 }
 
 // Test / tuning switches.  They are honoured only when TA_TUNING was set in the environment when the
@@ -225,7 +239,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         P.u = b2.u; P.o = 0; P.L = 1; P.PW = 128; P.lds_per_wave = b2.lds_per_wave; P.Tw = b2.Tw; P.ch = 64;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits2_launch(P, b2, trans, st, &grid, &lds));
-        li.kernel = 3; li.diags_per_lane = 4u * (uint32_t)b2.NA; li.lanes_per_pair = 1; li.pairs_per_wave = 128;
+        li.kernel = 3; li.diags_per_lane = 15; li.lanes_per_pair = 1; li.pairs_per_wave = 128;
         li.grid = grid; li.lds_bytes = lds; li.band_offset = 0;
     } else if (ch.kernel == LEV_K_BITS) {
         P.u = bp.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp.lds_per_wave; P.Tw = bp.Tw; P.ch = bp.ch;
@@ -329,6 +343,7 @@ int ta_device_count(void) {
 }
 
 const char *ta_last_error(void) { return g_last_error.c_str(); }
+const char *ta_last_kernel_name(void) { return g_last_kernel_name; }
 
 ta_edit_costs ta_levenshtein_costs(void) { ta_edit_costs c = {1, 1, 0, 0, 0}; return c; }
 ta_edit_costs ta_rdamerau_costs(void) { ta_edit_costs c = {1, 1, 0, 1, 1}; return c; }
@@ -406,7 +421,21 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     uint64_t max_len = 0;
     rc = batch_max_len(a, b, (uint32_t)n, st, &max_len);
     if (rc) return rc;
-    return lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st);
+    // Ragged (CSR) batches: the band kernels run a wavefront to the longest of its 64 / L pairs, so the pairs are taken in the
+    // order of a counting sort on their length class (util_kernels.hip: three small launches, ~20 us per million pairs) --
+    // every wavefront then sees pairs within 8 bytes of each other.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
+    const uint32_t *order = nullptr;
+    if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
+        Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
+        constexpr size_t BINS_BYTES = 2 * 1024 * 8 * 4;                    // histogram + cursors: 1024 bins x 8 counters each
+        const bool fresh = bins.cap < BINS_BYTES;
+        if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
+        if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));   // once: every pass leaves the histogram zeroed behind it
+        const uint32_t u = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
+        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u, max_len, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
+        order = (const uint32_t *)ord.dev;
+    }
+    return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st);
 }
 
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,

@@ -12,6 +12,9 @@ namespace ta {
 
 void set_last_error(const char *what, hipError_t e);
 void set_last_error_msg(const char *msg);
+// the dominant kernel of this thread's last pass as a profiler prints it, without "void ta::" and the parameter list
+// (ta_last_kernel_name: bench.py refuses to splice committed counter figures recorded for another kernel)
+void set_last_kernel_name(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define TA_HIP(expr)                                        \
     do {                                                    \
@@ -30,7 +33,7 @@ struct Scratch {
     void release();
     ~Scratch();
 };
-constexpr int TA_SCRATCH_SLOTS = 13;
+constexpr int TA_SCRATCH_SLOTS = 15;
 Scratch &tls_scratch(int which);
 
 // Per-thread context of the single-call host API: its own non-blocking stream (concurrent callers never meet on the null
@@ -94,7 +97,11 @@ hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint
 hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st);
 hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*device, preset to ~0*/, ta_match *out, uint32_t cap,
                             uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
-hipError_t iota_launch(uint32_t *p, uint32_t n, hipStream_t st);
+// counting sort of the pairs of a ragged batch by length class (util_kernels.hip): subset_out = the pairs (of subset_in, or
+// 0..n) ordered so that 64 consecutive ones are within a few bytes of each other; bins = 2 x 8192 u32 of device scratch, the
+// first half zero on entry (it is zero again on exit)
+hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
+                               uint32_t *bins, uint32_t *subset_out, hipStream_t st);
 
 struct SearchParams {
     const uint8_t *hay;       // device

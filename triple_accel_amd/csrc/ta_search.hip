@@ -450,6 +450,101 @@ int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_le
     return give(res, out, n_out);
 }
 
+}  // extern "C"
+
+// windows of a resident haystack until one holds a hit; `upload(lo, hi)` makes bytes [lo, hi) present (host form) or is a no-op
+template <class Upload>
+static int first_hit_windows(const uint8_t *needle, size_t needle_len, const uint8_t *hay_dev, size_t h, uint32_t k,
+                             const ta_edit_costs *costs, uint64_t base, ta_match *out, int *found, hipStream_t st, Upload upload) {
+    *found = 0;
+    const uint32_t unit_k = lev_sat_sub(k, costs->start_gap_cost) / costs->gap_cost;
+    const uint64_t halo = (uint64_t)needle_len + unit_k + 2;
+    Scratch &ob = tls_scratch(1);
+    const size_t cap = 1u << 16;                                  // hits kept per window; a denser window is cut down (below)
+    int rc = ob.ensure(cap * sizeof(ta_match));
+    if (rc) return rc;
+    std::vector<ta_match> hits;
+    uint64_t lo = 0, chunk = 64u << 10, uploaded = 0;
+    while (lo < h) {
+        const uint64_t hi = lo + chunk < h ? lo + chunk : h, ctx = lo > halo ? lo - halo : 0;
+        if (hi > uploaded) { if ((rc = upload(uploaded, hi))) return rc; uploaded = hi; }
+        uint64_t count = 0;
+        // the window [ctx, hi) as a haystack of its own: a DP started fresh `halo` bytes before `lo` is exact for every cost <= k
+        rc = search_dev_core(needle, needle_len, hay_dev + ctx, (size_t)(hi - ctx), k, costs, 0, base + ctx, base + lo,
+                             (ta_match *)ob.dev, cap, &count, nullptr, st);
+        if (rc == TA_ERR_CAPACITY) {                              // more hits than the buffer holds: the first one is in a shorter window
+            if (hi - lo <= 2048) return rc;                       // (cannot happen: a window emits at most one hit per end position)
+            chunk = (hi - lo) / 16 < 2048 ? 2048 : (hi - lo) / 16;
+            continue;
+        }
+        if (rc) return rc;
+        if (count) {
+            hits.resize((size_t)count);
+            TA_HIP(hipMemcpyAsync(hits.data(), ob.dev, (size_t)count * sizeof(ta_match), hipMemcpyDeviceToHost, st));
+            TA_HIP(hipStreamSynchronize(st));
+            const ta_match *best = &hits[0];
+            for (const ta_match &m : hits)
+                if (m.end < best->end || (m.end == best->end && m.start < best->start)) best = &m;
+            *out = *best;
+            *found = 1;
+            return TA_OK;
+        }
+        lo = hi;
+        if (chunk < (256u << 20)) chunk *= 4;
+    }
+    return TA_OK;
+}
+
+extern "C" {
+
+int ta_levenshtein_search_first_dev(const uint8_t *needle_host, size_t needle_len,
+                                    const uint8_t *haystack_dev, size_t haystack_len,
+                                    uint32_t k, const ta_edit_costs *costs, uint64_t base,
+                                    ta_match *out, int *found, void *stream) {
+    if (!out || !found || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
+    *found = 0;
+    if (!search_costs_ok(costs) || ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;
+    if (needle_len == 0 || haystack_len == 0) return TA_OK;
+    return first_hit_windows(needle_host, needle_len, haystack_dev, haystack_len, k, costs, base, out, found, (hipStream_t)stream,
+                             [](uint64_t, uint64_t) { return (int)TA_OK; });
+}
+
+int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                                uint32_t k, const ta_edit_costs *costs, int anchored, ta_match *out, int *found) {
+    if (!out || !found || (!needle && needle_len) || (!haystack && haystack_len)) return TA_ERR_ARG;
+    *found = 0;
+    if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (needle_len == 0) {                                                      // src/levenshtein.rs:1919-1963
+        if (anchored) { *out = ta_match{0, 0, 0, 0}; *found = 1; }
+        return TA_OK;
+    }
+    if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;     // :1965
+    const uint32_t whole_gap = (uint32_t)needle_len * costs->gap_cost + costs->start_gap_cost;
+    if (whole_gap <= k) { *out = ta_match{0, 0, whole_gap, 0}; *found = 1; return TA_OK; }     // the end == 0 match comes first (:1693-1706)
+    if (haystack_len == 0) return TA_OK;
+    if (anchored) {                                                             // a prefix of needle_len + unit_k bytes: one small pass
+        ta_match *all = nullptr;
+        size_t n_all = 0;
+        int rc = ta_levenshtein_search_simd_with_opts(needle, needle_len, haystack, haystack_len, k, TA_SEARCH_ALL, costs, 1, &all, &n_all);
+        if (rc) return rc;
+        if (n_all) { *out = all[0]; *found = 1; }
+        free(all);
+        return TA_OK;
+    }
+    if (!device_ready()) return TA_ERR_HIP;
+    CallCtx &cx = call_ctx();
+    int rc = cx.ensure();
+    if (rc) return rc;
+    Scratch &hs = tls_scratch(0);
+    if ((rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64))) return rc;
+    uint8_t *hd = (uint8_t *)hs.dev;
+    hipStream_t st = cx.st;
+    return first_hit_windows(needle, needle_len, hd, haystack_len, k, costs, 0, out, found, st, [&](uint64_t from, uint64_t to) -> int {
+        TA_HIP(hipMemcpyAsync(hd + from, haystack + from, (size_t)(to - from), hipMemcpyHostToDevice, st));   // only as far as the scan gets
+        return (int)TA_OK;
+    });
+}
+
 int ta_levenshtein_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
                           ta_match **out, size_t *n_out) {                     // src/levenshtein.rs:1866-1878
     ta_edit_costs c = ta_levenshtein_costs();

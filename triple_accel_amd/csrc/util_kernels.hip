@@ -59,6 +59,7 @@ hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, 
     uint32_t G = 1;
     while (G < 64 && (uint64_t)G * 16 < len) G <<= 1;
     const uint32_t ppw = 64 / G, waves = (n + ppw - 1) / ppw;
+    set_last_kernel_name("hamming_batch_kernel");
     hipLaunchKernelGGL(hamming_batch_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a, b, n, out, G);
     return hipGetLastError();
 }
@@ -107,6 +108,101 @@ hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint
                                 uint32_t *list_out, uint32_t *count, hipStream_t st) {
     if (n_in == 0) return hipSuccess;
     hipLaunchKernelGGL(compact_bound_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, bound, k, list_in, n_in, list_out, count);
+    return hipGetLastError();
+}
+
+// ---- ragged batches: the pairs ordered by length ("bucket by length first if lengths vary so waves are uniform").
+// The band kernels run a wavefront to the longest of its pairs; with the pairs of a CSR batch taken in the order of a counting
+// sort on  key = 0 for a pair outside the band (|len_a - len_b| > unit_k: None before any cell, src/levenshtein.rs:426-428),
+// else 1 + (max(len_a, len_b) >> shift)  every wavefront's pairs are within 2^shift bytes of each other.  Three small launches:
+// histogram (per-block counters in LDS, one global atomic per non-empty bin and block), exclusive scan of <= LEN_BINS bins,
+// scatter (a block reserves its share of every bin with one atomic, its pairs take their places through LDS counters).  The
+// order inside a bin is whatever the atomics make it -- the results are per pair and do not depend on it.
+constexpr uint32_t LEN_BINS = 1024, LEN_PAIRS_PER_BLOCK = 2048, LEN_PPT = LEN_PAIRS_PER_BLOCK / 256;
+// every bin has LEN_SUB counters (a block uses the one of its index mod LEN_SUB): a thousand blocks bumping the same ~30 addresses
+// serialise at the L2 (18 us per million pairs with one counter per bin)
+constexpr uint32_t LEN_SUB = 8;
+__device__ __forceinline__ uint32_t len_key(const StrView &a, const StrView &b, uint32_t pair, uint32_t u, uint32_t shift) {
+    const uint64_t la = a.off ? a.off[pair + 1] - a.off[pair] : a.len, lb = b.off ? b.off[pair + 1] - b.off[pair] : b.len;
+    const uint64_t mx = la > lb ? la : lb, mn = la > lb ? lb : la;
+    if (mx - mn > u) return 0u;
+    const uint64_t key = 1u + (mx >> shift);
+    return key < LEN_BINS ? (uint32_t)key : LEN_BINS - 1u;
+}
+// the block's pairs and their keys, all loads in flight before the first LDS atomic (a load -> atomic chain per pair made
+// the kernels latency-bound: 13.5 us per million pairs each)
+__device__ __forceinline__ void len_load_keys(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint32_t shift,
+                                              uint32_t (&pair)[LEN_PPT], uint32_t (&key)[LEN_PPT]) {
+    const uint32_t base = blockIdx.x * LEN_PAIRS_PER_BLOCK;
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_PPT; q++) {
+        const uint32_t i = base + threadIdx.x + 256u * q;
+        pair[q] = i < n ? (subset_in ? subset_in[i] : i) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_PPT; q++) key[q] = pair[q] != 0xFFFFFFFFu ? len_key(a, b, pair[q], u, shift) : 0u;
+}
+__global__ __launch_bounds__(256) void len_hist_kernel(StrView a, StrView b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint32_t shift, uint32_t *hist) {
+    __shared__ uint32_t h[LEN_BINS];
+    for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u) h[i] = 0;
+    uint32_t pair[LEN_PPT], key[LEN_PPT];
+    len_load_keys(a, b, subset_in, n, u, shift, pair, key);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_PPT; q++)
+        if (pair[q] != 0xFFFFFFFFu) atomicAdd(&h[key[q]], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u)
+        if (h[i]) atomicAdd(&hist[i * LEN_SUB + (blockIdx.x % LEN_SUB)], h[i]);
+}
+// hist -> exclusive prefix sums in `cursor`; hist itself goes back to zero (the next call's starting state: no fill per call)
+__global__ __launch_bounds__(LEN_BINS) void len_scan_kernel(uint32_t *hist, uint32_t *cursor) {
+    __shared__ uint32_t s[LEN_BINS];
+    const uint32_t t = threadIdx.x;
+    uint32_t part[LEN_SUB], tot = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_SUB; q++) { part[q] = hist[t * LEN_SUB + q]; hist[t * LEN_SUB + q] = 0; tot += part[q]; }
+    s[t] = tot;
+    __syncthreads();
+    for (uint32_t d = 1; d < LEN_BINS; d <<= 1) {
+        const uint32_t v = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? s[t - 1] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_SUB; q++) { cursor[t * LEN_SUB + q] = run; run += part[q]; }
+}
+__global__ __launch_bounds__(256) void len_scatter_kernel(StrView a, StrView b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint32_t shift,
+                                                          uint32_t *cursor, uint32_t *subset_out) {
+    __shared__ uint32_t h[LEN_BINS];
+    for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u) h[i] = 0;
+    uint32_t pair[LEN_PPT], key[LEN_PPT], rank[LEN_PPT];
+    len_load_keys(a, b, subset_in, n, u, shift, pair, key);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_PPT; q++)
+        if (pair[q] != 0xFFFFFFFFu) rank[q] = atomicAdd(&h[key[q]], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u)
+        if (h[i]) h[i] = atomicAdd(&cursor[i * LEN_SUB + (blockIdx.x % LEN_SUB)], h[i]);     // the block's first place in bin i
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < LEN_PPT; q++)
+        if (pair[q] != 0xFFFFFFFFu) subset_out[h[key[q]] + rank[q]] = pair[q];
+}
+// bins: 2 * LEN_BINS * LEN_SUB u32 (64 KiB) of device scratch whose first half is ZERO on entry (and again on exit: zero it once, when it is
+// allocated); subset_out: n u32.  max_len = the batch's longest string.
+hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
+                               uint32_t *bins, uint32_t *subset_out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t shift = 3;                                               // 8-byte classes while 1022 of them cover the longest string
+    while ((max_len >> shift) + 2 > LEN_BINS) shift++;
+    const uint32_t blocks = (n + LEN_PAIRS_PER_BLOCK - 1) / LEN_PAIRS_PER_BLOCK;
+    hipLaunchKernelGGL(len_hist_kernel, dim3(blocks), dim3(256), 0, st, a, b, subset_in, n, u, shift, bins);
+    hipLaunchKernelGGL(len_scan_kernel, dim3(1), dim3(LEN_BINS), 0, st, bins, bins + LEN_BINS * LEN_SUB);
+    hipLaunchKernelGGL(len_scatter_kernel, dim3(blocks), dim3(256), 0, st, a, b, subset_in, n, u, shift, bins + LEN_BINS * LEN_SUB, subset_out);
     return hipGetLastError();
 }
 

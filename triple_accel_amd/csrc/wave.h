@@ -191,6 +191,9 @@ struct DevWave {
     // (lo >> 8) | (byte N of hi << 24): the dword slides one byte down, byte N of `hi` enters on top -> one v_perm_b32
     template <int N>
     static __device__ __forceinline__ U32 slide_in_byte(U32 hi, U32 lo) { return __builtin_amdgcn_perm(hi, lo, 0x00030201u | ((4u + (uint32_t)N) << 24)); }
+    // bytes picked by the constant selector SEL out of {hi: 4..7, lo: 0..3} (0x0C: the constant 0x00) -> v_perm_b32
+    template <uint32_t SEL>
+    static __device__ __forceinline__ U32 perm(U32 hi, U32 lo) { return __builtin_amdgcn_perm(hi, lo, SEL); }
     // (a & m) | c -> v_and_or_b32
     // (hipcc would rather emit v_and per term and join three terms per v_or3: 11 instructions for 8 terms instead of 8)
     static __device__ __forceinline__ U32 and_or(U32 a, uint32_t m, U32 c) {
