@@ -66,6 +66,19 @@ bits2)
   done 2>&1 | tee $O/bits2.txt
   TA_TUNING=1 TA_BITS2=1 trace cfg4_bits2 --workload cfg4 --steps 10 --warmup 2
   TA_TUNING=1 TA_BITS2=1 python scripts/pmc_collect.py --out $O/cfg4_bits2_pmc.json --workload cfg4 --sets sq1,sq2,rd_b,write --steps 5 2>&1 | tail -2 ;;
+bandab)
+  timeout 1800 python -m pytest tests/test_gpu_lev_batch.py tests/test_gpu_trace.py tests/test_gpu_kats.py -x -q 2>&1 | tail -5 | tee $O/pytest_band.txt
+  for rep in 1 2; do
+    for wl in cfg2w cfg4w; do echo "$wl: $(run --workload $wl --steps 30 --warmup 5)"; done
+  done 2>&1 | tee $O/bandab.txt ;;
+sizes)
+  for rep in 1 2; do
+    for n in 500000 1000000 2000000 4000000; do
+      echo "cfg4 n=$n one pair: $(TA_TUNING=1 TA_NO_BITS2=1 run --workload cfg4 --pairs $n --steps 30 --warmup 5)"
+      echo "cfg4 n=$n two pairs: $(run --workload cfg4 --pairs $n --steps 30 --warmup 5)"
+    done
+    for n in 500000 1000000 2000000; do echo "cfg2 n=$n: $(run --workload cfg2 --pairs $n --steps 30 --warmup 5)"; done
+  done 2>&1 | tee $O/sizes.txt ;;
 *) echo "unknown part $part" ;;
 esac
 done

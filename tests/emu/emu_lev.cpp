@@ -11,20 +11,25 @@
 
 using namespace ta;
 
-template <int D> static void run_d(const LevParams &P, bool affine, int trans, uint32_t waves) {
+template <int D, bool L1> static void run_dl(const LevParams &P, bool affine, int trans, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     for (uint32_t w = 0; w < waves; w++) {
         if (affine) {
-            if (trans == 1) LevBand<EmuWave, D, true, 1>::run(P, w, lds);
-            else if (trans == 2) LevBand<EmuWave, D, true, 2>::run(P, w, lds);
-            else LevBand<EmuWave, D, true, 0>::run(P, w, lds);
+            if (trans == 1) LevBand<EmuWave, D, true, 1, false, L1>::run(P, w, lds);
+            else if (trans == 2) LevBand<EmuWave, D, true, 2, false, L1>::run(P, w, lds);
+            else LevBand<EmuWave, D, true, 0, false, L1>::run(P, w, lds);
         } else {
-            if (trans == 1) LevBand<EmuWave, D, false, 1>::run(P, w, lds);
-            else if (trans == 2) LevBand<EmuWave, D, false, 2>::run(P, w, lds);
-            else LevBand<EmuWave, D, false, 0>::run(P, w, lds);
+            if (trans == 1) LevBand<EmuWave, D, false, 1, false, L1>::run(P, w, lds);
+            else if (trans == 2) LevBand<EmuWave, D, false, 2, false, L1>::run(P, w, lds);
+            else LevBand<EmuWave, D, false, 0, false, L1>::run(P, w, lds);
         }
     }
     free(lds);
+}
+// as the launcher (lev_band.hip): the one-lane-per-pair instantiation whenever the plan says L == 1
+template <int D> static void run_d(const LevParams &P, bool affine, int trans, uint32_t waves) {
+    if (P.L == 1) run_dl<D, true>(P, affine, trans, waves);
+    else run_dl<D, false>(P, affine, trans, waves);
 }
 
 int g_emu_force_ch = 0;

@@ -401,7 +401,6 @@ def test_two_pairs_per_lane_narrow_bands(monkeypatch, L, Lb, k, costs):
         s = (s + bytes(g.integers(97, 101, size=Lb, dtype=np.uint8)))[:Lb]
         b[row] = np.frombuffer(s, dtype=np.uint8)
     sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
-    monkeypatch.setenv("TA_BITS2", "1")                 # opt-in (level with the one-pair form in time: profiles/r02/ab_band_kernel.md)
     got = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
     info = T.last_launch_info()
     assert info["kernel"] == 3 and info["pairs_per_wave"] == 128, info
@@ -411,7 +410,7 @@ def test_two_pairs_per_lane_narrow_bands(monkeypatch, L, Lb, k, costs):
     tail = O.levenshtein_k_batch(O.csr_from_fixed(a[-500:]), O.csr_from_fixed(b[-500:]), k, costs)
     assert np.array_equal(got[-500:], tail)
     assert (want != 0xFFFFFFFF).any() and (want == 0xFFFFFFFF).any()
-    monkeypatch.delenv("TA_BITS2")
+    monkeypatch.setenv("TA_NO_BITS2", "1")
     one = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
     assert T.last_launch_info()["pairs_per_wave"] == 64
     assert np.array_equal(got, one)
@@ -420,7 +419,6 @@ def test_two_pairs_per_lane_narrow_bands(monkeypatch, L, Lb, k, costs):
 def test_two_pairs_per_lane_is_for_big_batches_only(monkeypatch):
     import triple_accel_amd as T
     from triple_accel_amd import batch as B
-    monkeypatch.setenv("TA_BITS2", "1")
     a, b = Dg.pairs_mutated_fixed(5, 5000, 128, 8)
     B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 8)
     assert T.last_launch_info()["pairs_per_wave"] == 64

@@ -9,17 +9,20 @@ namespace ta {
 
 constexpr int LEV_WAVES_PER_BLOCK = 4;
 
-template <int D, bool AFFINE, int TRANS>
+// L1: one lane per pair (the whole band in one lane's D diagonals: bands of up to 66 diagonals with 64 pairs per wavefront)
+template <int D, bool AFFINE, int TRANS, bool L1>
 __global__ __launch_bounds__(64 * LEV_WAVES_PER_BLOCK) void lev_band_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBand<DevWave, D, AFFINE, TRANS>::run(P, blockIdx.x * LEV_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+    LevBand<DevWave, D, AFFINE, TRANS, false, L1>::run(P, blockIdx.x * LEV_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
 }
 
 template <int D>
 static hipError_t launch_d(const LevParams &P, bool affine, int trans, uint32_t grid, size_t lds, hipStream_t s) {
     dim3 g(grid), b(64 * LEV_WAVES_PER_BLOCK);
-#define TA_L(A, T) hipLaunchKernelGGL((lev_band_kernel<D, A, T>), g, b, lds, s, P)
+    const bool l1 = P.L == 1;
+#define TA_L(A, T) do { if (l1) hipLaunchKernelGGL((lev_band_kernel<D, A, T, true>), g, b, lds, s, P); \
+                        else hipLaunchKernelGGL((lev_band_kernel<D, A, T, false>), g, b, lds, s, P); } while (0)
     if (affine) { if (trans == 1) TA_L(true, 1); else if (trans == 2) TA_L(true, 2); else TA_L(true, 0); }
     else { if (trans == 1) TA_L(false, 1); else if (trans == 2) TA_L(false, 2); else TA_L(false, 0); }
 #undef TA_L
@@ -35,7 +38,7 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
-    set_last_kernel_name("lev_band_kernel<%d, %s, %d>", pl.D, affine ? "true" : "false", trans);
+    set_last_kernel_name("lev_band_kernel<%d, %s, %d, %s>", pl.D, affine ? "true" : "false", trans, P.L == 1 ? "true" : "false");
     switch (pl.D) {
 #define TA_CASE(d) case d: return launch_d<d>(P, affine, trans, grid, lds, s);
         TA_CASE(2) TA_CASE(4) TA_CASE(6) TA_CASE(8) TA_CASE(10) TA_CASE(12) TA_CASE(16) TA_CASE(18) TA_CASE(20)

@@ -57,7 +57,8 @@ struct LevParams {
 constexpr int lev_trace_words(int D) { return (D + 31) / 32; }   // 2 bits x D/2 cells per phase
 
 // TRANS: 0 = no transposition, 1 = transposition as a dot4 penalty (needs 2*mc <= 255 + tc), 2 = as a select
-template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false>
+// L1: one lane per pair (the band fits D diagonals: P.L == 1) -- no neighbour lane, so no DPP moves and no edge selects
+template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false, bool L1 = false>
 struct LevBand {
     static_assert(D % 2 == 0 && D >= 2, "D must be even");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
@@ -104,7 +105,9 @@ struct LevBand {
         // cells, or as their own diagonal predecessor), odd-q cells raw with HA = dp + 2gc for their even
         // neighbours -- one add per TWO cells instead of one per cell.
         U32 xl = INF, xr = INF;
-        if (PAR == 0) {
+        if (L1) {
+            // every lane is its pair's first and last: both band edges
+        } else if (PAR == 0) {
             xl = W::from_lower0(st.HA[D - 1]);
             xl = W::sel(is_g0, INF, xl);            // band edge: nothing left of the pair's first diagonal
         } else {
@@ -178,9 +181,12 @@ struct LevBand {
 #pragma unroll
             for (int w = 0; w < NW; w++) st.AWp[w] = st.AW[w];
         }
-        U32 t = st.AW[sb >> 2] >> (8 * (sb & 3));
-        t = W::from_lower0(t);
-        t = W::sel(is_g0, a_in, t);
+        U32 t = a_in;
+        if (!L1) {
+            t = st.AW[sb >> 2] >> (8 * (sb & 3));
+            t = W::from_lower0(t);
+            t = W::sel(is_g0, a_in, t);
+        }
         st.AW[0] = W::bfi(0xffu, t, st.AW[0]);
 #pragma unroll
         for (int w = NW - 1; w >= 1; w--) st.AW[w] = W::template alignbyte<3>(st.AW[w], st.AW[w - 1]);
@@ -192,9 +198,12 @@ struct LevBand {
 #pragma unroll
             for (int w = 0; w < NW; w++) st.BWp[w] = st.BW[w];
         }
-        U32 t = st.BW[0] >> 8;   // byte 1 = cell 0
-        t = W::from_upper0(t);
-        t = W::sel(is_gl, b_in, t);
+        U32 t = b_in;
+        if (!L1) {
+            t = st.BW[0] >> 8;   // byte 1 = cell 0
+            t = W::from_upper0(t);
+            t = W::sel(is_gl, b_in, t);
+        }
         constexpr int ib = Dh + 1, iw = ib >> 2, ish = 8 * (ib & 3);
         st.BW[iw] = W::bfi(0xffu << ish, t << ish, st.BW[iw]);
 #pragma unroll
@@ -283,7 +292,10 @@ struct LevBand {
         U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
 
         const uint32_t CH = P.ch, RMASK = 2u * CH - 1u;
-        const U32 a_slot = grp * lev_slot_bytes(CH), b_slot = (grp + P.PW) * lev_slot_bytes(CH);
+        // (lanes beyond the last whole pair of the wavefront -- 64 % L of them -- read the first pair's rings: their values go nowhere,
+        // but an address past the wavefront's LDS is not theirs to read; found by the AddressSanitizer build of the emulation)
+        const U32 grp_r = W::sel(active, grp, W::splat(0));
+        const U32 a_slot = grp_r * lev_slot_bytes(CH), b_slot = (grp_r + P.PW) * lev_slot_bytes(CH);
 
         // iterations before min(ca, cb) would only shift zeros into zero windows: start there
         const uint32_t hfar = W::wave_max(W::sel(active, W::sel(h + h >= L * Dh, h, W::splat(L * Dh) - h), W::splat(0)));

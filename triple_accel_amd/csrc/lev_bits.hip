@@ -48,9 +48,9 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(Le
     LevBits2<DevWave, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
-// two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront, one wavefront per block (fine grains at the launch's tail)
+// two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
-    uint32_t wpb = 1;
+    uint32_t wpb = 2;                               // cfg4: 0.1180 ms against 0.1195 with one or four wavefronts per block
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t waves = (P.n + 127u) / 128u, grid = (waves + wpb - 1) / wpb;
     const size_t lds = (size_t)pl.lds_per_wave * wpb;

@@ -24,8 +24,8 @@
 //
 // Strings: fixed-length batches only (the band geometry is one number per launch, every event is wave-uniform).  Each lane
 // requests HALF a 128-byte line (four 16-byte pieces) of each of its four strings at a time and parks it in registers (64 VGPRs);
-// LDS holds per pair a ring of 3 pieces of `a` and 2 of `b` (52 + 36 bytes, as the stride-8 line form): 11 KB per wavefront,
-// 14 wavefronts per CU.  A piece moves registers -> LDS every 16 columns; the burst for the next half line follows the commit
+// LDS holds per pair a ring of 2 pieces of `a` and 1 of `b` (36 + 20 bytes with the wrap copies): 7 KB per wavefront; the
+// 119 - 123 VGPRs allow 16 wavefronts per CU.  A piece moves registers -> LDS every 16 columns; the burst for the next half line follows the commit
 // of a half line's last piece.  Same result contract as lev_bits_body.h (d if d <= k else None, src/levenshtein.rs:539-541).
 #pragma once
 #include "lev_bits_body.h"
@@ -40,7 +40,10 @@ struct LevBits2 {
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
     using Q = typename W::Q;
-    static constexpr int32_t RA = 3, RB = 2;                   // ring pieces of `a` / `b` per pair
+    // ring pieces of `a` / `b` per pair: a span of 16 iterations reads 16 + 15 bytes of `a` from where its first byte sits in a
+    // piece (two pieces) and one piece of `b` (its stream starts on a piece boundary: T0 is a multiple of 64); the piece a span
+    // needs last is committed at the span's start into the slot of the piece the span before finished with
+    static constexpr int32_t RA = 2, RB = 1;
     static constexpr uint32_t SLOT_A = 16u * RA + 4u, SLOT_B = 16u * RB + 4u;   // + a wrap copy of the ring's first dword
     static constexpr uint32_t LDS_PER_WAVE = 128u * (SLOT_A + SLOT_B);
     static constexpr int BURST = 4;                            // pieces per request: half a line

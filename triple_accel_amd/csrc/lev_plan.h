@@ -151,7 +151,7 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
            pairs >= LEV_BITS2_MIN_PAIRS;
     p.NA = 8;                                                  // the stride-8 window: 8 registers of 2 + 2 bytes
     p.Tw = (p.u + (has_t ? 1u : 0u) + 2u + 63u) & ~63u;        // (the stream of `a` runs two iterations ahead of the window's last row)
-    p.lds_per_wave = 128u * (52u + 36u);                       // rings of 3 + 2 sixteen-byte pieces per pair (+ wrap copies)
+    p.lds_per_wave = 128u * (36u + 20u);                       // rings of 2 + 1 sixteen-byte pieces per pair (+ wrap copies)
     return p;
 }
 

@@ -231,11 +231,10 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         return TA_OK;
     }
     const LevBits2Plan b2 = lev_bits2_make_plan(k, c->mismatch_cost, gc, sg, trans, tcost, max_len, !a->off && !b->off, n_work);
-    if (ch.kernel == LEV_K_BITS && b2.ok && !pinned && env_int("TA_BITS2")) {
-        // narrow band, big fixed-length batch: two pairs per lane share the recurrence (lev_bits2_body.h).  OPT-IN (TA_TUNING=1
-        // TA_BITS2=1): 27 % fewer instructions per pair, but twice the LDS per wavefront leaves 8 wavefronts per CU, the kernel
-        // stops being issue-bound (6.5 cycles per VALU instruction against 4.1) and ends up level with the one-pair form on cfg4
-        // while fetching 1.9x the string bytes (profiles/r02/ab_band_kernel.md)
+    if (ch.kernel == LEV_K_BITS && b2.ok && !pinned && !env_int("TA_NO_BITS2")) {
+        // narrow band, big fixed-length batch: two pairs per lane share the recurrence AND the byte test (lev_bits2_body.h, the
+        // stride-8 window with both pairs' bytes in every register): 27 % fewer instructions per pair, 16 wavefronts per CU;
+        // cfg4 0.118 against 0.135 ms (profiles/r03/ab_band_kernel.md).  TA_NO_BITS2=1 keeps one pair per lane.
         P.u = b2.u; P.o = 0; P.L = 1; P.PW = 128; P.lds_per_wave = b2.lds_per_wave; P.Tw = b2.Tw; P.ch = 64;
         uint32_t grid = 0, lds = 0;
         TA_HIP(lev_bits2_launch(P, b2, trans, st, &grid, &lds));
