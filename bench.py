@@ -46,11 +46,15 @@ def parse_args():
                     help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
                          "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
-    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged"],
-                    help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair")
+    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna"],
+                    help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair; "
+                         "dna: fixed-length strings over A C G T (half of the pairs mutated copies), passed with alphabet=b'ACGT' -- the small-alphabet kernel")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--early-out", action="store_true",
+                    help="ta_set_option(TA_OPT_EARLY_OUT): wavefronts stop once none of their pairs can end at or below k -- same answers, "
+                         "data-dependent work; NOT the headline (the reference evaluates its whole band): the line says so in config.early_out")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed passes for this long BEFORE the W warm-up steps: the input set-up on the host leaves the GPU idle for "
                          "seconds and its clocks take longer than a handful of 0.4 ms passes to come back (0 = off)")
@@ -111,6 +115,8 @@ def main():
     from triple_accel_amd import batch as B
     from triple_accel_amd import dist as TD
 
+    if args.early_out:
+        T.set_option(T.OPT_EARLY_OUT, True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,6 +196,15 @@ def main():
                 return csr[0], csr[1], None
             if args.dist == "random":
                 a, b = Dg.pairs_random(seed, n, L)
+            elif args.dist == "dna":
+                sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+                a = sym[g.integers(0, 4, size=(n, L))]
+                b = sym[g.integers(0, 4, size=(n, L))]
+                near = np.arange(n) % 2 == 1                      # every other pair: a copy with up to k / 2 substitutions
+                b[near] = a[near]
+                pos = g.integers(0, L, size=(n, max(1, (k or 64) // 2)))
+                rows = np.nonzero(near)[0]
+                b[rows[:, None], pos[rows]] = sym[g.integers(0, 4, size=(len(rows), pos.shape[1]))]
             else:
                 a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
                 b = a.copy()
@@ -239,7 +254,8 @@ def main():
                 run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
                 oracle = lambda l, h, th: O.levenshtein_exp_batch(*csr(l, h), costs, threads=th)
             else:
-                run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out)
+                alphabet = b"ACGT" if args.dist == "dna" else None
+                run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out, alphabet=alphabet)
                 oracle = lambda l, h, th: O.levenshtein_k_batch(*csr(l, h), k, costs, threads=th)
             if n == 0:
                 run = lambda: None
@@ -425,7 +441,8 @@ def main():
     traffic = None
     traffic_source = None
     valu_issue = None
-    pmc = load_json(PROFILE_ROUND, "bench_%s%s_pmc.json" % (wl, "_ragged" if args.dist == "ragged" else ""))
+    tag = wl + ("" if args.dist in ("random", "mutated") else "_" + args.dist)       # the profile files of this workload / distribution
+    pmc = load_json(PROFILE_ROUND, "bench_%s_pmc.json" % tag)
     # a committed counter pass is only spliced into the line when it was recorded for the kernel this run launched
     # (T.last_kernel_name(): the dominant kernel of the pass, as rocprofv3 prints it) -- never for another build's kernel
     if pmc and kernel_name and kernel_name not in str(pmc.get("_dominant", "")):
@@ -436,7 +453,7 @@ def main():
         try:
             traffic = int(pmc["_traffic"]["bytes_per_pass"])      # size-resolved L2 fabric-side requests, all kernels of one pass
             traffic_source = ("replayed from the committed counter pass profiles/%s/bench_%s_pmc.json (rocprofv3 --pmc, separate passes, "
-                              "same command, kernel %s); not measured in this run" % (PROFILE_ROUND, wl, pmc.get("_dominant")))
+                              "same command, kernel %s); not measured in this run" % (PROFILE_ROUND, tag, pmc.get("_dominant")))
         except Exception:
             traffic = None
         try:
@@ -446,10 +463,10 @@ def main():
                           "cycles_per_valu_inst_per_simd": cyc_per_inst,
                           # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 -> the hard ceiling
                           "frac_of_2cycle_ceiling": 2.0 / cyc_per_inst,
-                          "source": "profiles/%s/bench_%s_pmc.json" % (PROFILE_ROUND, wl)}
+                          "source": "profiles/%s/bench_%s_pmc.json" % (PROFILE_ROUND, tag)}
             mix = load_json(PROFILE_ROUND, "isa_mix.json")
-            if mix and wl in mix:          # opcode histogram of the inner loop x per-class issue cost measured opcode by opcode
-                m = mix[wl]
+            if mix and tag in mix:          # opcode histogram of the inner loop x per-class issue cost measured opcode by opcode
+                m = mix[tag]
                 valu_issue["isa_model_cycles_per_valu_inst"] = m["modelled_cycles_per_valu_inst"]
                 valu_issue["frac_of_isa_model"] = m["modelled_cycles_per_valu_inst"] / cyc_per_inst
             # what a MIXED stream really costs on this chip (profiles/<round>/ubench_mix.txt: a full-rate op next to half-rate ones
@@ -563,7 +580,8 @@ def main():
                    "parallelism": "independent units sharded x%d (%s), %s" % (
                        world, args.scaling, "no collective" if wl != "cfg5" or world == 1 else
                        "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
-                   "backend": backend if world > 1 else None},
+                   "backend": backend if world > 1 else None,
+                   "early_out": bool(args.early_out)},
         "value_evaluated_cells": evaluated_value,
         "end_to_end_ms": e2e_ms,          # host buffers in, answers out (pinned H2D + pass + D2H); never the headline
         "strong_scaling": strong_fig,

@@ -85,6 +85,14 @@ int ta_edit_costs_check_search(const ta_edit_costs *c);
 /* ---- runtime ------------------------------------------------------------------------- */
 const char *ta_version(void);
 const char *ta_status_str(int status);
+/* Options of the calling thread (0 = off, the default).
+ *   TA_OPT_EARLY_OUT: the bit-parallel band kernels of fixed-length unit-cost batches (bands of up to 33 diagonals) stop a
+ *   wavefront as soon as none of its pairs can still end at or below k (the top cell of the current band column minus the
+ *   downward steps below it -- a lower bound of every cell of the column -- exceeds k; checked every 24-32 columns).  The answers are the same -- those pairs are None either way
+ *   (src/levenshtein.rs:539-541) -- but the work then depends on the data: batches of dissimilar strings finish after a few
+ *   dozen columns.  Off by default: the reference evaluates its whole band, and so does every benchmark figure of this library. */
+enum { TA_OPT_EARLY_OUT = 1 };
+int ta_set_option(int option, int value);
 /* number of visible HIP devices (0 => every compute call returns TA_ERR_HIP) */
 int ta_device_count(void);
 /* text of the last HIP error seen on this thread ("" if none) */
@@ -212,6 +220,12 @@ typedef struct {
 /* N x levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) -> out[i] (u32 or TA_NONE). */
 int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k,
                            const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
+/* The same for strings written in a small alphabet the caller names (at most four distinct byte values -- DNA, RNA -- for which
+ * a two-bit code (byte >> h) & 3 exists): the match vector of a column becomes a table lookup, about half the instructions of the
+ * byte test.  The promise is verified on the device: pairs that hold any other byte are answered by the general kernel inside the
+ * same call.  Batches the small-alphabet kernel does not cover run ta_levenshtein_k_batch unchanged. */
+int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                    const uint8_t *alphabet, size_t alphabet_len, uint32_t *out_dev, void *stream);
 /* N x levenshtein_exp_with_opts(a_i, b_i, false, costs): doubling k from 30 over the still-unresolved
  * subset (src/levenshtein.rs:1480-1494).  Synchronises the stream between rounds. */
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,

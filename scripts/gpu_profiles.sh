@@ -1,28 +1,43 @@
 #!/bin/bash
 # The round's measurement pass on ONE GPU box: every number quoted in README.md / DESIGN.md comes from the files this writes
-# (copy gpurun_out/profiles/* into profiles/<round>/ afterwards, then run scripts/make_tables.py).
-#   bench_cfg{1..5}.json          one bench line per BASELINE configuration (cfg2 with the cpu_baseline leg)
-#   bench_cfg2_mutated.json       cfg2 on the "mutated" input distribution
-#   bench_cfg{1..5}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command; bench_cfgN_under_kernel_trace.json = what
-#                                 bench.py itself measured (HIP events) inside that profiled run
-#   bench_cfg{1..5}_pmc.json      SQ counters (VALU instructions, busy cycles, waits, LDS) + L2 fabric-side requests, separate passes
-#   host_cpu.txt, latency.txt, ubench_mix.txt, ubench_cellwidth.txt
+# (copy gpurun_out/profiles/* into profiles/<round>/ afterwards, then run scripts/isa_mix.py and scripts/make_tables.py <round>).
+# Workloads (tag = file stem): the five BASELINE configurations cfg1..cfg5 (cfg2 with the cpu_baseline leg), cfg2 on the mutated
+# distribution, the general-cost geometries cfg2w / cfg4w (DP band-wavefront kernel), the ragged CSR batch cfg2_ragged
+# (length-ordered on the device) and the DNA batch cfg2_dna (small-alphabet kernel).  Per tag:
+#   bench_<tag>.json                  the bench line (driver protocol)
+#   bench_<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command; bench_<tag>_under_kernel_trace.json = what
+#                                     bench.py itself measured (HIP events) inside that profiled run
+#   bench_<tag>_pmc.json              SQ counters (VALU instructions, busy cycles, waits, LDS) + L2 fabric-side requests, separate passes
+# plus host_cpu.txt, latency.txt, ubench_mix.txt, ubench_cellwidth.txt, bench_cfg2_early_out.json, bench_cfg2_2m.json
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/profiles; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 (lscpu | head -25; echo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc; rocminfo | grep -E "Marketing|Compute Unit|Max Clock|gfx" | head -12) > $O/host_cpu.txt 2>&1
-timeout 900 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
-timeout 600 python bench.py --dist mutated --no-cpu > $O/bench_cfg2_mutated.json 2>/dev/null
-timeout 600 python bench.py --workload cfg4 --steps 50 > $O/bench_cfg4.json 2>/dev/null
-timeout 600 python bench.py --workload cfg1 --steps 50 > $O/bench_cfg1.json 2>/dev/null
-timeout 900 python bench.py --workload cfg5 --steps 10 --warmup 2 > $O/bench_cfg5.json 2>/dev/null
-timeout 900 python bench.py --workload cfg3 --steps 3 --warmup 1 > $O/bench_cfg3.json 2>/dev/null
-for wl in cfg2 cfg4 cfg1 cfg5 cfg3; do
-  steps=5; [ $wl = cfg3 ] && steps=3
-  (cd /tmp; rm -rf /tmp/kt_$wl; rocprofv3 --kernel-trace --stats -d /tmp/kt_$wl -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps $steps --warmup 1 --no-cpu 2>/dev/null | grep '^{' > $O/bench_${wl}_under_kernel_trace.json; cp $(find /tmp/kt_$wl -name "kt_kernel_stats.csv" | head -1) $O/bench_${wl}_kernel_stats.csv; rm -rf /tmp/kt_$wl)
-  python scripts/pmc_collect.py --out $O/bench_${wl}_pmc.json --workload $wl --sets sq1,sq2,fetch,write,rd_b --steps $steps 2>&1 | tail -1
+flags() {   # tag -> bench.py flags
+  case $1 in
+    cfg2_mutated) echo "--workload cfg2 --dist mutated" ;;
+    cfg2_ragged) echo "--workload cfg2 --dist ragged" ;;
+    cfg2_dna) echo "--workload cfg2 --dist dna" ;;
+    *) echo "--workload $1" ;;
+  esac
+}
+steps() { case $1 in cfg3) echo "--steps 3 --warmup 1" ;; cfg5) echo "--steps 10 --warmup 2" ;; cfg2) echo "" ;; *) echo "--steps 50" ;; esac; }
+TAGS="cfg2 cfg2_mutated cfg4 cfg1 cfg5 cfg3 cfg2w cfg4w cfg2_ragged cfg2_dna"
+for tag in $TAGS; do
+  nocpu="--no-cpu"; [ $tag = cfg2 ] && nocpu=""
+  timeout 900 python bench.py $(flags $tag) $(steps $tag) $nocpu > $O/bench_$tag.json 2> $O/bench_$tag.err
+done
+timeout 600 python bench.py --early-out --no-cpu > $O/bench_cfg2_early_out.json 2>/dev/null
+timeout 600 python bench.py --pairs 2000000 --no-cpu > $O/bench_cfg2_2m.json 2>/dev/null
+for tag in $TAGS; do
+  [ $tag = cfg2_mutated ] && continue
+  st=5; [ $tag = cfg3 ] && st=3
+  (cd /tmp; rm -rf /tmp/kt_$tag; rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py $(flags $tag) --steps $st --warmup 1 --no-cpu 2>/dev/null | grep '^{' > $O/bench_${tag}_under_kernel_trace.json; cp $(find /tmp/kt_$tag -name "kt_kernel_stats.csv" | head -1) $O/bench_${tag}_kernel_stats.csv; rm -rf /tmp/kt_$tag)
+  wl=$(flags $tag | cut -d' ' -f2); extra=$(flags $tag | cut -s -d' ' -f3-)
+  python scripts/pmc_collect.py --out $O/bench_${tag}_pmc.json --workload $wl --sets sq1,sq2,fetch,write,rd_b --steps $st --extra "$extra" 2>&1 | tail -1
 done
 python scripts/measure_latency.py > $O/latency.txt 2>&1
+python scripts/measure_search_parts.py > $O/search_parts.txt 2>&1
 ./scripts/ubench_mix > $O/ubench_mix.txt 2>&1
 ./scripts/ubench_cellwidth > $O/ubench_cellwidth.txt 2>&1
-for f in $O/bench_cfg*.json; do echo $f; cut -c1-200 $f; done
+for f in $O/bench_cfg*.json; do echo $f; cut -c1-160 $f; done

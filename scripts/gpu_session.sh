@@ -79,6 +79,28 @@ sizes)
     done
     for n in 500000 1000000 2000000; do echo "cfg2 n=$n: $(run --workload cfg2 --pairs $n --steps 30 --warmup 5)"; done
   done 2>&1 | tee $O/sizes.txt ;;
+early)
+  timeout 1200 python -m pytest tests/test_gpu_lev_bits.py -x -q -k "early_out or two_pairs or cfg" 2>&1 | tail -4 | tee $O/pytest_early.txt
+  for rep in 1 2; do
+    for wl in cfg2 cfg4; do
+      echo "$wl random: $(run --workload $wl --steps 50 --warmup 5)"
+      echo "$wl random, early out: $(run --workload $wl --steps 50 --warmup 5 --early-out)"
+      echo "$wl mutated, early out: $(run --workload $wl --dist mutated --steps 50 --warmup 5 --early-out)"
+    done
+    echo "cfg2 geometry through the DP band kernel: $(TA_TUNING=1 TA_NO_BITS=1 run --workload cfg2 --steps 20 --warmup 3)"
+    echo "cfg4 geometry through the DP band kernel: $(TA_TUNING=1 TA_NO_BITS=1 run --workload cfg4 --steps 20 --warmup 3)"
+  done 2>&1 | tee $O/early.txt ;;
+dna)
+  timeout 1200 python -m pytest tests/test_gpu_lev_bits.py -x -q -k "small_alphabet" 2>&1 | tail -6 | tee $O/pytest_dna.txt
+  for rep in 1 2; do
+    for wl in cfg2 cfg4; do
+      echo "$wl random bytes: $(run --workload $wl --steps 50 --warmup 5)"
+      echo "$wl dna, small-alphabet kernel: $(run --workload $wl --dist dna --steps 50 --warmup 5)"
+      echo "$wl dna, byte-test kernel: $(TA_TUNING=1 TA_NO_BITSQ=1 run --workload $wl --dist dna --steps 50 --warmup 5)"
+    done
+  done 2>&1 | tee $O/dna.txt
+  trace cfg2_dna --workload cfg2 --dist dna --steps 10 --warmup 2
+  python scripts/pmc_collect.py --out $O/cfg2_dna_pmc.json --workload cfg2 --sets sq1,sq2,rd_b,write --steps 5 --extra "--dist dna" 2>&1 | tail -2 ;;
 *) echo "unknown part $part" ;;
 esac
 done

@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 D = os.path.join(ROOT, "profiles", RND)
 
 
@@ -51,12 +51,12 @@ def main():
             "`SQ_INSTS_VALU` of the dominant kernel.", ""]
     out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
             "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
-    for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg3", "cfg5", "cfg1"):
+    for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg3", "cfg5", "cfg1", "cfg2w", "cfg4w", "cfg2_ragged", "cfg2_dna", "cfg2_early_out", "cfg2_2m"):
         b = J("bench_%s.json" % wl)
         if not b:
             continue
-        base = wl.split("_")[0]
-        p = J("bench_%s_pmc.json" % base) if wl == base else None
+        base = wl
+        p = J("bench_%s_pmc.json" % wl)
         r = b["roofline"]
         ev = b.get("value_evaluated_cells")
         tr = (p or {}).get("_traffic", {}).get("bytes_per_pass")
@@ -71,6 +71,16 @@ def main():
             "%.3g" % v["insts"] if v else "—", "%.2f" % v["cyc"] if v else "—",
             "%.2f" % v["f2"] if v else "—", "%.2f" % v["fm"] if v and v["fm"] else "—",
             wl, ", `bench_%s_pmc.json`" % base if p else ""))
+    out += ["", "(cfg2w / cfg4w: the cfg2 / cfg4 geometry under EditCosts(2,3,1,None) k=32 / (2,2,1,Some(3)) k=8 -- the DP band-wavefront kernel; "
+            "cfg2_ragged: CSR batch, lengths uniform on 32..256, taken in length order on the device, cells credited pair by pair; cfg2_dna: strings "
+            "over A C G T through the small-alphabet kernel; cfg2_early_out: `ta_set_option(TA_OPT_EARLY_OUT)` on the random batch -- same answers, "
+            "data-dependent work, NOT a headline figure; cfg2_2m: 2M pairs per pass.)", ""]
+    e2e = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg5", "cfg1", "cfg2_ragged")]
+    out += ["## Host buffers in, answers out (`end_to_end_ms`: pinned H2D of the batch + the pass + D2H; never the headline)", "",
+            "| config | ms per pass, inputs resident | ms end to end | untimed ramp passes before the timed region |", "|---|---|---|---|"]
+    for wl, b in e2e:
+        if b and b.get("end_to_end_ms"):
+            out.append("| %s | %.4f | %.2f | %s |" % (wl, b["ms_per_step"], b["end_to_end_ms"], b.get("prewarm_passes")))
     out.append("")
     b2 = J("bench_cfg2.json")
     if b2 and b2.get("cpu_baseline"):
@@ -83,7 +93,9 @@ def main():
         out += ["", "thread scaling of the best variant (threads, GCUPS): " + ", ".join("%d: %.1f" % (t, g) for t, g in c.get("thread_scaling_gcups", [])), ""]
     out += ["## Dominant kernels (rocprofv3 --kernel-trace --stats, `bench_cfgN_kernel_stats.csv`)", "", "| config | kernel | calls | average us |", "|---|---|---|---|"]
     for wl, needle in (("cfg2", "lev_bits_"), ("cfg4", "lev_bits"), ("cfg3", "lev_widebits_kernel"), ("cfg3", "bag_bound"), ("cfg5", "lev_filter_kernel"),
-                       ("cfg5", "lev_search_list"), ("cfg1", "hamming")):
+                       ("cfg5", "lev_search_wave_kernel"), ("cfg1", "hamming"), ("cfg2w", "lev_band_kernel"), ("cfg4w", "lev_band_kernel"),
+                       ("cfg2_ragged", "lev_bits_"), ("cfg2_ragged", "len_hist"), ("cfg2_ragged", "len_scan"), ("cfg2_ragged", "len_scatter"),
+                       ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8")):
         k = kernel_us(wl, needle)
         if k:
             out.append("| %s | `%s` | %d | %.1f |" % (wl, needle, k[1], k[0]))

@@ -13,6 +13,8 @@ using namespace ta;
 extern int g_emu_force_ch;
 static int g_emu_bits_fixed_chunk = 0;      // 1: fixed-length batches take the chunk form (as the launcher does up to one line per string)
 extern "C" void emu_bits_set_fixed_chunk(int on) { g_emu_bits_fixed_chunk = on; }
+static uint32_t g_emu_bits_tune = 0;        // LevParams::tune bits (2: early out)
+extern "C" void emu_bits_set_tune(uint32_t bits) { g_emu_bits_tune = bits; }
 
 // ---- bit-parallel band kernel (lev_bits_body.h)
 #include "lev_bits_body.h"
@@ -55,6 +57,7 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
+    P.tune = g_emu_bits_tune;
     if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.s8 ? 3 : pl.stat; }
     const uint32_t waves = (n + 63) / 64;
     // fixed-length batches take the line form here whatever their length (the launcher keeps the chunk form up to one line per
@@ -63,7 +66,9 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
         uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
         const bool line = !a_off && !b_off && !g_emu_bits_fixed_chunk;
         for (uint32_t w = 0; w < waves; w++) {
-            if (has_t) { if (line) LevBits<EmuWave, 8, true, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, true, false, false, true>::run(P, w, lds); }
+            if (line && (P.tune & 2u)) {           // as the launcher: the early-out instantiation under the option
+                if (has_t) LevBits<EmuWave, 8, true, false, true, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, true, true, true>::run(P, w, lds);
+            } else if (has_t) { if (line) LevBits<EmuWave, 8, true, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, true, false, false, true>::run(P, w, lds); }
             else { if (line) LevBits<EmuWave, 8, false, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, false, true>::run(P, w, lds); }
         }
         free(lds);
@@ -94,12 +99,43 @@ extern "C" int emu_lev_bits2(const uint8_t *a_blob, uint64_t a_len, const uint8_
     P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 128; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = 64;
+    P.tune = g_emu_bits_tune;
     if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; }
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     const uint32_t waves = (n + 127) / 128;
     for (uint32_t w = 0; w < waves; w++) {
-        if (has_t) LevBits2<EmuWave, true>::run(P, w, lds);
+        if (P.tune & 2u) { if (has_t) LevBits2<EmuWave, true, true>::run(P, w, lds); else LevBits2<EmuWave, false, true>::run(P, w, lds); }
+        else if (has_t) LevBits2<EmuWave, true>::run(P, w, lds);
         else LevBits2<EmuWave, false>::run(P, w, lds);
+    }
+    free(lds);
+    return 0;
+}
+
+// ---- small alphabets (lev_bitsq_body.h): fixed-length batches, the match vector from per-symbol tables
+#include "lev_bitsq_body.h"
+
+// out entries of pairs that hold a byte outside the alphabet stay untouched; bad_out[0] = their number, bad_out[1..] = the pairs
+extern "C" int emu_lev_bitsq(const uint8_t *a_blob, uint64_t a_len, const uint8_t *b_blob, uint64_t b_len, const uint32_t *subset,
+                             uint32_t n, uint32_t k, int has_t, const uint8_t *sym, uint32_t n_sym, uint32_t *out, uint32_t *bad_out) {
+    const uint64_t max_len = a_len > b_len ? a_len : b_len;
+    uint32_t u = 0;
+    if (!lev_bitsq_applies(k, 1, 1, 0, has_t != 0, 1, max_len, true, LEV_BITSQ_MIN_PAIRS, &u)) return 1;
+    LevParams P;
+    P.a = StrView{a_blob, nullptr, a_len, a_len};
+    P.b = StrView{b_blob, nullptr, b_len, b_len};
+    P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
+    P.u = u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = LevBitsQ<EmuWave, false>::LDS_PER_WAVE; P.Tw = 0; P.ch = 0;
+    if (!lev_bitsq_hash(sym, n_sym, &P.q_shift, &P.q_table)) return 3;
+    bad_out[0] = 0;
+    P.q_bad_count = bad_out; P.q_bad_list = bad_out + 1;
+    uint8_t *lds = (uint8_t *)malloc(P.lds_per_wave + 64);
+    const uint32_t waves = (n + 63) / 64;
+    for (uint32_t w = 0; w < waves; w++) {
+        memset(lds, 0xA5, P.lds_per_wave + 64);            // LDS starts out as garbage on the device
+        if (has_t) LevBitsQ<EmuWave, true>::run(P, w, lds);
+        else LevBitsQ<EmuWave, false>::run(P, w, lds);
     }
     free(lds);
     return 0;

@@ -182,6 +182,29 @@ struct EmuWave {
         }
         return r;
     }
+    static U32 perm_sel(const U32 &hi, const U32 &lo, const U32 &sel) {        // selectors 0..7 only
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            const uint64_t src = ((uint64_t)hi.v[i] << 32) | lo.v[i];
+            uint32_t o = 0;
+            for (int k = 0; k < 4; k++) o |= (uint32_t)((src >> (8 * ((sel.v[i] >> (8 * k)) & 7u))) & 0xffu) << (8 * k);
+            r.v[i] = o;
+        }
+        return r;
+    }
+    static U32 shr_u(const U32 &x, uint32_t s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] >> (s & 31u); return r; }
+    static U32 alignbit_rt(const U32 &hi, const U32 &lo, uint32_t s) {
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> (s & 31u)); return r;
+    }
+    static void lds_read64(const uint8_t *lds, const U32 &off, U32 &lo, U32 &hi) {
+        for (int i = 0; i < 64; i++) { memcpy(&lo.v[i], lds + off.v[i], 4); memcpy(&hi.v[i], lds + off.v[i] + 4, 4); }
+    }
+    static void lds_write16(uint8_t *lds, const U32 &off, const U32 &v) {
+        for (int i = 0; i < 64; i++) { const uint16_t h = (uint16_t)v.v[i]; memcpy(lds + off.v[i], &h, 2); }
+    }
+    static void append_u32(uint32_t *list, uint32_t *counter, const U32 &v, const Bool &pred) {
+        for (int i = 0; i < 64; i++) if (pred.v[i]) list[(*counter)++] = v.v[i];
+    }
     static U32 and_or(const U32 &a, uint32_t m, const U32 &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m) | c.v[i]; return r; }
     template <int N>
     static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }

@@ -131,6 +131,12 @@ def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
+def bits_set_tune(bits):
+    """LevParams::tune for the bit-parallel bodies (2: early out)."""
+    lib().emu_bits_set_tune.argtypes = [C.c_uint32]
+    lib().emu_bits_set_tune(bits)
+
+
 def lev_bits2(a2d, b2d, k, trans=False, subset=None):
     """Two pairs per lane (lev_bits2_body.h) on a fixed-length batch; None when the planner declines (band wider than 15)."""
     a2d, b2d = np.ascontiguousarray(a2d, dtype=np.uint8), np.ascontiguousarray(b2d, dtype=np.uint8)
@@ -150,6 +156,32 @@ def lev_bits2(a2d, b2d, k, trans=False, subset=None):
         raise RuntimeError("emu_lev_bits2 rc=%d" % rc)
     res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
+
+
+def lev_bitsq(a2d, b2d, k, alphabet, trans=False, subset=None):
+    """Small-alphabet form (lev_bitsq_body.h) on a fixed-length batch -> (results with 'untouched' where a pair holds a byte outside
+    the alphabet, sorted list of those pairs); (None, None) when the planner declines or the alphabet has no code hash."""
+    a2d, b2d = np.ascontiguousarray(a2d, dtype=np.uint8), np.ascontiguousarray(b2d, dtype=np.uint8)
+    n_all, la = a2d.shape
+    lb = b2d.shape[1]
+    ab = np.concatenate([a2d.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    bb = np.concatenate([b2d.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    out = np.full(n_all, 0xDEADBEEF, dtype=np.uint32)
+    bad = np.zeros(n_all + 1, dtype=np.uint32)
+    sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
+    n = n_all if sub is None else len(sub)
+    f = lib().emu_lev_bitsq
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32,
+                  C.c_void_p, C.c_void_p]
+    rc = f(ab.ctypes.data, la, bb.ctypes.data, lb, None if sub is None else sub.ctypes.data, n, k, int(bool(trans)), bytes(alphabet),
+           len(alphabet), out.ctypes.data, bad.ctypes.data)
+    if rc in (1, 3):
+        return None, None
+    if rc:
+        raise RuntimeError("emu_lev_bitsq rc=%d" % rc)
+    res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
+    return res, sorted(int(x) for x in bad[1:1 + int(bad[0])])
 
 
 def lev_one(a, b, k, trans=False):

@@ -326,3 +326,91 @@ def test_emu_lev_one_edges():
     x = bytes(range(256)) * 4
     y = x[1:] + bytes([0])
     assert E.lev_one(x, x, 0, False) == 0 and E.lev_one(x, y, 2, False) == O.levenshtein_naive_k_with_opts(x, y, 2, False, LEV)[0] == 2
+
+
+# ---- early out (LevParams::tune bit 1): same answers, the wavefront stops once none of its pairs can end at or below k
+@pytest.mark.parametrize("la,lb,k,trans", [(256, 256, 32, False), (256, 250, 30, True), (400, 400, 25, False), (128, 128, 8, True),
+                                           (128, 128, 8, False), (200, 207, 12, False), (300, 300, 4, True), (96, 96, 0, False)])
+def test_emu_early_out_same_answers(la, lb, k, trans):
+    """Waves of far pairs only (they stop early), of near pairs only, and mixed ones (one near pair keeps its wavefront going)."""
+    g = Dg.rng(la + lb + k)
+    n = 64 * 5 + 17
+    a, b = _fixed_batch(la * 7 + k, n, la, lb, k, swaps=trans)                 # near pairs ...
+    far = np.zeros(n, dtype=bool)
+    far[:128] = True                                                           # ... two wavefronts of random (far) pairs ...
+    far[192:256] = g.random(64) < 0.9                                          # ... and a mixed one
+    b[far] = g.integers(33, 127, size=(int(far.sum()), lb), dtype=np.uint8)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(n)]
+    try:
+        E.bits_set_tune(2)
+        got, plan = E.lev_bits_fixed(a, b, k, trans)
+        assert got == want, (plan, [(i, x, y) for i, (x, y) in enumerate(zip(got, want)) if x != y][:5])
+        got2, _ = E.lev_bits2(a, b, k, trans)
+        if got2 is not None:
+            assert got2 == want
+    finally:
+        E.bits_set_tune(0)
+    assert any(w is None for w in want[:128]) and any(w is not None for w in want[256:])
+
+
+# ---- small alphabets (lev_bitsq_body.h): the match vector from per-symbol tables
+def _dna_batch(seed, n, la, lb, k, alphabet, swaps=False):
+    g = Dg.rng(seed)
+    sym = np.frombuffer(bytes(alphabet), dtype=np.uint8)
+    a = sym[g.integers(0, len(sym), size=(n, la))]
+    b = np.empty((n, lb), dtype=np.uint8)
+    for i in range(n):
+        r = i % 4
+        if r == 0:
+            b[i] = sym[g.integers(0, len(sym), size=lb)]                       # unrelated
+        else:
+            s = bytearray(a[i].tobytes())
+            for _ in range(int(g.integers(0, k + 2))):
+                t = int(g.integers(0, 4 if swaps else 3))
+                p = int(g.integers(0, max(1, len(s))))
+                if t == 0 and s: s[p] = int(sym[g.integers(0, len(sym))])
+                elif t == 1: s.insert(p, int(sym[g.integers(0, len(sym))]))
+                elif t == 2 and s: del s[p]
+                elif t == 3 and len(s) > 1 and p + 1 < len(s): s[p], s[p + 1] = s[p + 1], s[p]
+            s = (bytes(s) + sym[g.integers(0, len(sym), size=lb)].tobytes())[:lb]
+            b[i] = np.frombuffer(s, dtype=np.uint8)
+    return a, b
+
+
+@pytest.mark.parametrize("la,lb,k,trans,alphabet", [
+    (256, 256, 32, False, b"ACGT"), (256, 256, 30, True, b"ACGT"), (128, 128, 8, True, b"acgt"), (100, 97, 12, False, b"ACGU"),
+    (100, 110, 20, True, b"ACGT"), (300, 300, 31, False, b"TGCA"), (513, 520, 25, False, b"ACGT"), (64, 64, 0, False, b"AC"),
+    (40, 40, 5, True, bytes([0, 1, 2, 3])), (17, 30, 14, False, b"ACG"), (1, 1, 1, False, b"A"), (1000, 1000, 7, True, b"ACGT"),
+    (255, 257, 32, False, b"ACGT"), (129, 160, 32, False, b"ACGT"), (160, 129, 30, True, b"ACGT")])
+def test_emu_bitsq_small_alphabets(la, lb, k, trans, alphabet):
+    n = 64 * 3 + 9
+    a, b = _dna_batch(la * 5 + lb + k, n, la, lb, k, alphabet, swaps=trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(n)]
+    got, bad = E.lev_bitsq(a, b, k, alphabet, trans)
+    assert got is not None, "declined"
+    assert bad == [] and got == want, (bad[:5], [(i, x, y) for i, (x, y) in enumerate(zip(got, want)) if x != y][:5])
+
+
+def test_emu_bitsq_foreign_bytes_and_subsets():
+    """Pairs with a byte outside the alphabet -- anywhere in either string, the last byte included -- are left to the caller's
+    fallback (listed, out untouched); the others are answered.  Alphabets without a code hash and wide bands are declined."""
+    a, b = _dna_batch(7, 200, 150, 150, 20, b"ACGT")
+    foreign = {3: (0, 0), 64: (1, 149), 65: (0, 77), 130: (1, 16), 199: (0, 149)}
+    for i, (which, pos) in foreign.items():
+        (a if which == 0 else b)[i, pos] = ord("N")
+    got, bad = E.lev_bitsq(a, b, 20, b"ACGT")
+    assert bad == sorted(foreign)
+    for i in range(200):
+        if i in foreign:
+            assert got[i] == "untouched"
+        else:
+            assert got[i] == O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 20, False, (1, 1, 0, None))[0], i
+    assert E.lev_bitsq(a, b, 20, b"@AQP")[0] is None            # 0x40 0x41 0x51 0x50: no two adjacent bits tell the four apart
+    assert E.lev_bitsq(a, b, 33, b"ACGT")[0] is None and E.lev_bitsq(a, b, 31, b"ACGT", trans=True)[0] is None
+    sub = np.arange(0, 200, 3, dtype=np.uint32)
+    got, bad = E.lev_bitsq(a, b, 20, b"ACGT", subset=sub)
+    assert bad == [i for i in sorted(foreign) if i % 3 == 0]
+    for i in range(200):
+        assert (got[i] == "untouched") == (i % 3 != 0 or i in foreign)

@@ -452,3 +452,75 @@ def test_single_pair_kernel(monkeypatch, costs):
     assert seen > 150
     monkeypatch.delenv("TA_NO_ONE", raising=False)
     assert T.levenshtein(b"kitten", b"sitting") == 3 and kernel_id() == 6          # unbounded k on short strings clamps into the band
+
+
+@pytest.mark.parametrize("L,k,costs", [(256, 32, LEV), (128, 8, RDAM), (200, 20, RDAM)])
+def test_early_out_option_same_answers(L, k, costs):
+    """ta_set_option(TA_OPT_EARLY_OUT): wavefronts of far pairs stop after a few dozen columns, wavefronts that hold a near pair
+    run on -- the answers are those of the default pass, pair by pair, and the oracle's on a sample."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n = 300_000 + 33
+    g = Dg.rng(L + k)
+    a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
+    b = g.integers(33, 127, size=(n, L), dtype=np.uint8)
+    near = g.random(n) < 0.02                                                  # most wavefronts hold far pairs only
+    near[:20000] = g.random(20000) < 0.5
+    b[near] = a[near]
+    pos = g.integers(0, L, size=(n, max(1, k // 2)))
+    rows = np.nonzero(near)[0]
+    b[rows[:, None], pos[rows]] = 32
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    base = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    try:
+        T.set_option(T.OPT_EARLY_OUT, True)
+        got = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    finally:
+        T.set_option(T.OPT_EARLY_OUT, False)
+    assert np.array_equal(got, base)
+    ns = 20000
+    assert np.array_equal(got[:ns], O.levenshtein_k_batch(O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns]), k, costs))
+    assert (base != 0xFFFFFFFF).sum() > 1000 and (base == 0xFFFFFFFF).sum() > 1000
+
+
+@pytest.mark.parametrize("L,Lb,k,costs,alphabet", [(256, 256, 32, LEV, b"ACGT"), (128, 128, 8, RDAM, b"ACGT"), (200, 190, 30, RDAM, b"acgu"),
+                                                   (96, 100, 20, LEV, b"TG")])
+def test_small_alphabet_kernel(L, Lb, k, costs, alphabet):
+    """levenshtein_k_batch(..., alphabet=...): the table-lookup kernel (lev_bitsq_body.h) against the oracle on a sample and pair by
+    pair against the byte-test kernels; pairs that hold a byte outside the alphabet (here: 'N', first / last / middle positions)
+    are answered by the general kernel inside the same call."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n = 200_000 + 21
+    g = Dg.rng(L + Lb + k)
+    sym = np.frombuffer(alphabet, dtype=np.uint8)
+    a = sym[g.integers(0, len(sym), size=(n, L))]
+    b = sym[g.integers(0, len(sym), size=(n, Lb))]
+    m = min(L, Lb)
+    near = g.random(n) < 0.6
+    b[near, :m] = a[near, :m]
+    for row in np.nonzero(near)[0][:20000]:
+        s = Dg.mutate(g, bytes(b[row]), int(g.integers(0, k + 3)), swaps=costs[3] is not None)
+        s = bytes(int(sym[c % len(sym)]) if c not in sym else c for c in s)       # mutate() writes spaces / printable bytes: fold them into the alphabet
+        s = (s + sym[g.integers(0, len(sym), size=Lb)].tobytes())[:Lb]
+        b[row] = np.frombuffer(s, dtype=np.uint8)
+    foreign = g.choice(n, size=300, replace=False)
+    for t, row in enumerate(foreign):
+        (a if t % 2 else b)[row, [0, (Lb if t % 2 == 0 else L) - 1, m // 2][t % 3]] = ord("N")
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    got = B.levenshtein_k_batch(sa, sb, k, costs, alphabet=alphabet).cpu().numpy().view(np.uint32)
+    info = T.last_launch_info()
+    assert info["kernel"] == 7 and T.last_kernel_name().startswith("lev_bitsq_kernel"), (info, T.last_kernel_name())
+    base = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    assert T.last_launch_info()["kernel"] == 3
+    assert np.array_equal(got, base), np.flatnonzero(got != base)[:10]
+    ns = 20000
+    assert np.array_equal(got[:ns], O.levenshtein_k_batch(O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns]), k, costs))
+    fr = np.sort(foreign)[:200]
+    assert np.array_equal(got[fr], O.levenshtein_k_batch(O.csr_from_fixed(a[fr]), O.csr_from_fixed(b[fr]), k, costs))
+    assert (base != 0xFFFFFFFF).sum() > 1000 and (base == 0xFFFFFFFF).sum() > 1000
+    # what the kernel does not cover runs the general path: wide bands, general costs, alphabets without a two-bit code
+    for kk, cc, al in [(40, costs, alphabet), (k, (2, 3, 1, None), alphabet), (k, costs, b"ACGTN"), (k, costs, b"@AQP")]:
+        out = B.levenshtein_k_batch(sa, sb, kk, cc, alphabet=al).cpu().numpy().view(np.uint32)
+        assert T.last_launch_info()["kernel"] != 7
+        assert np.array_equal(out[:2000], O.levenshtein_k_batch(O.csr_from_fixed(a[:2000]), O.csr_from_fixed(b[:2000]), kk, cc))

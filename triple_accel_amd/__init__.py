@@ -299,6 +299,15 @@ def last_kernel_name():
     return _n.lib().ta_last_kernel_name().decode()
 
 
+OPT_EARLY_OUT = 1
+
+
+def set_option(option, value):
+    """Options of the calling thread (include/triple_accel_amd.h): OPT_EARLY_OUT -- the band kernels of fixed-length unit-cost
+    batches stop a wavefront once none of its pairs can end at or below k (same answers, data-dependent work)."""
+    _n.check(_n.lib().ta_set_option(int(option), int(bool(value))))
+
+
 def device_count():
     return int(_n.lib().ta_device_count())
 

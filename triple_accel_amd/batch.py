@@ -72,11 +72,19 @@ def _out(n, device):
     return torch.empty(n, dtype=torch.int32, device=device)
 
 
-def levenshtein_k_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, out=None):
-    """out[i] = levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) as int32 (-1 == None)."""
+def levenshtein_k_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, out=None, alphabet=None):
+    """out[i] = levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) as int32 (-1 == None).
+    alphabet: the (at most four) byte values the strings are written in, e.g. b"ACGT": the small-alphabet kernel (same answers;
+    pairs with other bytes are still answered, by the general kernel)."""
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out
     cc = _costs(costs)._c()
+    if alphabet is not None:
+        alphabet = bytes(alphabet)
+        rc = _n.lib().ta_levenshtein_k_batch_alphabet(a._ref(), b._ref(), a.n, k, _C.byref(cc), alphabet, len(alphabet), out.data_ptr(), _stream())
+        if rc:
+            _raise(rc)
+        return out
     rc = _n.lib().ta_levenshtein_k_batch(a._ref(), b._ref(), a.n, k, _C.byref(cc), out.data_ptr(), _stream())
     if rc:
         _raise(rc)

@@ -47,6 +47,11 @@ struct LevParams {
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
     uint32_t ch;              // bytes per string per streamed chunk
     uint32_t tune = 0;        // bit 0: chunk form of the bit-parallel band kernel's fetch also for fixed-length batches (set by the launcher)
+                              // bit 1: early out of the bit-parallel band kernels (ta_set_option(TA_OPT_EARLY_OUT, 1))
+    uint32_t q_table = 0, q_shift = 0;       // lev_bitsq: byte c of q_table = the symbol with code c, code = (byte >> q_shift) & 3
+    uint32_t *q_bad_count = nullptr, *q_bad_list = nullptr;   // lev_bitsq: the pairs that hold a byte outside the alphabet
+    uint32_t *q_next_count = nullptr;        // lev_bitsq: the NEXT pass's counter, zeroed by this pass (two counters taken in turn)
+    const uint32_t *n_dev = nullptr;         // bit-parallel band kernels: the number of pairs, read on the device (a list a kernel before wrote)
     uint32_t *bnd = nullptr;  // lev_widebits: per wave 6 boundary lines of bnd_line u32 (strings spanning several stripes)
     uint64_t bnd_line = 0;
     uint64_t trace_cols = 0;  // lev_widebits TRACE: columns per stripe in P.trace (>= b_len + 64)

@@ -15,41 +15,49 @@ constexpr int BITS_WAVES_PER_BLOCK = 4;
 template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
-    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    LevParams Q = P;
+    if (P.n_dev) Q.n = *P.n_dev;                       // the pairs of a list a kernel before this one wrote (lev_bitsq's fallback)
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (Q.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, lists of unknown length)
     for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
-        LevBits<DevWave, NA, TRANS, STATIC>::run(P, w, lds + wave * P.lds_per_wave);
+        LevBits<DevWave, NA, TRANS, STATIC>::run(Q, w, lds + wave * P.lds_per_wave);
 }
 
 // line-form launches (fixed-length batches of strings longer than one line)
 template <int NA, bool TRANS, bool STATIC>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_line_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
-    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    LevParams Q = P;
+    if (P.n_dev) Q.n = *P.n_dev;                       // the pairs of a list a kernel before this one wrote (lev_bitsq's fallback)
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (Q.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, lists of unknown length)
     for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
-        LevBits<DevWave, NA, TRANS, STATIC, true>::run(P, w, lds + wave * P.lds_per_wave);
+        LevBits<DevWave, NA, TRANS, STATIC, true>::run(Q, w, lds + wave * P.lds_per_wave);
 }
 
 // stride-8 form (bands of up to 33 diagonals), either fetch form
-template <bool TRANS, bool LINE>
+template <bool TRANS, bool LINE, bool EARLY = false>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
-    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, profiles/r03/ab_band_kernel.md)
+    LevParams Q = P;
+    if (P.n_dev) Q.n = *P.n_dev;                       // the pairs of a list a kernel before this one wrote (lev_bitsq's fallback)
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (Q.n + 63u) >> 6;
+    // one trip when the grid covers the batch; a smaller (persistent) grid strides over it (TA_BITS_PERSIST, lists of unknown length)
     for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
-        LevBits<DevWave, 8, TRANS, false, LINE, true>::run(P, w, lds + wave * P.lds_per_wave);
+        LevBits<DevWave, 8, TRANS, false, LINE, true, EARLY>::run(Q, w, lds + wave * P.lds_per_wave);
 }
 
-template <bool TRANS>
+template <bool TRANS, bool EARLY = false>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
-    LevBits2<DevWave, TRANS>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    LevBits2<DevWave, TRANS, EARLY>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
 }
 
 // two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront
-hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
+hipError_t lev_bits2_launch(const LevParams &P0, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
+    LevParams P = P0;
+    if (early_out_enabled()) P.tune |= 2u;
     uint32_t wpb = 2;                               // cfg4: 0.1180 ms against 0.1195 with one or four wavefronts per block
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t waves = (P.n + 127u) / 128u, grid = (waves + wpb - 1) / wpb;
@@ -58,9 +66,13 @@ hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool tra
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
     dim3 g(grid), b(64 * wpb);
-    set_last_kernel_name("lev_bits2_kernel<%s>", trans ? "true" : "false");
-    if (trans) hipLaunchKernelGGL(lev_bits2_kernel<true>, g, b, lds, s, P);
-    else hipLaunchKernelGGL(lev_bits2_kernel<false>, g, b, lds, s, P);
+    const bool early = (P.tune & 2u) != 0u;
+    set_last_kernel_name("lev_bits2_kernel<%s, %s>", trans ? "true" : "false", early ? "true" : "false");
+    if (early) {
+        if (trans) hipLaunchKernelGGL((lev_bits2_kernel<true, true>), g, b, lds, s, P);
+        else hipLaunchKernelGGL((lev_bits2_kernel<false, true>), g, b, lds, s, P);
+    } else if (trans) hipLaunchKernelGGL((lev_bits2_kernel<true, false>), g, b, lds, s, P);
+    else hipLaunchKernelGGL((lev_bits2_kernel<false, false>), g, b, lds, s, P);
     return hipGetLastError();
 }
 
@@ -101,6 +113,7 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     // line the chunk form has nothing to refetch and its coarser events (one per 64 columns, not per 16) are cheaper:
     // cfg4 0.150 ms against 0.180 ms (profiles/r02/ab_band_kernel.md).  TA_BITS_NO_COOP=1 pins the chunk form.
     if (max_len <= 128u || env_int("TA_BITS_NO_COOP")) P.tune |= 1u;
+    if (early_out_enabled()) P.tune |= 2u;
     const bool line_form = !P.a.off && !P.b.off && !(P.tune & 1u);
     if (pl.s8 && line_form) P.lds_per_wave = 64u * (52u + 36u);       // the stride-8 line form's small rings (lev_bits_body.h)
     const uint32_t waves = (P.n + 63u) / 64u;
@@ -112,6 +125,7 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     uint32_t grid = (waves + wpb - 1) / wpb;
     if (const char *e = env_str("TA_BITS_PERSIST")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < grid) grid = (uint32_t)v; }   // A/B: persistent grid
+    if (P.n_dev && grid > 512u) grid = 512u;           // a list whose length only the device knows (usually empty): a small striding grid
     // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
     // (12 waves) per CU instead of four -- a quarter fewer pairs in flight lets the 4 MB L2 keep more lines until their second
     // half is read.  Fixed-length batches (line form: every line requested once) run the four blocks the LDS allows: 16 waves
@@ -124,11 +138,15 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
-    if (pl.s8) set_last_kernel_name("lev_bits_s8_kernel<%s, %s>", trans ? "true" : "false", line_form ? "true" : "false");
+    const bool early = line_form && pl.s8 && (P.tune & 2u) != 0u;
+    if (pl.s8) set_last_kernel_name("lev_bits_s8_kernel<%s, %s, %s>", trans ? "true" : "false", line_form ? "true" : "false", early ? "true" : "false");
     else set_last_kernel_name("%s<%d, %s, %s>", line_form ? "lev_bits_line_kernel" : "lev_bits_kernel", pl.NA, trans ? "true" : "false", pl.stat ? "true" : "false");
     if (pl.s8) {
         dim3 g(grid), b(64 * wpb);
-        if (trans) { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<true, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<true, false>), g, b, lds, s, P); }
+        if (early) {
+            if (trans) hipLaunchKernelGGL((lev_bits_s8_kernel<true, true, true>), g, b, lds, s, P);
+            else hipLaunchKernelGGL((lev_bits_s8_kernel<false, true, true>), g, b, lds, s, P);
+        } else if (trans) { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<true, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<true, false>), g, b, lds, s, P); }
         else { if (line_form) hipLaunchKernelGGL((lev_bits_s8_kernel<false, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_kernel<false, false>), g, b, lds, s, P); }
         return hipGetLastError();
     }

@@ -32,7 +32,7 @@
 
 namespace ta {
 
-template <class W, bool TRANS>
+template <class W, bool TRANS, bool EARLY = false>
 struct LevBits2 {
     static constexpr int WB = 15;                              // window bits per pair (bit 15 / 31: the spare row)
     static constexpr uint32_t WM = (1u << WB) - 1u, WM2 = WM | (WM << 16);
@@ -198,6 +198,8 @@ struct LevBits2 {
             }
         };
 
+        const bool early = EARLY && (P.tune & 2u) != 0u && P.k < 0x7FFFFFFFu;               // stop once no pair of the wavefront can end at or below k (lev_bits_body.h)
+        bool dead = false;
         if (inband) {
             uint32_t tp = (uint32_t)ca_s & ~7u;                // whole blocks: the extra leading iterations slide bytes in that leave again
             const uint32_t tb0 = tp & ~15u;
@@ -209,6 +211,12 @@ struct LevBits2 {
             for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
             for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
             for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
+                if (EARLY && early && tb > T0 && (tb & 16u) == 0u) {    // every 32 columns (lev_bits_body.h, EARLY OUT): tb - T0 columns are done
+                    const U32 topA = W::splat(dhi + (tb - T0)) - (st.cnt & 0xFFFFu), topB = W::splat(dhi + (tb - T0)) - (st.cnt >> 16);
+                    const Bool liveA = valid[0] & (topA <= W::bcnt(st.VN & WM, W::splat(P.k)));
+                    const Bool liveB = valid[1] & (topB <= W::bcnt(st.VN & (WM << 16), W::splat(P.k)));
+                    if (!W::any(liveA | liveB)) { dead = true; break; }
+                }
                 commit_a(qa + RA - 1);                         // into the slot of piece qa - 1, which the last span finished
                 commit_b(qb + RB - 1);
                 W::lds_wave_sync();
@@ -226,7 +234,7 @@ struct LevBits2 {
         const U32 downB = W::bcnt(st.VP & (mb << 16), zero) - W::bcnt(st.VN & (mb << 16), zero);
         const U32 base = W::splat(dhi + blen_u);               // the top diagonal starts at d_hi; + columns - zero steps + way down
         const U32 dA = base - (st.cnt & 0xFFFFu) + downA, dB = base - (st.cnt >> 16) + downB;
-        const Bool ok = W::splat(inband ? 1u : 0u) != 0u;
+        const Bool ok = W::splat(inband && !dead ? 1u : 0u) != 0u;
         W::store_u32(P.out, pair[0], W::sel(ok & (dA <= P.k), dA, W::splat(0xFFFFFFFFu)), valid[0]);
         W::store_u32(P.out, pair[1], W::sel(ok & (dB <= P.k), dB, W::splat(0xFFFFFFFFu)), valid[1]);
     }

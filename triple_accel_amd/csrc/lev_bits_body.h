@@ -42,7 +42,7 @@ namespace ta {
 //     register that wraps around (one v_perm_b32); the loop is unrolled 8 columns so the names are fixed: no moves at all;
 //   * the 33rd diagonal is the ONEBIT one (below): its byte is the one about to enter, its match a v_cmp on that byte.
 // 39 VALU instructions per column instead of 48 (static form).
-template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false>
+template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false>
 struct LevBits {
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static_assert(!S8 || (NA == 8 && !STATIC), "the stride-8 form is its own window layout: 8 registers, 33 diagonals");
@@ -237,6 +237,16 @@ struct LevBits {
             return t;
         };
         U32 tail = way_down();                                 // (column 0: a pair without columns ends here)
+        // EARLY OUT (P.tune bit 1; fixed-length batches in the stride-8 line form): a cell of the column just finished is its top
+        // diagonal's cell plus the vertical steps above it, so no cell of the column is below  top - popcount(VN).  Once that
+        // bound exceeds k in every pair of the wavefront no pair can end at or below k any more -- every alignment of cost <= k
+        // stays inside the band and passes through this column -- and the wavefront stops: the answers are None either way
+        // (src/levenshtein.rs:539-541).  Checked when the zero-step register is counted (every 24-32 columns).  Its own kernel
+        // instantiation (EARLY), launched only under ta_set_option(TA_OPT_EARLY_OUT): the reference evaluates the whole band
+        // whatever the data, and so do the default kernel and the benchmark.
+        static_assert(!EARLY || (S8 && LINE), "the early out lives in the stride-8 line form");
+        const bool early = EARLY && (P.tune & 2u) != 0u && P.k < 0x7FFFFFFFu;
+        bool dead = false;
 
         // iteration tp inserts a[tp - ca] into the window and, from tp = T0 on, runs column tp - T0 + 1 with b[tp - T0]
         const uint32_t T0 = P.Tw;
@@ -269,7 +279,13 @@ struct LevBits {
                 const bool cap = UNI ? false : W::any(t_stop < p_hi);
                 if (!cap) {
                     for (; tp + 8u <= p_hi; tp += 8u) {    // the hot loop: whole blocks, every pair live
-                        if (__builtin_expect(nacc > 24u, 0)) flush();
+                        if (__builtin_expect(nacc > 24u, 0)) {
+                            flush();
+                            if (EARLY && UNI && early) {   // tp - T0 columns are done
+                                const U32 top = (dhi + (tp - T0)) - cnt;
+                                if (!W::any(valid & inband & (top <= W::bcnt(st.VN[0], W::splat(P.k))))) { dead = true; return tp; }
+                            }
+                        }
                         const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
                         const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
                         const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
@@ -433,6 +449,7 @@ struct LevBits {
                     tp = run_span(tp, b_hi,
                                   [&](uint32_t t) { return a_slot + fmod((int32_t)t - ca_s, 16 * RA); },
                                   [&](uint32_t t) { return b_slot + fmod((int32_t)t - (int32_t)T0, 16 * RB); }, std::true_type());
+                    if (dead) break;
                 }
             }
             tail = way_down();                                  // every pair's last column was the last one run
@@ -509,7 +526,7 @@ struct LevBits {
 
         if (nacc) flush();
         const U32 d = (dhi + blen) - cnt + tail;               // the top diagonal starts at d_hi; + columns - zero-difference steps + way down
-        const Bool some = inband & (d <= P.k);                 // :539-541, :1166-1168
+        const Bool some = inband & (d <= P.k) & (W::splat(dead ? 1u : 0u) == 0u);                 // :539-541, :1166-1168
         W::store_u32(P.out, pair, W::sel(some, d, W::splat(0xFFFFFFFFu)), valid);
     }
 };

@@ -1,6 +1,7 @@
 // lev_plan.h -- host-side launch planning for the band-wavefront kernel (lev_band_body.h).
 // Pure integer logic, shared by the product's C ABI (ta_api.hip) and the test-only emulation.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace ta {
@@ -153,6 +154,42 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
     p.Tw = (p.u + (has_t ? 1u : 0u) + 2u + 63u) & ~63u;        // (the stream of `a` runs two iterations ahead of the window's last row)
     p.lds_per_wave = 128u * (36u + 20u);                       // rings of 2 + 1 sixteen-byte pieces per pair (+ wrap copies)
     return p;
+}
+
+// ---- small alphabets (lev_bitsq_body.h): fixed-length unit-cost batches whose band (+ the transposition test's two extra rows) fits
+// the 33-diagonal window; the caller names at most four symbols (the launcher checks that a code hash exists for them)
+constexpr uint32_t LEV_BITSQ_MIN_PAIRS = 16384;
+static inline bool lev_bitsq_applies(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len,
+                                     bool fixed_length, uint64_t pairs, uint32_t *u_out) {
+    const uint32_t u = lev_batch_unit_k(k, mc, gc, sg, max_len);
+    if (u_out) *u_out = u;
+    return mc == 1 && gc == 1 && sg == 0 && (!has_t || tc == 1) && fixed_length && (uint64_t)u + 1u + (has_t ? 2u : 0u) <= 33u &&
+           max_len >= 1 && max_len <= 0x7FFFFF00ull && pairs >= LEV_BITSQ_MIN_PAIRS;
+}
+
+// h in 0..6 with ((s >> h) & 3) distinct over the n <= 4 distinct symbols, and the table whose byte c is the symbol of code c
+// (a byte that does NOT hash to c where no symbol does: nothing matches it).  false: no such shift (or bad arguments).
+static inline bool lev_bitsq_hash(const uint8_t *sym, size_t n, uint32_t *shift_out, uint32_t *table_out) {
+    if (!sym || n == 0 || n > 4) return false;
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = i + 1; j < n; j++)
+            if (sym[i] == sym[j]) return false;
+    for (uint32_t h = 0; h <= 6; h++) {
+        uint32_t seen = 0, table = 0;
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) {
+            const uint32_t c = (sym[i] >> h) & 3u;
+            if (seen & (1u << c)) ok = false;
+            seen |= 1u << c;
+            table |= (uint32_t)sym[i] << (8 * c);
+        }
+        if (!ok) continue;
+        for (uint32_t c = 0; c < 4; c++)
+            if (!(seen & (1u << c))) table |= ((((c + 1u) & 3u) << h) & 0xFFu) << (8 * c);
+        *shift_out = h; *table_out = table;
+        return true;
+    }
+    return false;
 }
 
 // ---- ONE pair, band of at most 64 diagonals (lev_one_body.h: match vectors 64 columns at a time, the recurrence on the scalar unit)

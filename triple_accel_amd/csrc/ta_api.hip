@@ -133,6 +133,9 @@ int env_int(const char *name) {
     return v ? atoi(v) : 0;
 }
 
+static thread_local bool g_opt_early_out = false;
+bool early_out_enabled() { return g_opt_early_out || env_int("TA_EARLY_OUT"); }
+
 static bool costs_ok(const ta_edit_costs *c) {   // EditCosts::new, src/levenshtein.rs:44-52
     if (!c) return false;
     if (!(c->mismatch_cost > 0) || !(c->gap_cost > 0)) return false;
@@ -343,6 +346,11 @@ int ta_device_count(void) {
 
 const char *ta_last_error(void) { return g_last_error.c_str(); }
 const char *ta_last_kernel_name(void) { return g_last_kernel_name; }
+int ta_set_option(int option, int value) {
+    if (option == TA_OPT_EARLY_OUT) { g_opt_early_out = value != 0; return TA_OK; }
+    set_last_error_msg("unknown option");
+    return TA_ERR_ARG;
+}
 
 ta_edit_costs ta_levenshtein_costs(void) { ta_edit_costs c = {1, 1, 0, 0, 0}; return c; }
 ta_edit_costs ta_rdamerau_costs(void) { ta_edit_costs c = {1, 1, 0, 1, 1}; return c; }
@@ -435,6 +443,72 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
         order = (const uint32_t *)ord.dev;
     }
     return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st);
+}
+
+/* ta_levenshtein_k_batch for strings written in a SMALL ALPHABET the caller names (at most four distinct byte values: DNA, RNA):
+ * the column's match vector is then a table lookup (lev_bitsq_body.h) instead of a byte test -- the same answers, bit for bit.
+ * The promise is verified on the device, byte by byte: a pair that holds any other byte is answered by the general kernel in the
+ * same call (a second, usually empty, launch over the list of such pairs; no host round trip).  Batches the small-alphabet kernel
+ * does not cover (CSR batches, general EditCosts, bands beyond 33 diagonals, fewer than 16384 pairs, alphabets of more than four
+ * symbols or without a two-bit code) run ta_levenshtein_k_batch as they are. */
+int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                    const uint8_t *alphabet, size_t alphabet_len, uint32_t *out_dev, void *stream) {
+    int rc = check_batch_args(a, b, n, out_dev);
+    if (rc) return rc;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (n == 0) return TA_OK;
+    const bool fixed = !a->off && !b->off;
+    const bool trans = costs->has_transpose != 0;
+    const uint64_t max_len = fixed ? (a->len > b->len ? a->len : b->len) : 0;
+    uint32_t u = 0, q_shift = 0, q_table = 0;
+    const bool pinned = env_int("TA_NO_BITS") || env_int("TA_FORCE_NA") || env_int("TA_BITS_STATIC") || env_int("TA_FORCE_D") || env_int("TA_NO_BITSQ");
+    if (!fixed || pinned || !alphabet ||
+        !lev_bitsq_applies(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, trans ? costs->transpose_cost : 0, max_len, true, n, &u) ||
+        !lev_bitsq_hash(alphabet, alphabet_len, &q_shift, &q_table))
+        return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
+    hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
+    Scratch &bad = tls_scratch(15), &cnt = tls_scratch(16);
+    // two counters taken in turn: this pass appends to one and zeroes the other for the next pass (no fill per call; both are
+    // zeroed once, when the scratch is allocated)
+    static thread_local uint32_t turn = 0;
+    const bool fresh = cnt.cap < 64;
+    if ((rc = bad.ensure(n * 4)) || (rc = cnt.ensure(64))) return rc;
+    if (fresh) { TA_HIP(hipMemsetAsync(cnt.dev, 0, 64, st)); turn = 0; }
+    uint32_t *counters = (uint32_t *)cnt.dev;
+    const uint32_t mine = turn & 1u;
+    turn++;
+    LevParams P;
+    P.a = view_of(a); P.b = view_of(b);
+    P.subset = nullptr; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
+    P.u = u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
+    P.q_table = q_table; P.q_shift = q_shift; P.q_bad_count = counters + 8u * mine; P.q_bad_list = (uint32_t *)bad.dev;
+    P.q_next_count = counters + 8u * (mine ^ 1u);
+    ta_launch_info li = {};
+    li.transpose = trans;
+    ta_lev_select sel;
+    ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
+    li.cell_bits = sel.cell_bits;
+    uint32_t grid = 0, lds = 0;
+    TA_HIP(lev_bitsq_launch(P, trans, st, &grid, &lds));
+    li.kernel = 7; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
+    // the pairs that hold a byte outside the alphabet: the byte-test kernel over the list the first kernel wrote (its length is read
+    // on the device; a small grid strides over it)
+    const LevBitsPlan bp = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 0);
+    LevParams F = P;
+    F.subset = (const uint32_t *)bad.dev; F.n_dev = counters + 8u * mine;
+    F.q_bad_count = nullptr; F.q_bad_list = nullptr; F.q_next_count = nullptr;
+    F.u = bp.u; F.lds_per_wave = bp.lds_per_wave; F.Tw = bp.Tw; F.ch = bp.ch;
+    char name[96];
+    snprintf(name, sizeof(name), "%s", ta_last_kernel_name());
+    TA_HIP(lev_bits_launch(F, bp, trans, max_len, st, nullptr, nullptr));
+    set_last_kernel_name("%s", name);                   // the pass's dominant kernel is the first one
+    if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=%zu k=%u u=%u kernel=7 (small alphabet, shift %u table %08x) grid=%u lds=%u\n", n, k, u, q_shift, q_table, grid, lds);
+    g_last_launch = li;
+    g_answer_single_store = false;
+    return TA_OK;
 }
 
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,

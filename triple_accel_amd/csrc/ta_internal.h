@@ -33,7 +33,7 @@ struct Scratch {
     void release();
     ~Scratch();
 };
-constexpr int TA_SCRATCH_SLOTS = 15;
+constexpr int TA_SCRATCH_SLOTS = 17;
 Scratch &tls_scratch(int which);
 
 // Per-thread context of the single-call host API: its own non-blocking stream (concurrent callers never meet on the null
@@ -64,6 +64,8 @@ bool tuning_enabled();
 const char *env_str(const char *name);
 int env_int(const char *name);
 
+// ta_set_option(TA_OPT_EARLY_OUT) of the calling thread
+bool early_out_enabled();
 // true when a HIP device is usable (lazy, cached)
 bool device_ready();
 
@@ -74,6 +76,7 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s);
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
+hipError_t lev_bitsq_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipStream_t s, uint32_t *lds_out);
 bool lev_sliced_applies(const StrView &a, const StrView &b, uint32_t unit_k, uint32_t *strips_out);

@@ -194,6 +194,21 @@ struct DevWave {
     // bytes picked by the constant selector SEL out of {hi: 4..7, lo: 0..3} (0x0C: the constant 0x00) -> v_perm_b32
     template <uint32_t SEL>
     static __device__ __forceinline__ U32 perm(U32 hi, U32 lo) { return __builtin_amdgcn_perm(hi, lo, SEL); }
+    // the same with a per-lane selector (bytes 0..3: lo, 4..7: hi) -> v_perm_b32
+    static __device__ __forceinline__ U32 perm_sel(U32 hi, U32 lo, U32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+    // x >> s and ({hi,lo} >> s)[31:0] with a wave-uniform run-time s (< 32): v_lshrrev_b32 / v_alignbit_b32 with a scalar shift
+    static __device__ __forceinline__ U32 shr_u(U32 x, uint32_t s) { return x >> s; }
+    static __device__ __forceinline__ U32 alignbit_rt(U32 hi, U32 lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+    // two consecutive lane-private dwords in LDS (4-byte aligned offset) -> ds_read2_b32
+    static __device__ __forceinline__ void lds_read64(const uint8_t *lds, U32 off, U32 &lo, U32 &hi) {
+        const uint32_t *p = (const uint32_t *)(lds + off);
+        lo = p[0]; hi = p[1];
+    }
+    static __device__ __forceinline__ void lds_write16(uint8_t *lds, U32 off, U32 v) { *(uint16_t *)(lds + off) = (uint16_t)v; }
+    // list[(*counter)++] = v in the lanes where pred holds (rare paths: one global atomic per such lane)
+    static __device__ __forceinline__ void append_u32(uint32_t *list, uint32_t *counter, U32 v, Bool pred) {
+        if (pred) list[atomicAdd(counter, 1u)] = v;
+    }
     // (a & m) | c -> v_and_or_b32
     // (hipcc would rather emit v_and per term and join three terms per v_or3: 11 instructions for 8 terms instead of 8)
     static __device__ __forceinline__ U32 and_or(U32 a, uint32_t m, U32 c) {
