@@ -267,8 +267,8 @@ def main():
                 assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
                 return ns
 
-            def end_to_end(reps=3):
-                """host buffers in, answers out: pinned H2D of the batch + the pass + D2H of the results; ms"""
+            def end_to_end(reps=5):
+                """host buffers in, answers out: pinned H2D of the batch + the pass + D2H of the results; ms (median)"""
                 pins = [(dst, torch.from_numpy(np.ascontiguousarray(src).reshape(-1)).pin_memory()) for dst, src in host_blobs]
                 out_h = torch.empty(max(n, 1), dtype=torch.int32).pin_memory()
                 ts = []
@@ -281,7 +281,7 @@ def main():
                     out_h[:n].copy_(out, non_blocking=True)
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
-                return float(np.mean(ts[1:]))
+                return float(np.median(ts[1:]))
             return run, n, parity, {"csr": csr, "oracle": oracle, "cells_total": cells_total, "bytes_total": bytes_total, "end_to_end": end_to_end}
     else:   # cfg5: levenshtein_search, 32 B needle over a 1 GiB random shard per GPU
         mib = args.pairs or 1024
@@ -328,8 +328,8 @@ def main():
                     dist.all_gather(allv, mine)
                     assert len({int(v[0].item()) for v in allv}) == 1, "sharded search: ranks disagree"
                 return ns
-            def end_to_end(reps=2):
-                """host haystack in, Best matches out: pinned H2D of the shard + the pass (its report comes back by itself); ms"""
+            def end_to_end(reps=3):
+                """host haystack in, Best matches out: pinned H2D of the shard + the pass (its report comes back by itself); ms (median)"""
                 pin = torch.from_numpy(hay_np).pin_memory()
                 ts = []
                 for _ in range(reps + 1):
@@ -339,7 +339,7 @@ def main():
                     run()
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
-                return float(np.mean(ts[1:]))
+                return float(np.median(ts[1:]))
             return run, hay_np.size, parity, {"hay_np": hay_np, "cells_total": cells_unit * hay_np.size, "bytes_total": bytes_unit * hay_np.size,
                                               "end_to_end": end_to_end}
 

@@ -53,9 +53,16 @@ mod ffi {
         pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                  search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
+        pub fn ta_thread_release();
     }
+    /// Frees what a thread holds inside the library (its stream, pinned buffers, device scratch) when the thread ends: the
+    /// library itself frees nothing from a thread-exit hook.  Touched by every call through `check`.
+    pub struct ThreadGuard;
+    impl Drop for ThreadGuard { fn drop(&mut self) { unsafe { ta_thread_release() } } }
+    thread_local! { pub static THREAD_GUARD: ThreadGuard = ThreadGuard; }
     /// status codes -> the reference's panics (src/hamming.rs:318, src/lib.rs:240, src/levenshtein.rs:44-52,69)
     pub fn check(rc: c_int) {
+        THREAD_GUARD.with(|_| ());
         match rc {
             0 => (),
             1 => panic!("assertion failed: a.len() == b.len()"),

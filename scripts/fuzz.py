@@ -32,7 +32,9 @@ def rand_pairs(n, lo, hi, alpha, sim, edits):
 t_end, rounds, kinds = time.time() + 60 * minutes, 0, {}
 while time.time() < t_end:
     rounds += 1
-    kind = int(g.integers(0, 6))
+    kind = int(g.integers(0, 9))
+    early = bool(g.random() < 0.3)                 # the early-out option must never change an answer
+    T.set_option(T.OPT_EARLY_OUT, early)
     alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
     costs = COSTS[int(g.integers(0, len(COSTS)))]
     if not O.costs_valid(costs):
@@ -81,6 +83,54 @@ while time.time() < t_end:
             want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, anch)
             ok = got == want
             what = ("search", n, k, st, anch, costs, len(hay))
+        elif kind in (6, 7):    # round 3: big batches -- two pairs per lane, length-ordered CSR, the small-alphabet kernel (with foreign bytes)
+            unit = [(1, 1, 0, None), (1, 1, 0, 1)][int(g.integers(0, 2))]
+            costs = unit if kind == 7 or g.random() < 0.7 else costs
+            small = kind == 7
+            n = int(g.choice([20000, 70000, 270000]))
+            L = int(g.choice([24, 64, 128, 200, 256, 300]))
+            Lb = max(1, L + int(g.integers(-6, 7)))
+            k = int(g.choice([0, 3, 8, 12, 14, 15, 20, 30, 32, 33]))
+            sym = np.frombuffer(b"ACGT", dtype=np.uint8) if small else np.arange(alpha[0], alpha[1], dtype=np.uint8)
+            fa = sym[g.integers(0, len(sym), size=(n, L))]
+            fb = sym[g.integers(0, len(sym), size=(n, Lb))]
+            near = g.random(n) < 0.5
+            m = min(L, Lb)
+            fb[near, :m] = fa[near, :m]
+            pos = g.integers(0, m, size=(n, 4))
+            rows = np.nonzero(near)[0]
+            fb[rows[:, None], pos[rows]] = sym[g.integers(0, len(sym), size=(len(rows), 4))]
+            alphabet = None
+            if small:
+                alphabet = b"ACGT"
+                bad = g.choice(n, size=int(g.integers(0, 50)), replace=False)
+                fa[bad, g.integers(0, L, size=len(bad))] = ord("N")
+            if g.random() < 0.5 and not small:              # the same pairs as a CSR batch with ragged tails: taken in length order
+                la = g.integers(max(1, L - 40), L + 1, size=n); lb = np.minimum(Lb, np.maximum(1, la + g.integers(-5, 6, size=n)))
+                a = [fa[i, :la[i]].tobytes() for i in range(n)]; b = [fb[i, :lb[i]].tobytes() for i in range(n)]
+                got = B.levenshtein_k_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs).cpu().numpy().view(np.uint32)
+                want = O.levenshtein_k_batch(O.csr_from_list(a), O.csr_from_list(b), k, costs)
+            else:
+                got = B.levenshtein_k_batch(B.Strings.from_fixed(fa), B.Strings.from_fixed(fb), k, costs, alphabet=alphabet).cpu().numpy().view(np.uint32)
+                want = O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), k, costs)
+            ok = np.array_equal(got, want)
+            what = ("big_batch", n, L, Lb, k, costs, small, early, T.last_launch_info()["kernel"], T.last_kernel_name())
+        elif kind == 8:         # first hit of a long haystack (the lazy All-mode iterator's first element)
+            if not O.costs_valid_search(costs):
+                continue
+            n = int(g.choice([4, 17, 32, 60]))
+            needle = g.integers(max(1, alpha[0]), alpha[1], n, dtype=np.uint8).tobytes()
+            k = int(g.integers(0, max(1, n // 3) + 1))
+            size = int(g.choice([3000, 70000, 300000, 1500000]))
+            hay = bytearray(g.integers(max(1, alpha[0]), alpha[1], size, dtype=np.uint8).tobytes())
+            if g.random() < 0.8:
+                p0 = int(g.integers(0, size - n))
+                hay[p0:p0 + n] = needle
+            hay = bytes(hay)
+            got = T.levenshtein_search_first(needle, hay, k, T.EditCosts(*costs))
+            want = O.levenshtein_search_naive_with_opts(needle, hay, k, O.ALL, costs, False)
+            ok = (tuple(got) if got else None) == (want[0] if want else None)
+            what = ("search_first", n, k, costs, size)
         else:                   # hamming + hamming search
             n = int(g.choice([1, 9, 32, 33, 100, 700]))
             needle = g.integers(1, 256, n, dtype=np.uint8).tobytes()

@@ -101,6 +101,20 @@ dna)
   done 2>&1 | tee $O/dna.txt
   trace cfg2_dna --workload cfg2 --dist dna --steps 10 --warmup 2
   python scripts/pmc_collect.py --out $O/cfg2_dna_pmc.json --workload cfg2 --sets sq1,sq2,rd_b,write --steps 5 --extra "--dist dna" 2>&1 | tail -2 ;;
+benchlines)   # the bench lines again, now that profiles/<round>/ holds this build's counter passes (roofline.traffic, valu_issue)
+  mkdir -p $O/lines
+  for tag in cfg2 cfg2_mutated cfg4 cfg1 cfg5 cfg3 cfg2w cfg4w cfg2_ragged cfg2_dna; do
+    case $tag in cfg2_mutated) fl="--workload cfg2 --dist mutated" ;; cfg2_ragged) fl="--workload cfg2 --dist ragged" ;; cfg2_dna) fl="--workload cfg2 --dist dna" ;; *) fl="--workload $tag" ;; esac
+    case $tag in cfg3) st="--steps 3 --warmup 1" ;; cfg5) st="--steps 10 --warmup 2" ;; cfg2) st="" ;; *) st="--steps 50" ;; esac
+    nocpu="--no-cpu"; [ $tag = cfg2 ] && nocpu=""
+    timeout 900 python bench.py $fl $st $nocpu > $O/lines/bench_$tag.json 2> $O/lines/bench_$tag.err
+    cut -c1-150 $O/lines/bench_$tag.json; grep -h "not spliced" $O/lines/bench_$tag.err
+  done
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/lines/bench_driver_command.json 2>/dev/null; cut -c1-200 $O/lines/bench_driver_command.json ;;
+fuzz)
+  timeout 900 python scripts/fuzz.py 8 20260929 2>&1 | tail -5 | tee $O/fuzz.txt ;;
+cfg5ab)
+  bash scripts/gpu_session_cfg5.sh 2>&1 | tail -40; bash scripts/gpu_session_cfg5b.sh 2>&1 | tail -40 ;;
 *) echo "unknown part $part" ;;
 esac
 done

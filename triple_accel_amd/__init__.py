@@ -308,6 +308,12 @@ def set_option(option, value):
     _n.check(_n.lib().ta_set_option(int(option), int(bool(value))))
 
 
+def thread_release():
+    """Free what the calling thread holds inside the library (its stream, pinned buffers, device scratch).  A worker thread calls
+    this before it ends; otherwise those live until process exit."""
+    _n.lib().ta_thread_release()
+
+
 def device_count():
     return int(_n.lib().ta_device_count())
 
