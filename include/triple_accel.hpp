@@ -107,6 +107,24 @@ inline std::vector<Match> levenshtein_search_simd_with_opts(bytes needle, bytes 
     check_(ta_levenshtein_search_simd_with_opts(needle.data(), needle.size(), haystack.data(), haystack.size(), k, (int)st, costs.raw(), anchored, &m, &n));
     return take_(m, n);
 }
+// pairs produced one at a time, answered together by ONE batch pass per flush (ta_queue_*; no reference analogue)
+class Queue {
+public:
+    Queue(std::uint32_t k, const EditCosts &costs) { check_(ta_queue_create(k, costs.raw(), &q_)); }
+    ~Queue() { ta_queue_destroy(q_); }
+    Queue(const Queue &) = delete;
+    Queue &operator=(const Queue &) = delete;
+    std::size_t push(bytes a, bytes b) { std::size_t t = 0; check_(ta_queue_push(q_, a.data(), a.size(), b.data(), b.size(), &t)); return t; }
+    std::vector<std::optional<std::uint32_t>> flush() {
+        const std::uint32_t *r = nullptr; std::size_t n = 0;
+        check_(ta_queue_flush(q_, &r, &n));
+        std::vector<std::optional<std::uint32_t>> v; v.reserve(n);
+        for (std::size_t i = 0; i < n; i++) v.push_back(opt_(r[i]));
+        return v;
+    }
+private:
+    ta_queue *q_ = nullptr;
+};
 // `.next()` on the reference's lazy All-mode iterator (src/levenshtein.rs:2282-2420): the first match, found without scanning the rest
 inline std::optional<Match> levenshtein_search_first(bytes needle, bytes haystack, std::uint32_t k, const EditCosts &costs, bool anchored) {
     ta_match m; int found = 0;

@@ -233,6 +233,20 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
 /* N x hamming(a_i, b_i); out[i] = TA_NONE where the lengths differ (Rust: panic). */
 int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out_dev, void *stream);
 
+/* ---- a queue for callers that produce pairs ONE AT A TIME (the reference's calling convention, src/levenshtein.rs:714-720) but
+ * can wait for the answers: a single call costs a kernel launch (22-25 us for a 256-byte pair, against ~2 us on a host core);
+ * pushed pairs are copied into pinned staging and answered together by ONE ta_levenshtein_k_batch per flush.
+ *   ta_queue_create: every pair of the queue is levenshtein_simd_k_with_opts(a, b, k, false, costs).
+ *   ta_queue_push:   copies the pair; *ticket = its index in the next flush's result array.
+ *   ta_queue_flush:  uploads, one batch pass (CSR, length-ordered on the device), downloads; *results (library-owned, valid until
+ *                    the next push / flush / destroy) holds *n answers (TA_NONE = None) in push order; the queue is empty again.
+ * A queue belongs to one thread at a time.  Tickets restart at 0 after every flush. */
+typedef struct ta_queue ta_queue;
+int ta_queue_create(uint32_t k, const ta_edit_costs *costs, ta_queue **out);
+int ta_queue_push(ta_queue *q, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t *ticket);
+int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n);
+void ta_queue_destroy(ta_queue *q);
+
 /* All-mode hits of one haystack shard resident in HBM (levenshtein_search_simd_with_opts with
  * SearchType::All; the order-dependent Best fold is a sequential host pass, ta_search_fold_best).
  * `base` is added to start/end (global offset of this shard inside a larger haystack);

@@ -54,6 +54,10 @@ mod ffi {
                                                  search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
         pub fn ta_thread_release();
+        pub fn ta_queue_create(k: u32, costs: *const TaEditCosts, out: *mut *mut c_void) -> c_int;
+        pub fn ta_queue_push(q: *mut c_void, a: *const u8, a_len: usize, b: *const u8, b_len: usize, ticket: *mut usize) -> c_int;
+        pub fn ta_queue_flush(q: *mut c_void, results: *mut *const u32, n: *mut usize) -> c_int;
+        pub fn ta_queue_destroy(q: *mut c_void);
     }
     /// Frees what a thread holds inside the library (its stream, pinned buffers, device scratch) when the thread ends: the
     /// library itself frees nothing from a thread-exit hook.  Touched by every call through `check`.
@@ -196,6 +200,29 @@ pub mod levenshtein {
     pub fn levenshtein_exp(a: &[u8], b: &[u8]) -> u32 { levenshtein_exp_with_opts(a, b, false, LEVENSHTEIN_COSTS).0 }
     /// src/levenshtein.rs:1516
     pub fn rdamerau_exp(a: &[u8], b: &[u8]) -> u32 { levenshtein_exp_with_opts(a, b, false, RDAMERAU_COSTS).0 }
+
+    /// Pairs produced one at a time, answered together: a single call costs a kernel launch (22-25 us for a 256-byte pair against
+    /// ~2 us on a host core); `push` copies a pair and returns its ticket, `flush` runs ONE batch pass over everything pushed and
+    /// returns `levenshtein_simd_k_with_opts(a, b, k, false, costs)` of every pair in push order.  (No reference analogue.)
+    pub struct Queue { q: *mut c_void }
+    impl Queue {
+        pub fn new(k: u32, costs: EditCosts) -> Self {
+            let mut q = std::ptr::null_mut();
+            check(unsafe { ta_queue_create(k, &costs.raw(), &mut q) });
+            Queue { q }
+        }
+        pub fn push(&mut self, a: &[u8], b: &[u8]) -> usize {
+            let mut t = 0usize;
+            check(unsafe { ta_queue_push(self.q, a.as_ptr(), a.len(), b.as_ptr(), b.len(), &mut t) });
+            t
+        }
+        pub fn flush(&mut self) -> Vec<Option<u32>> {
+            let (mut p, mut n) = (std::ptr::null::<u32>(), 0usize);
+            check(unsafe { ta_queue_flush(self.q, &mut p, &mut n) });
+            (0..n).map(|i| { let v = unsafe { *p.add(i) }; if v == TA_NONE { None } else { Some(v) } }).collect()
+        }
+    }
+    impl Drop for Queue { fn drop(&mut self) { unsafe { ta_queue_destroy(self.q) } } }
 
     /// All-mode result over a long haystack, lazily (the reference's iterator is lazy too, src/levenshtein.rs:2282-2420): the
     /// first element comes from `ta_levenshtein_search_first`, which stops scanning (and uploading) at the first window that

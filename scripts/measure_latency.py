@@ -18,3 +18,15 @@ for n in (16, 256, 4096):
         n, lat(lambda: T.hamming(x, x)), lat(lambda: T.levenshtein_simd_k(x, y, 8)), lat(lambda: T.levenshtein_simd_k(x, y, 32)),
         lat(lambda: T.levenshtein(x, y)), lat(lambda: T.levenshtein_exp(x, y)), lat(lambda: T.rdamerau(x, y)),
         lat(lambda: T.levenshtein_search_simd_with_opts(x[:8], y, 2, T.SearchType.Best, T.LEVENSHTEIN_COSTS, False))), flush=True)
+
+# the queue: pairs pushed one at a time, one batch pass per flush (amortised cost per pair, host buffers in, answers out)
+for n in (256,):
+    x = Dg.rand_str(g, n); y = Dg.mutate(g, x, max(1, n // 20))
+    for per_flush in (100, 1000, 10000):
+        q = T.Queue(32)
+        def round_trip():
+            for _ in range(per_flush): q.push(x, y)
+            return q.flush()
+        us = lat(round_trip, reps=20) / per_flush
+        print("queue, %d-byte pairs, k = 32, %5d pairs per flush: %6.2f us per pair (push + its share of the flush)" % (n, per_flush, us), flush=True)
+        q.close()

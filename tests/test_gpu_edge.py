@@ -131,3 +131,24 @@ def test_generic_items_beyond_256_symbols_and_buffer_inputs():
         list(T.hamming_search_naive_with_opts(b"", b"abc", 2, T.SearchType.Best))
     with pytest.raises(T.PanicError):
         list(T.hamming_search_naive(b"", b"abc"))
+
+
+def test_queue_of_single_pairs():
+    """ta_queue_*: pairs pushed one at a time, answered by one batch pass per flush -- the answers of the single calls, in push order;
+    tickets restart after a flush; an empty flush is fine; general EditCosts too."""
+    import triple_accel_amd as T
+    g = Dg.rng(91)
+    for k, costs in [(8, (1, 1, 0, None)), (30, (1, 1, 0, 1)), (12, (2, 3, 1, None))]:
+        q = T.Queue(k, T.EditCosts(*costs))
+        assert q.flush() == []
+        for rnd, n in enumerate((1, 300, 6000)):
+            pairs = []
+            for i in range(n):
+                x = Dg.rand_str(g, int(g.integers(0, 200)))
+                y = Dg.mutate(g, x, int(g.integers(0, 12)), costs[3] is not None) if i % 3 else Dg.rand_str(g, int(g.integers(0, 200)))
+                assert q.push(x, y) == i
+                pairs.append((x, y))
+            got = q.flush()
+            want = O.levenshtein_k_batch(O.csr_from_list([p[0] for p in pairs]), O.csr_from_list([p[1] for p in pairs]), k, costs)
+            assert got == [None if int(w) == 0xFFFFFFFF else int(w) for w in want], (k, costs, n)
+        q.close()

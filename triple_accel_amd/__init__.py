@@ -299,6 +299,38 @@ def last_kernel_name():
     return _n.lib().ta_last_kernel_name().decode()
 
 
+class Queue:
+    """Pairs produced one at a time, answered together (include/triple_accel_amd.h, ta_queue_*): push() copies a pair and returns its
+    ticket, flush() runs ONE batch pass and returns the answers in push order (None where the distance exceeds k)."""
+
+    def __init__(self, k, costs=None):
+        self._q = _C.c_void_p()
+        cc = _costs(costs if costs is not None else LEVENSHTEIN_COSTS)._c()
+        _raise(_n.lib().ta_queue_create(_k(k), _C.byref(cc), _C.byref(self._q)))
+
+    def push(self, a, b):
+        a, b = _b(a), _b(b)
+        t = _C.c_size_t()
+        _raise(_n.lib().ta_queue_push(self._q, a, len(a), b, len(b), _C.byref(t)))
+        return int(t.value)
+
+    def flush(self):
+        res, n = _C.POINTER(_C.c_uint32)(), _C.c_size_t()
+        _raise(_n.lib().ta_queue_flush(self._q, _C.byref(res), _C.byref(n)))
+        return [None if res[i] == _n.NONE else int(res[i]) for i in range(n.value)]
+
+    def close(self):
+        if self._q:
+            _n.lib().ta_queue_destroy(self._q)
+            self._q = _C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 OPT_EARLY_OUT = 1
 
 

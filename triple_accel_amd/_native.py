@@ -16,7 +16,7 @@ TA_OK, TA_ERR_LEN_MISMATCH, TA_ERR_NULL_BYTE, TA_ERR_BAD_COSTS, TA_ERR_HIP, TA_E
 # every symbol include/triple_accel_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ta_levenshtein_costs", "ta_rdamerau_costs", "ta_edit_costs_new", "ta_edit_costs_check_search",
-    "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_last_kernel_name", "ta_set_option", "ta_levenshtein_k_batch_alphabet", "ta_levenshtein_search_first", "ta_levenshtein_search_first_dev", "ta_levenshtein_select",
+    "ta_version", "ta_status_str", "ta_device_count", "ta_last_error", "ta_last_kernel_name", "ta_set_option", "ta_queue_create", "ta_queue_push", "ta_queue_flush", "ta_queue_destroy", "ta_levenshtein_k_batch_alphabet", "ta_levenshtein_search_first", "ta_levenshtein_search_first_dev", "ta_levenshtein_select",
     "ta_last_launch_info", "ta_hamming", "ta_levenshtein_simd_k_with_opts", "ta_levenshtein_trace",
     "ta_levenshtein_exp_trace", "ta_levenshtein_simd_k",
     "ta_levenshtein", "ta_rdamerau", "ta_levenshtein_exp", "ta_levenshtein_exp_with_opts", "ta_rdamerau_exp",
@@ -98,6 +98,10 @@ def lib():
     sig("ta_last_error", C.c_char_p, [])
     sig("ta_last_kernel_name", C.c_char_p, [])
     sig("ta_set_option", C.c_int, [C.c_int, C.c_int])
+    sig("ta_queue_create", i32, [u32, cp, C.POINTER(C.c_void_p)])
+    sig("ta_queue_push", i32, [C.c_void_p, u8p, sz, u8p, sz, C.POINTER(sz)])
+    sig("ta_queue_flush", i32, [C.c_void_p, C.POINTER(C.POINTER(u32)), C.POINTER(sz)])
+    sig("ta_queue_destroy", None, [C.c_void_p])
     sig("ta_levenshtein_costs", EditCostsC, [])
     sig("ta_rdamerau_costs", EditCostsC, [])
     sig("ta_edit_costs_new", i32, [C.c_uint8, C.c_uint8, C.c_uint8, i32, C.c_uint8, cp])

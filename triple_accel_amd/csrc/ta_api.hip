@@ -20,6 +20,7 @@ static thread_local ta_launch_info g_last_launch = {};
 // true when the last distance pass of this thread was ONE kernel whose only store to its result slot is the answer: the
 // single-call entry points may then watch the pinned result word instead of synchronising the stream (fetch_u32)
 static thread_local bool g_answer_single_store = false;
+static thread_local int g_exp_passes = 0;          // distance passes the last ta_levenshtein_exp_batch of this thread launched
 
 void set_last_error(const char *what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -534,6 +535,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         TA_HIP(hipMemsetAsync(out_dev, 0xFF, n * 4, st));
         TA_HIP(bag_bound_launch(view_of(a), view_of(b), (uint32_t)n, costs->mismatch_cost, costs->gap_cost, (uint32_t *)bnd.dev, st));
     }
+    g_exp_passes = 0;
     uint32_t *sub_in = nullptr, *bufs[2] = {(uint32_t *)s0.dev, (uint32_t *)s1.dev};
     uint32_t n_left = (uint32_t)n;                          // unresolved pairs (sub_in == nullptr: all of them)
     uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
@@ -560,6 +562,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         }
         if (n_work > 0) {
             rc = lev_pass(a, b, n_work, work, k, costs, max_len, out_dev, st);
+            g_exp_passes++;
             if (rc) return rc;
             if (k == 0xFFFFFFFFu) break;                    // the unbounded pass answers every pair it is given (all that were left)
             TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
@@ -584,6 +587,89 @@ int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_
     StreamGuard guard((hipStream_t)stream);
     TA_HIP(hamming_batch_launch(view_of(a), view_of(b), (uint32_t)n, out_dev, (hipStream_t)stream));
     return TA_OK;
+}
+
+/* ---------------------------------------------------------------- queue: pairs pushed one at a time, answered by one batch pass */
+}  // extern "C"
+
+struct ta_queue {
+    uint32_t k;
+    ta_edit_costs costs;
+    std::vector<uint8_t> blob[2];          // the pushed strings back to back (a: 0, b: 1)
+    std::vector<uint64_t> off[2];          // CSR offsets (n + 1)
+    uint64_t max_len = 0;
+    std::vector<uint32_t> results;
+    void *dev = nullptr;                   // device staging: [a blob | b blob | a offsets | b offsets | results]
+    size_t dev_cap = 0;
+    hipStream_t st = nullptr;
+};
+
+extern "C" {
+
+int ta_queue_create(uint32_t k, const ta_edit_costs *costs, ta_queue **out) {
+    if (!out) return TA_ERR_ARG;
+    *out = nullptr;
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    ta_queue *q = new ta_queue();
+    q->k = k; q->costs = *costs;
+    q->off[0].push_back(0); q->off[1].push_back(0);
+    if (hipStreamCreateWithFlags(&q->st, hipStreamNonBlocking) != hipSuccess) { delete q; return TA_ERR_HIP; }
+    *out = q;
+    return TA_OK;
+}
+
+int ta_queue_push(ta_queue *q, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t *ticket) {
+    if (!q || (!a && a_len) || (!b && b_len) || a_len > 0xFFFFFFF0ull || b_len > 0xFFFFFFF0ull) return TA_ERR_ARG;
+    if (q->off[0].size() > 0xFFFFFFF0ull) return TA_ERR_CAPACITY;
+    if (ticket) *ticket = q->off[0].size() - 1;
+    q->blob[0].insert(q->blob[0].end(), a, a + a_len);
+    q->blob[1].insert(q->blob[1].end(), b, b + b_len);
+    q->off[0].push_back(q->blob[0].size());
+    q->off[1].push_back(q->blob[1].size());
+    const uint64_t m = a_len > b_len ? a_len : b_len;
+    if (m > q->max_len) q->max_len = m;
+    return TA_OK;
+}
+
+int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n_out) {
+    if (!q || !results || !n_out) return TA_ERR_ARG;
+    const size_t n = q->off[0].size() - 1;
+    *results = nullptr; *n_out = n;
+    q->results.assign(n, 0);
+    if (n == 0) return TA_OK;
+    auto pad = [](size_t x) { return (x + TA_BLOB_SLACK + 255) & ~(size_t)255; };
+    const size_t sa = pad(q->blob[0].size()), sb = pad(q->blob[1].size()), so = pad((n + 1) * 8), sr = pad(n * 4);
+    const size_t need = sa + sb + 2 * so + sr;
+    if (need > q->dev_cap) {
+        if (q->dev) (void)hipFree(q->dev);
+        q->dev = nullptr; q->dev_cap = 0;
+        TA_HIP(hipMalloc(&q->dev, need + need / 2));
+        q->dev_cap = need + need / 2;
+    }
+    uint8_t *base = (uint8_t *)q->dev;
+    uint8_t *da = base, *db = base + sa, *doa = base + sa + sb, *dob = doa + so, *dr = dob + so;
+    hipStream_t st = q->st;
+    if (!q->blob[0].empty()) TA_HIP(hipMemcpyAsync(da, q->blob[0].data(), q->blob[0].size(), hipMemcpyHostToDevice, st));
+    if (!q->blob[1].empty()) TA_HIP(hipMemcpyAsync(db, q->blob[1].data(), q->blob[1].size(), hipMemcpyHostToDevice, st));
+    TA_HIP(hipMemcpyAsync(doa, q->off[0].data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    TA_HIP(hipMemcpyAsync(dob, q->off[1].data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    ta_strings A = {da, (const uint64_t *)doa, 0, 0, q->max_len ? q->max_len : 1}, B = {db, (const uint64_t *)dob, 0, 0, q->max_len ? q->max_len : 1};
+    int rc = ta_levenshtein_k_batch(&A, &B, n, q->k, &q->costs, (uint32_t *)dr, st);
+    if (rc) return rc;
+    TA_HIP(hipMemcpyAsync(q->results.data(), dr, n * 4, hipMemcpyDeviceToHost, st));
+    TA_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < 2; s++) { q->blob[s].clear(); q->off[s].assign(1, 0); }
+    q->max_len = 0;
+    *results = q->results.data();
+    return TA_OK;
+}
+
+void ta_queue_destroy(ta_queue *q) {
+    if (!q) return;
+    if (q->st) { (void)hipStreamSynchronize(q->st); (void)hipStreamDestroy(q->st); }
+    if (q->dev) (void)hipFree(q->dev);
+    delete q;
 }
 
 /* ---------------------------------------------------------------- single-call host API */
@@ -646,12 +732,12 @@ static inline void cpu_relax() {
 static int fetch_u32(const Staged &S, uint32_t *out, bool single_store = false) {
     if (S.out_host) {
         if (single_store) {
-            // a short spin (the answer of a short pair arrives within ~10-25 us), then the runtime's own wait: a host core is
-            // never held for longer than 200 us per call
+            // watch the word (the answer of a short pair arrives within ~10-25 us, of a 4 KiB pair within ~0.6 ms; the runtime's own
+            // wait costs ~40 us more than the watch), for at most 2 ms: then the runtime's wait takes over
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spin = 0; *S.out_host == TA_SLOT_EMPTY; spin++) {
                 cpu_relax();
-                if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+                if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
             }
             const uint32_t v = *S.out_host;
             if (v != TA_SLOT_EMPTY) { *out = v; return TA_OK; }
@@ -918,7 +1004,9 @@ int ta_levenshtein_exp_with_opts(const uint8_t *a, size_t a_len, const uint8_t *
     if (rc) return rc;
     rc = ta_levenshtein_exp_batch(&S.sa, &S.sb, 1, costs, S.out_dev, S.st);
     if (rc) return rc;
-    return fetch_u32(S, out);
+    // one pass, one kernel, one store (a short pair goes straight to the unbounded pass): the pinned word can be watched; after
+    // several rounds the slot already holds an earlier round's None
+    return fetch_u32(S, out, g_exp_passes == 1 && g_answer_single_store);
 }
 int ta_levenshtein_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out) {
     ta_edit_costs c = ta_levenshtein_costs();
