@@ -114,7 +114,7 @@ int ta_levenshtein_select(size_t a_len, size_t b_len, uint32_t k, const ta_edit_
 /* What the last distance batch launched on this thread used (for tests / debug logging;
  * the analogue of the reference's `debug` feature println, src/levenshtein.rs:840-847). */
 typedef struct {
-    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup, 3 = bit-parallel band (unit costs), 4 = bit-parallel full columns (unit costs, long pairs), 5 = pair-sliced systolic band (EXPERIMENTAL builds), 6 = single pair, band <= 64 diagonals (unit costs; pairs_per_wave 128 with kernel 3 = two pairs per lane) */
+    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup, 3 = bit-parallel band (unit costs), 4 = bit-parallel full columns (unit costs, long pairs), 5 = pair-sliced systolic band (EXPERIMENTAL builds), 6 = single pair, band <= 64 diagonals (unit costs), 7 = small-alphabet bit-parallel band (ta_levenshtein_k_batch_alphabet); pairs_per_wave 128 with kernel 3 = two pairs per lane */
     uint32_t diags_per_lane;  /* D */
     uint32_t lanes_per_pair;  /* L */
     uint32_t pairs_per_wave;

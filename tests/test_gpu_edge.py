@@ -152,3 +152,8 @@ def test_queue_of_single_pairs():
             want = O.levenshtein_k_batch(O.csr_from_list([p[0] for p in pairs]), O.csr_from_list([p[1] for p in pairs]), k, costs)
             assert got == [None if int(w) == 0xFFFFFFFF else int(w) for w in want], (k, costs, n)
         q.close()
+        # the queue's stream is gone now; a scratch-using call on another stream must not touch it (the library once recorded its
+        # cross-stream event lazily, on the previous stream: a crash here)
+        a = [Dg.rand_str(g, int(g.integers(0, 60))) for _ in range(5000)]
+        b = [Dg.mutate(g, x, 3) for x in a]
+        assert np.array_equal(gpu_k(a, b, 4), oracle_k(a, b, 4))

@@ -114,33 +114,28 @@ struct LevBitsQ {
                 S[c] = W::gload16(W::ptr_add(ptr, W::splat(off < len_u ? off : 0u)), ok);
             }
         };
-        // wave-uniform: one of eight parked pieces; the consumer runs inside the switch arm (a piece handed out by value cost a
-        // dozen v_mov per span)
-        auto with_piece = [&](const Q (&S)[8], uint32_t piece, auto use) {
+        auto take = [&](const Q (&S)[8], uint32_t piece) -> Q {   // wave-uniform: one of eight parked pieces
             switch (piece & 7u) {
-                case 0: use(S[0]); break; case 1: use(S[1]); break; case 2: use(S[2]); break; case 3: use(S[3]); break;
-                case 4: use(S[4]); break; case 5: use(S[5]); break; case 6: use(S[6]); break; default: use(S[7]); break;
+                case 0: return S[0]; case 1: return S[1]; case 2: return S[2]; case 3: return S[3];
+                case 4: return S[4]; case 5: return S[5]; case 6: return S[6]; default: return S[7];
             }
         };
-        // the four codes of each dword of a 16-byte piece of text that starts at string offset x; the symbol a code stands for must
-        // be the byte itself (one v_perm_b32 lookup per dword); bytes at or beyond the string's end are not looked at
-        auto codes_of = [&](const Q &q, uint32_t len_u, uint32_t x, U32 (&c)[4]) {
-            U32 diff = W::splat(0);
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const U32 dw = W::qword(q, d);
-                c[d] = W::shr_u(dw, hs) & 0x03030303u;
-                const uint32_t xo = x + 4u * (uint32_t)d;
-                if (xo + 4u <= len_u) diff = diff | (W::perm_sel(table, table, c[d]) ^ dw);
-                else if (xo < len_u) diff = diff | ((W::perm_sel(table, table, c[d]) ^ dw) & ((1u << (8u * (len_u - xo))) - 1u));
+        // the four codes of a dword of text; bytes at or beyond `inside` (0..4, wave-uniform) lie past the string's end
+        auto codes_of = [&](U32 dw, uint32_t inside) -> U32 {
+            const U32 c = W::shr_u(dw, hs) & 0x03030303u;
+            if (inside) {
+                const uint32_t m = inside >= 4u ? 0xFFFFFFFFu : ((1u << (8u * inside)) - 1u);
+                bad = bad | ((W::perm_sel(table, table, c) ^ dw) & m);     // the symbol the code stands for must be the byte itself
             }
-            bad = bad | diff;
+            return c;
         };
+        auto inside_of = [](uint32_t len_u, uint32_t x) -> uint32_t { return x >= len_u ? 0u : (len_u - x >= 4u ? 4u : len_u - x); };
         // rows 16 piece .. 16 piece + 15 of `a` -> 16 bits of every symbol's ring
         auto commit_a = [&](uint32_t piece) {
-          with_piece(SA, piece, [&](const Q &q) {
+            const Q q = take(SA, piece);
             U32 c[4];
-            codes_of(q, alen_u, 16u * piece, c);
+#pragma unroll
+            for (int d = 0; d < 4; d++) c[d] = codes_of(W::qword(q, d), inside_of(alen_u, 16u * piece + 4u * (uint32_t)d));
             const U32 lo_w = W::splat(0x08040201u), hi_w = W::splat(0x80402010u);
             U32 h0 = W::dot4(c[1] & 0x01010101u, hi_w, W::dot4(c[0] & 0x01010101u, lo_w, W::splat(0)));
             U32 g0 = W::dot4(c[3] & 0x01010101u, hi_w, W::dot4(c[2] & 0x01010101u, lo_w, W::splat(0)));
@@ -154,17 +149,16 @@ struct LevBitsQ {
                 W::lds_write16(lds, ring + s * SYM_STRIDE + hw, M[s]);
                 if (hw < 4u) W::lds_write16(lds, ring + s * SYM_STRIDE + 16u + hw, M[s]);      // the wrap copy of the ring's first dword
             }
-          });
             if ((piece & 7u) == 7u) fetch(SA, aptr, alen_u, (int32_t)(piece >> 3) + 1);
         };
         // the 16 columns of piece `piece` of `b` -> the byte offsets of their symbols' rings (code * SYM_STRIDE), in registers
         auto convert_b = [&](uint32_t piece, U32 (&bo)[4]) {
-          with_piece(SB, piece, [&](const Q &q) {
-            U32 c[4];
-            codes_of(q, blen_u, 16u * piece, c);
+            const Q q = take(SB, piece);
 #pragma unroll
-            for (int d = 0; d < 4; d++) bo[d] = W::lshl_add(c[d], 4, c[d] << 2);   // * 20: four byte offsets 0 / 20 / 40 / 60, no carry between the bytes
-          });
+            for (int d = 0; d < 4; d++) {
+                const U32 c = codes_of(W::qword(q, d), inside_of(blen_u, 16u * piece + 4u * (uint32_t)d));
+                bo[d] = W::lshl_add(c, 4, c << 2);             // * 20
+            }
             if ((piece & 7u) == 7u) fetch(SB, bptr, blen_u, (int32_t)(piece >> 3) + 1);
         };
         // column t + 1 (t = c0 + c): the window's top row is a[t - d_hi]

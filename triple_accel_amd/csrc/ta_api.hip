@@ -48,7 +48,11 @@ bool device_ready() {
     return state == 1;
 }
 
+// set by every Scratch::ensure, consumed by the StreamGuard of the call: did this call put thread-local scratch to use?
+static thread_local bool g_scratch_in_use = false;
+
 int Scratch::ensure(size_t bytes) {
+    g_scratch_in_use = true;
     if (bytes <= cap) return TA_OK;
     if (dev) { (void)hipFree(dev); dev = nullptr; cap = 0; }
     size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
@@ -108,20 +112,20 @@ static LastUse &last_use() {
     static thread_local LastUse u;
     return u;
 }
-// Lazily: nothing is recorded while a thread stays on one stream (the normal case -- an event record per call was a fifth of
-// a small batch call's cost).  When a call arrives on ANOTHER stream, the event is recorded on the previous stream then --
-// behind everything this thread ever queued there, a superset of the last call's work -- and the new stream waits for it.
+// A call that put thread-local scratch to use records an event at its end (its kernels may still be reading that scratch when
+// it returns); a later call of the thread on ANOTHER stream waits for that event first.  Calls that touch no scratch -- the
+// fixed-length batch passes, ta_hamming_batch: the hot paths -- record nothing (an event record per call was a fifth of a small
+// batch call's cost).  The event is recorded while the stream is certainly alive: the caller may destroy it afterwards.
 StreamGuard::StreamGuard(hipStream_t s) : st(s) {
     LastUse &u = last_use();
-    if (u.pending && u.st != s) {
-        if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) u.ev = nullptr;
-        if (u.ev && hipEventRecord(u.ev, u.st) == hipSuccess) (void)hipStreamWaitEvent(s, u.ev, 0);
-        else (void)hipStreamSynchronize(u.st);                  // no event to be had: wait on the host
-    }
+    if (u.pending && u.st != s && u.ev) (void)hipStreamWaitEvent(s, u.ev, 0);
 }
 StreamGuard::~StreamGuard() {
+    if (!g_scratch_in_use) return;
+    g_scratch_in_use = false;
     LastUse &u = last_use();
-    u.st = st; u.pending = true;
+    if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) { u.ev = nullptr; return; }
+    if (hipEventRecord(u.ev, st) == hipSuccess) { u.st = st; u.pending = true; }
 }
 
 // Test / tuning switches.  They are honoured only when TA_TUNING was set in the environment when the
