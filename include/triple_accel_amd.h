@@ -158,8 +158,8 @@ int ta_levenshtein_exp_with_opts(const uint8_t *a, size_t a_len, const uint8_t *
 int ta_rdamerau_exp(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, uint32_t *out);
 
 /* levenshtein_search_simd_with_opts(needle, haystack, k, search_type, costs, anchored),
- * src/levenshtein.rs:1911-1918.  The lazy iterator is materialised: *out is library-owned
- * (release with ta_free), *n_out its length. */
+ * src/levenshtein.rs:1911-1918.  This entry returns the whole result: *out is library-owned (release with ta_free), *n_out its
+ * length.  The reference's iterator is lazy; ta_levenshtein_search_first (below) is its `.next()`. */
 int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
                                          const uint8_t *haystack, size_t haystack_len,
                                          uint32_t k, int search_type, const ta_edit_costs *costs, int anchored,

@@ -375,3 +375,18 @@ def test_search_first_is_the_head_of_the_all_mode_list():
     # a dense result (k >= needle_len: every position matches) still has a first element
     hay = bytes(g.integers(33, 127, size=2_000_000, dtype=np.uint8).tobytes())
     assert tuple(T.levenshtein_search_first(b"abcd", hay, 3)) == O.levenshtein_search_naive_with_opts(b"abcd", hay[:5000], 3, O.ALL, (1, 1, 0, None), False)[0]
+
+
+def test_search_first_on_a_resident_shard():
+    """ta_levenshtein_search_first_dev: the first hit of a shard in HBM (positions + base), whatever window it falls into."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(515)
+    needle = Dg.rand_str(g, 24)
+    for where in (None, 5, 65_000, 262_200, 1_400_000, 5_999_900):
+        hay = bytearray(g.integers(33, 127, size=6_000_000, dtype=np.uint8).tobytes())
+        if where is not None:
+            hay[where:where + 24] = Dg.mutate(g, needle, 3)[:24].ljust(24, b"y")
+        hay = bytes(hay)
+        want = O.levenshtein_search_naive_with_opts(needle, hay, 5, O.ALL, (1, 1, 0, None), False)
+        got = B.levenshtein_search_first_dev(needle, B.haystack_tensor(hay), 5, base=1000)
+        assert got == ((want[0][0] + 1000, want[0][1] + 1000, want[0][2]) if want else None), where

@@ -173,6 +173,19 @@ def levenshtein_search_best_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, ba
     return rows
 
 
+def levenshtein_search_first_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, base=0):
+    """The first All-mode hit (smallest end) of a resident haystack shard, or None: the shard is searched window by window and the
+    scan stops at the first window that holds a hit (`.next()` on the reference's lazy iterator, src/levenshtein.rs:2282-2420)."""
+    hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
+    assert hay.dtype == torch.uint8 and hay.is_cuda and hay.is_contiguous()
+    needle = bytes(needle)
+    m, found = _n.MatchC(), _C.c_int()
+    cc = _costs(costs)._c()
+    _raise(_n.lib().ta_levenshtein_search_first_dev(needle, len(needle), hay.data_ptr(), length, k, _C.byref(cc), base,
+                                                    _C.byref(m), _C.byref(found), _stream()))
+    return (int(m.start), int(m.end), int(m.k)) if found.value else None
+
+
 def hamming_search_dev(needle, haystack, k, base=0, cap=None):
     hay, length = haystack if isinstance(haystack, tuple) else (haystack, haystack.numel() - SLACK)
     needle = bytes(needle)
