@@ -20,3 +20,5 @@ mkdir -p "$(dirname "$LOG")"
       tests/test_emu_lev_band.py tests/test_emu_lev_bits.py tests/test_emu_lev_widebits.py tests/test_emu_search.py tests/test_emu_filter.py \
       tests/test_emu_ham_search.py tests/test_plan.py 2>&1 | tail -15
 } 2>&1 | tee "$LOG"
+# the sanitizer builds are 450 MB of objects: not something to leave in a tree that is snapshotted to GPU boxes
+rm -f tests/emu/build/san_*.o tests/emu/libta_emu_san.so oracle/libta_oracle_san.so
