@@ -63,6 +63,22 @@ int main(int argc, char **argv) {
     threw = false;
     try { ta::hamming_search(B("a"), ta::bytes(reinterpret_cast<const std::uint8_t *>("a\0b"), 3)); } catch (const ta::panic_error &) { threw = true; }
     CHECK(threw);
+    // round 3: the first match of the lazy All-mode iterator (tests/basic_tests.rs:628-632) and the queue of single pairs
+    auto first = ta::levenshtein_search_first(B("tst"), B("testing 123 tasting!"), 1, ta::LEVENSHTEIN_COSTS, false);
+    CHECK(first.has_value() && *first == (ta::Match{0, 4, 1}));
+    CHECK(!ta::levenshtein_search_first(B("abc"), B("xyzxyz"), 0, ta::LEVENSHTEIN_COSTS, false).has_value());
+    {
+        ta::Queue q(2, ta::LEVENSHTEIN_COSTS);
+        CHECK(q.push(B("kitten"), B("sitting")) == 0);
+        CHECK(q.push(B("abc"), B("abd")) == 1);
+        CHECK(q.push(B(""), B("")) == 2);
+        auto res = q.flush();
+        CHECK(res.size() == 3 && !res[0].has_value() && res[1].value_or(99) == 1 && res[2].value_or(99) == 0);
+        CHECK(q.flush().empty());
+    }
+    threw = false;
+    try { ta::hamming_search_naive_with_opts(B(""), B("abc"), 1, ta::SearchType::Best); } catch (const ta::panic_error &) { threw = true; }
+    CHECK(threw);                                                       // src/hamming.rs:136: haystack_len / 0
     std::printf(fails ? "mirror_check gpu: %d failures\n" : "mirror_check gpu: ok\n", fails);
     return fails ? 1 : 0;
 }

@@ -296,3 +296,22 @@ def test_length_order_edge_shapes():
         assert np.array_equal(gpu_k(a, b, k, (1, 1, 0, None)), oracle_k(a, b, k, (1, 1, 0, None))), k
     a2 = [Dg.rand_str(g, 10) for _ in range(5000)]; b2 = [Dg.rand_str(g, 30) for _ in range(5000)]
     assert np.array_equal(gpu_k(a2, b2, 5, (1, 1, 0, 1)), oracle_k(a2, b2, 5, (1, 1, 0, 1)))
+
+
+def test_exp_batch_ragged_length_ordered(monkeypatch):
+    """levenshtein_exp over a ragged CSR batch of 6,000 pairs: the doubling rounds take their pairs in length order; same
+    distances as the oracle and as the batch-order schedule."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(606)
+    a, b = [], []
+    for i in range(6000):
+        x = Dg.rand_str(g, int(g.integers(1, 400)))
+        y = Dg.mutate(g, x, int(g.integers(0, 90)), True) if i % 4 else Dg.rand_str(g, int(g.integers(1, 400)))
+        a.append(x); b.append(y)
+    for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 1, None)]:
+        want = O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), costs)
+        got = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), costs).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (costs, np.flatnonzero(got != want)[:10])
+    monkeypatch.setenv("TA_NO_LENGTH_ORDER", "1")
+    got = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), (1, 1, 0, None)).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), (1, 1, 0, None)))

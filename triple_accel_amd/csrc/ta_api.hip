@@ -543,6 +543,18 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     uint32_t *sub_in = nullptr, *bufs[2] = {(uint32_t *)s0.dev, (uint32_t *)s1.dev};
     uint32_t n_left = (uint32_t)n;                          // unresolved pairs (sub_in == nullptr: all of them)
     uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
+    // ragged (CSR) batches: the rounds take their pairs in length order, as ta_levenshtein_k_batch does (the list of the still
+    // unresolved pairs is compacted from the ordered one, which keeps it ordered block by block)
+    if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
+        Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
+        constexpr size_t BINS_BYTES = 2 * 1024 * 8 * 4;
+        const bool fresh = bins.cap < BINS_BYTES;
+        if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
+        if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));
+        const uint32_t u0 = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
+        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u0, max_len, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
+        sub_in = (uint32_t *)ord.dev;
+    }
     int flip = 0;
     const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
     const bool dpo = env_int("TA_NO_BITS") != 0, faithful = env_int("TA_EXP_FAITHFUL") != 0;
