@@ -439,7 +439,7 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     const uint32_t *order = nullptr;
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
         Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
-        constexpr size_t BINS_BYTES = 2 * 1024 * 8 * 4;                    // histogram + cursors: 1024 bins x 8 counters each
+        constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;                    // histogram + cursors: 1024 bins x 32 counters each
         const bool fresh = bins.cap < BINS_BYTES;
         if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
         if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));   // once: every pass leaves the histogram zeroed behind it
@@ -547,7 +547,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     // unresolved pairs is compacted from the ordered one, which keeps it ordered block by block)
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
         Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
-        constexpr size_t BINS_BYTES = 2 * 1024 * 8 * 4;
+        constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;
         const bool fresh = bins.cap < BINS_BYTES;
         if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
         if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));

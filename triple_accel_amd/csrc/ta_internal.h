@@ -101,7 +101,7 @@ hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint
 hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*device, preset to ~0*/, ta_match *out, uint32_t cap,
                             uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 // counting sort of the pairs of a ragged batch by length class (util_kernels.hip): subset_out = the pairs (of subset_in, or
-// 0..n) ordered so that 64 consecutive ones are within a few bytes of each other; bins = 2 x 8192 u32 of device scratch, the
+// 0..n) ordered so that 64 consecutive ones are within a few bytes of each other; bins = 2 x 32768 u32 of device scratch, the
 // first half zero on entry (it is zero again on exit)
 hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
                                uint32_t *bins, uint32_t *subset_out, hipStream_t st);

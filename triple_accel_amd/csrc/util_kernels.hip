@@ -119,9 +119,9 @@ hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint
 // scatter (a block reserves its share of every bin with one atomic, its pairs take their places through LDS counters).  The
 // order inside a bin is whatever the atomics make it -- the results are per pair and do not depend on it.
 constexpr uint32_t LEN_BINS = 1024, LEN_PAIRS_PER_BLOCK = 2048, LEN_PPT = LEN_PAIRS_PER_BLOCK / 256;
-// every bin has LEN_SUB counters (a block uses the one of its index mod LEN_SUB): a thousand blocks bumping the same ~30 addresses
-// serialise at the L2 (18 us per million pairs with one counter per bin)
-constexpr uint32_t LEN_SUB = 8;
+// every bin has LEN_SUB counters (a block uses the one of its index mod LEN_SUB): hundreds of blocks bumping the same ~30 addresses
+// serialise at the L2 (18 us per million pairs with one counter per bin, 15.7 with 8)
+constexpr uint32_t LEN_SUB = 32;     // counters laid out [sub][bin]: the scan reads them coalesced
 __device__ __forceinline__ uint32_t len_key(const StrView &a, const StrView &b, uint32_t pair, uint32_t u, uint32_t shift) {
     const uint64_t la = a.off ? a.off[pair + 1] - a.off[pair] : a.len, lb = b.off ? b.off[pair + 1] - b.off[pair] : b.len;
     const uint64_t mx = la > lb ? la : lb, mn = la > lb ? lb : la;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void len_hist_kernel(StrView a, StrView b, con
         if (pair[q] != 0xFFFFFFFFu) atomicAdd(&h[key[q]], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u)
-        if (h[i]) atomicAdd(&hist[i * LEN_SUB + (blockIdx.x % LEN_SUB)], h[i]);
+        if (h[i]) atomicAdd(&hist[(blockIdx.x % LEN_SUB) * LEN_BINS + i], h[i]);
 }
 // hist -> exclusive prefix sums in `cursor`; hist itself goes back to zero (the next call's starting state: no fill per call)
 __global__ __launch_bounds__(LEN_BINS) void len_scan_kernel(uint32_t *hist, uint32_t *cursor) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(LEN_BINS) void len_scan_kernel(uint32_t *hist, uint
     const uint32_t t = threadIdx.x;
     uint32_t part[LEN_SUB], tot = 0;
 #pragma unroll
-    for (uint32_t q = 0; q < LEN_SUB; q++) { part[q] = hist[t * LEN_SUB + q]; hist[t * LEN_SUB + q] = 0; tot += part[q]; }
+    for (uint32_t q = 0; q < LEN_SUB; q++) { part[q] = hist[q * LEN_BINS + t]; hist[q * LEN_BINS + t] = 0; tot += part[q]; }
     s[t] = tot;
     __syncthreads();
     for (uint32_t d = 1; d < LEN_BINS; d <<= 1) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(LEN_BINS) void len_scan_kernel(uint32_t *hist, uint
     }
     uint32_t run = t ? s[t - 1] : 0u;
 #pragma unroll
-    for (uint32_t q = 0; q < LEN_SUB; q++) { cursor[t * LEN_SUB + q] = run; run += part[q]; }
+    for (uint32_t q = 0; q < LEN_SUB; q++) { cursor[q * LEN_BINS + t] = run; run += part[q]; }
 }
 __global__ __launch_bounds__(256) void len_scatter_kernel(StrView a, StrView b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint32_t shift,
                                                           uint32_t *cursor, uint32_t *subset_out) {
@@ -186,13 +186,13 @@ __global__ __launch_bounds__(256) void len_scatter_kernel(StrView a, StrView b, 
         if (pair[q] != 0xFFFFFFFFu) rank[q] = atomicAdd(&h[key[q]], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < LEN_BINS; i += 256u)
-        if (h[i]) h[i] = atomicAdd(&cursor[i * LEN_SUB + (blockIdx.x % LEN_SUB)], h[i]);     // the block's first place in bin i
+        if (h[i]) h[i] = atomicAdd(&cursor[(blockIdx.x % LEN_SUB) * LEN_BINS + i], h[i]);     // the block's first place in bin i
     __syncthreads();
 #pragma unroll
     for (uint32_t q = 0; q < LEN_PPT; q++)
         if (pair[q] != 0xFFFFFFFFu) subset_out[h[key[q]] + rank[q]] = pair[q];
 }
-// bins: 2 * LEN_BINS * LEN_SUB u32 (64 KiB) of device scratch whose first half is ZERO on entry (and again on exit: zero it once, when it is
+// bins: 2 * LEN_BINS * LEN_SUB u32 (256 KiB) of device scratch whose first half is ZERO on entry (and again on exit: zero it once, when it is
 // allocated); subset_out: n u32.  max_len = the batch's longest string.
 hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
                                uint32_t *bins, uint32_t *subset_out, hipStream_t st) {
