@@ -323,9 +323,9 @@ using namespace ta;
 extern "C" {
 
 #ifdef TA_EXPERIMENTAL
-const char *ta_version(void) { return "triple_accel_amd 0.2 (gfx950) +experimental"; }
+const char *ta_version(void) { return "triple_accel_amd 0.3 (gfx950) +experimental"; }
 #else
-const char *ta_version(void) { return "triple_accel_amd 0.2 (gfx950)"; }
+const char *ta_version(void) { return "triple_accel_amd 0.3 (gfx950)"; }
 #endif
 
 const char *ta_status_str(int s) {
