@@ -71,6 +71,17 @@ bandab)
   for rep in 1 2; do
     for wl in cfg2w cfg4w; do echo "$wl: $(run --workload $wl --steps 30 --warmup 5)"; done
   done 2>&1 | tee $O/bandab.txt ;;
+scoreab)   # round 3: the band kernel's score form (cells as gc (i+j) - dp) against its cost form
+  timeout 1800 python -m pytest tests/test_gpu_lev_batch.py tests/test_gpu_trace.py tests/test_gpu_kats.py tests/test_gpu_edge.py -x -q 2>&1 | tail -5 | tee $O/pytest_band.txt
+  for rep in 1 2; do
+    for wl in cfg2w cfg4w; do
+      echo "$wl score form: $(run --workload $wl --steps 30 --warmup 5)"
+      echo "$wl cost form:  $(TA_TUNING=1 TA_NO_SCORE_FORM=1 run --workload $wl --steps 30 --warmup 5)"
+    done
+    echo "cfg2 (unit costs through the DP kernel) score form: $(TA_TUNING=1 TA_NO_BITS=1 run --workload cfg2 --steps 20 --warmup 3)"
+    echo "cfg2 (unit costs through the DP kernel) cost form:  $(TA_TUNING=1 TA_NO_BITS=1 TA_NO_SCORE_FORM=1 run --workload cfg2 --steps 20 --warmup 3)"
+    echo "cfg2w ragged score form: $(run --workload cfg2w --dist ragged --steps 20 --warmup 3)"
+  done 2>&1 | tee $O/scoreab.txt ;;
 sizes)
   for rep in 1 2; do
     for n in 500000 1000000 2000000 4000000; do

@@ -11,10 +11,23 @@
 
 using namespace ta;
 
+int g_emu_score = -1;   // -1: as the launcher (score form wherever lev_score_form_applies), 0: cost form always
+extern "C" void emu_lev_set_score(int v) { g_emu_score = v; }
+extern "C" int emu_lev_score_applies(uint32_t mc, uint32_t gc, int trans) { return lev_score_form_applies(mc, gc, trans) ? 1 : 0; }
+
 template <int D, bool L1> static void run_dl(const LevParams &P, bool affine, int trans, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
+    const bool score = g_emu_score != 0 && lev_score_form_applies(P.mc, P.gc, trans);
     for (uint32_t w = 0; w < waves; w++) {
-        if (affine) {
+        if (score) {
+            if (affine) {
+                if (trans == 1) LevBand<EmuWave, D, true, 1, false, L1, true>::run(P, w, lds);
+                else LevBand<EmuWave, D, true, 0, false, L1, true>::run(P, w, lds);
+            } else {
+                if (trans == 1) LevBand<EmuWave, D, false, 1, false, L1, true>::run(P, w, lds);
+                else LevBand<EmuWave, D, false, 0, false, L1, true>::run(P, w, lds);
+            }
+        } else if (affine) {
             if (trans == 1) LevBand<EmuWave, D, true, 1, false, L1>::run(P, w, lds);
             else if (trans == 2) LevBand<EmuWave, D, true, 2, false, L1>::run(P, w, lds);
             else LevBand<EmuWave, D, true, 0, false, L1>::run(P, w, lds);

@@ -52,6 +52,9 @@ struct EmuWave {
     static Bool land(const Bool &a, const Bool &b) { return a & b; }
     static U32 umin(const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
     static U32 umin3(const U32 &a, const U32 &b, const U32 &c) { return umin(umin(a, b), c); }
+    static U32 imax(const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (int32_t)a.v[i] > (int32_t)b.v[i] ? a.v[i] : b.v[i]; return r; }
+    static U32 imax3(const U32 &a, const U32 &b, const U32 &c) { return imax(imax(a, b), c); }
+    static U32 sel_bits(const U32 &m, const U32 &a, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m.v[i]) | (b.v[i] & ~m.v[i]); return r; }
     static U32 udiv(const U32 &a, uint32_t d) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] / d; return r; }
     template <int N> static U32 alignbyte(const U32 &hi, const U32 &lo) {
         V32 r;
@@ -158,6 +161,7 @@ struct EmuWave {
         for (int l = 0; l < 64; l++) r.v[l] = i == 0 ? q.v[l].x : i == 1 ? q.v[l].y : i == 2 ? q.v[l].z : q.v[l].w;
         return r;
     }
+    static Q128V qxor_v(Q128V q, const U32 &c) { for (int l = 0; l < 64; l++) { q.v[l].x ^= c.v[l]; q.v[l].y ^= c.v[l]; q.v[l].z ^= c.v[l]; q.v[l].w ^= c.v[l]; } return q; }
     static Q128V qxor(Q128V q, uint32_t c) { for (int l = 0; l < 64; l++) { q.v[l].x ^= c; q.v[l].y ^= c; q.v[l].z ^= c; q.v[l].w ^= c; } return q; }
     static void lds_store16(uint8_t *lds, const U32 &off, const Q128V &q, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &q.v[i], 16);
@@ -210,6 +214,7 @@ struct EmuWave {
     static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }
     static U32 lds_read32(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], lds + off.v[i], 4); return r; }
     static void lds_write32(uint8_t *lds, const U32 &off, const U32 &v) { for (int i = 0; i < 64; i++) memcpy(lds + off.v[i], &v.v[i], 4); }
+    static void lds_write32p(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) { for (int i = 0; i < 64; i++) if (pred.v[i]) memcpy(lds + off.v[i], &v.v[i], 4); }
     static void lds_or32(uint8_t *lds, const U32 &off, const U32 &v, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) { uint32_t t; memcpy(&t, lds + off.v[i], 4); t |= v.v[i]; memcpy(lds + off.v[i], &t, 4); }
     }

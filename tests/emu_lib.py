@@ -67,10 +67,19 @@ def pack(strings):
     return blob, off
 
 
+def lev_band_score_applies(costs, force_trans_select=False):
+    """what the launcher decides: the score form of the band kernel for these costs?"""
+    mc, gc, sg, tc = costs
+    trans = 0 if tc is None else (1 if 2 * mc <= 255 + tc and not force_trans_select else 2)
+    return bool(lib().emu_lev_score_applies(mc, gc, trans))
+
+
 def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False,
-             chunk=0):
-    """-> (list of dist|None, plan dict); chunk = bytes per streamed LDS chunk (0: the planner's choice)"""
+             chunk=0, score=True):
+    """-> (list of dist|None, plan dict); chunk = bytes per streamed LDS chunk (0: the planner's choice);
+    score=False: the cost form even where the launcher would take the score form"""
     lib().emu_lev_set_chunk(int(chunk))
+    lib().emu_lev_set_score(-1 if score else 0)
     n = len(a_list)
     ab, ao = pack(a_list)
     bb, bo = pack(b_list)

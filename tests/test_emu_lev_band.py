@@ -168,3 +168,48 @@ def test_emu_stream_chunk_lengths(chunk):
         for D, L in [(0, 0), (4, 0), (24, 2)]:
             got, plan = E.lev_band(a, b, k, costs, force_D=D, force_L=L, chunk=chunk)
             assert got == oracle(a, b, k, costs), (chunk, costs, k, plan)
+
+
+# ---- round 3: the score form (cells hold gc (i+j) - dp, maxima instead of minima) against the cost form and the oracle
+
+SCORE_COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 3, 1, None), (2, 2, 1, 3), (2, 1, 0, None), (1, 2, 0, None), (254, 127, 0, None),
+               (254, 127, 255, 253), (3, 2, 0, 2), (1, 127, 7, None), (4, 2, 255, None), (2, 1, 3, 1)]
+
+
+@pytest.mark.parametrize("costs", SCORE_COSTS)
+def test_emu_score_form_against_cost_form(costs):
+    assert O.costs_valid(costs) and E.lev_band_score_applies(costs)
+    a, b = make_pairs(31 + costs[0], 130, 70, 7, costs[3] is not None)
+    a += [b"", b"x", b"", b"abc" * 30, b"\0" * 50]
+    b += [b"", b"", b"yy", b"abc" * 29 + b"ab", b"\0" * 47]
+    for k in (0, 3, costs[1] * 6 + costs[2], 40, 300, 0xFFFFFFFF):
+        want = oracle(a, b, k, costs)
+        g_score, plan = E.lev_band(a, b, k, costs)
+        g_cost, _ = E.lev_band(a, b, k, costs, score=False)
+        assert g_score == want, (k, costs, plan)
+        assert g_cost == want, (k, costs, plan)
+
+
+@pytest.mark.parametrize("force_D,force_L", [(2, 8), (4, 4), (6, 1), (12, 1), (12, 2), (34, 1), (16, 64)])
+def test_emu_score_form_lane_layouts(force_D, force_L):
+    k = min(force_D * force_L - 2, 60)
+    for costs in [(2, 3, 1, None), (2, 2, 1, 3), (1, 1, 0, None), (2, 1, 0, 2)]:
+        ku = k * costs[1] + costs[2]
+        a, b = make_pairs(11 + force_D, 80, 75, max(1, k // 2), costs[3] is not None)
+        got, plan = E.lev_band(a, b, ku, costs, force_D=force_D, force_L=force_L)
+        assert (plan["D"], plan["L"]) == (force_D, force_L)
+        assert got == oracle(a, b, ku, costs), (ku, costs, plan)
+        assert E.lev_band(a, b, ku, costs, force_D=force_D, force_L=force_L, score=False)[0] == got
+
+
+def test_emu_score_form_rule():
+    """2 gc - mc and 2 gc are bytes of a v_dot4: the rule that keeps everything else on the cost form"""
+    assert not E.lev_band_score_applies((3, 1, 0, None))          # a mismatch dearer than two gap steps (possible with affine gaps)
+    assert not E.lev_band_score_applies((1, 128, 0, None))        # 2 gc > 255
+    assert not E.lev_band_score_applies((200, 130, 0, 255))
+    assert not E.lev_band_score_applies((2, 2, 1, 3), force_trans_select=True)
+    assert E.lev_band_score_applies((254, 127, 0, None)) and E.lev_band_score_applies((2, 1, 9, 0 + 1))
+    # and the costs the rule excludes still come out right (cost form)
+    a, b = make_pairs(5, 90, 60, 5, False)
+    for costs in [(3, 1, 0, None), (1, 128, 0, None), (255, 127, 3, None)]:
+        assert E.lev_band(a, b, 900, costs)[0] == oracle(a, b, 900, costs)

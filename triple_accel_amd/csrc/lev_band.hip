@@ -1,5 +1,6 @@
 // lev_band.hip -- gfx950 instantiations of the band-wavefront kernel (lev_band_body.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "lev_band_body.h"
 #include "lev_plan.h"
@@ -29,6 +30,9 @@ static hipError_t launch_d(const LevParams &P, bool affine, int trans, uint32_t 
     return hipGetLastError();
 }
 
+// lev_band_score.hip: the score-form instantiations (their own translation unit: as many kernels again)
+hipError_t lev_band_score_launch(const LevParams &P, const LevPlan &pl, bool affine, int trans, uint32_t grid, size_t lds, hipStream_t s);
+
 // Launches the kernel for plan `pl`; returns the grid size through *grid_out.
 hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, int trans, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out) {
@@ -38,6 +42,9 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
+    // cells as scores gc (i+j) - dp wherever the costs allow it (lev_plan.h): 5 instructions per affine cell instead of 7
+    static const bool no_score = env_str("TA_NO_SCORE_FORM") != nullptr;       // tuning switch (TA_TUNING=1): the cost form always
+    if (!no_score && lev_score_form_applies(P.mc, P.gc, trans)) return lev_band_score_launch(P, pl, affine, trans, grid, lds, s);
     set_last_kernel_name("lev_band_kernel<%d, %s, %d, %s>", pl.D, affine ? "true" : "false", trans, P.L == 1 ? "true" : "false");
     switch (pl.D) {
 #define TA_CASE(d) case d: return launch_d<d>(P, affine, trans, grid, lds, s);

@@ -27,6 +27,7 @@
 namespace ta {
 
 constexpr uint32_t LEV_INF = 0x3FFFFFFFu;   // "unreachable"; real costs stay far below (n+m < 2^22)
+constexpr uint32_t LEV_NEG = 0xC0000001u;   // the same in the score form: -LEV_INF as a signed number
 // Streamed chunk = P.ch iterations (= bytes per string; 16, 32 or 64, lev_plan.h), ring = 2 chunks per (pair, string)
 // slot in LDS, slot stride = ring + 4: an odd number of dwords, so the per-pair byte reads hit distinct banks
 // (slot order: the PW rings of `a`, then the PW rings of `b`).
@@ -63,11 +64,20 @@ constexpr int lev_trace_words(int D) { return (D + 31) / 32; }   // 2 bits x D/2
 
 // TRANS: 0 = no transposition, 1 = transposition as a dot4 penalty (needs 2*mc <= 255 + tc), 2 = as a select
 // L1: one lane per pair (the band fits D diagonals: P.L == 1) -- no neighbour lane, so no DPP moves and no edge selects
-template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false, bool L1 = false>
+// SCORE: the cells hold S(i,j) = gc (i+j) - dp(i,j) as SIGNED numbers and the recurrence takes maxima.  A gap step then costs
+//   nothing (dp + gc at step s+1 is the same S), the substitution adds the byte 2 gc - mc [a != b] (one v_dot4 with a one-hot
+//   multiplier of 1), and an affine cell is dot4, max3, one subtraction of sg, two max: 5 instructions against 7 (linear gaps:
+//   2 against 2.5).  Needs 0 <= 2 gc - mc and 2 gc <= 255 (lev_score_form_applies, lev_plan.h); answers are identical -- the
+//   map is monotone and exact in 32-bit integers (|S| < 2^31: lengths as for LEV_INF).
+template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false, bool L1 = false, bool SCORE = false>
 struct LevBand {
     static_assert(D % 2 == 0 && D >= 2, "D must be even");
+    static_assert(!SCORE || (!TRACE && TRANS != 2), "the score form has no traceback and no select-form transposition");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
     static constexpr int NW = (Dh + 2 + 3) / 4;      // packed window registers (Dh+2 bytes used)
+    // without the transposition test the a-window holds a ^ 0x0C (XOR-ed once per 16 bytes on the way into LDS), so the byte test's
+    // operand a ^ b ^ 0x0C is ONE v_xor per window register
+    static constexpr bool AX = (TRANS == 0);
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
@@ -87,7 +97,7 @@ struct LevBand {
     template <int PAR>
     static TA_HD inline __attribute__((always_inline)) void phase(State &st, const LevParams &P, Bool is_g0, Bool is_gl,
                                                                   uint32_t tau, U32 lane) {
-        const U32 INF = W::splat(LEV_INF);
+        const U32 INF = W::splat(SCORE ? LEV_NEG : LEV_INF);     // "unreachable" in the form the cells are held in
         U32 X[NW], Z[NW];
         U32 tcodes[lev_trace_words(D)];
         if (TRACE) {
@@ -102,8 +112,10 @@ struct LevBand {
             for (int w = 0; w < NW; w++) {
                 // b[j-2] and a[i-2] are exactly what the windows held before their last advance: no re-alignment needed
                 Z[w] = (st.AW[w] ^ st.BWp[w]) | (st.AWp[w] ^ st.BW[w]);
-                if (TRANS == 1)     // 1 per cell whose transposition test FAILS (non-zero byte; W::ne12: one v_perm_b32 byte test)
+                if (TRANS == 1 && !SCORE)     // 1 per cell whose transposition test FAILS (non-zero byte; W::ne12: one v_perm_b32 byte test)
                     Z[w] = W::ne12(Z[w] ^ 0x0C0C0C0Cu) & 0x01010101u;
+                if (TRANS == 1 && SCORE)      // 1 per cell whose test PASSES (one v_bfi_b32 instead of the v_and_b32)
+                    Z[w] = W::sel_bits(W::ne12(Z[w] ^ 0x0C0C0C0Cu), W::splat(0), W::splat(0x01010101u));
             }
         }
         // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
@@ -113,7 +125,7 @@ struct LevBand {
         if (L1) {
             // every lane is its pair's first and last: both band edges
         } else if (PAR == 0) {
-            xl = W::from_lower0(st.HA[D - 1]);
+            xl = W::from_lower0((SCORE && !AFFINE) ? st.reg[D - 1] : st.HA[D - 1]);
             xl = W::sel(is_g0, INF, xl);            // band edge: nothing left of the pair's first diagonal
         } else {
             xr = W::from_upper0(AFFINE ? st.HB[0] : st.reg[0]);
@@ -121,9 +133,13 @@ struct LevBand {
         }
         // per byte: 1 where a != b, four cells per VGPR (SWAR); each cell's substitution cost is then ONE
         // v_dot4_u32_u8 with a one-hot byte of mismatch_cost: reg + flag_byte * mc
+        if (SCORE) {
+            score_phase<PAR>(st, P, X, Z, xl, xr);
+            return;
+        }
 #pragma unroll
         for (int w = 0; w < NW; w++)                          // 1 per nonzero byte: x ^ 0x0C is 12 exactly where x is 0, and one
-            X[w] = W::ne12(X[w] ^ 0x0C0C0C0Cu) & 0x01010101u;  // v_perm_b32 with all-ones sources maps 12 to 0x00, the rest to 0xFF
+            X[w] = W::ne12(AX ? X[w] : X[w] ^ 0x0C0C0C0Cu) & 0x01010101u;  // v_perm_b32 with all-ones sources maps 12 to 0x00, the rest to 0xFF
         // all substitution candidates first: a v_dot4 result needs 3 wait states before another VALU may read it,
         // so the mins below must not directly follow their own dot4
         U32 subv[Dh];
@@ -179,9 +195,51 @@ struct LevBand {
         }
     }
 
+    // The same step on scores (SCORE): X = a ^ b per byte, Z = the transposition test's bytes (zero = passes).
+    template <int PAR>
+    static TA_HD inline __attribute__((always_inline)) void score_phase(State &st, const LevParams &P, U32 (&X)[NW], U32 (&Z)[NW], U32 xl, U32 xr) {
+        // per byte: 2 gc where a == b, 2 gc - mc where not -- what S(i-1,j-1) gains on the way to step i+j   (:471-475)
+        const U32 v_ne = W::splat((2u * P.gc - P.mc) * 0x01010101u), v_eq = W::splat(2u * P.gc * 0x01010101u);
+#pragma unroll
+        for (int w = 0; w < NW; w++) X[w] = W::sel_bits(W::ne12(AX ? X[w] : X[w] ^ 0x0C0C0C0Cu), v_ne, v_eq);
+        U32 subv[Dh];
+#pragma unroll
+        for (int c = 0; c < Dh; c++) subv[c] = W::dot4_byte(X[(c + 1) >> 2], (c + 1) & 3, 1u, st.reg[2 * c + PAR]);
+        U32 tqv[TRANS == 1 ? Dh : 1];
+        if (TRANS == 1) {
+            // PV holds S(i-2,j-2) + 4 gc - tc - 255; a passed test gives the 255 back, a failed one leaves the candidate
+            // below nv (the cost form's argument, :523-525, through the same monotone map)
+#pragma unroll
+            for (int c = 0; c < Dh; c++) tqv[c] = W::dot4_byte(Z[(c + 1) >> 2], (c + 1) & 3, 255u, st.PV[2 * c + PAR]);
+        }
+        const uint32_t t_gain = 4u * P.gc - P.tc - 255u;      // wraps: a signed constant
+#pragma unroll
+        for (int c = 0; c < Dh; c++) {
+            const int q = 2 * c + PAR;
+            const int ql = q > 0 ? q - 1 : 0, qr = q + 1 < D ? q + 1 : D - 1;
+            U32 lft = (PAR == 0 && c == 0) ? xl : (AFFINE ? st.HA[ql] : st.reg[ql]);          // a_gap  :476-483
+            U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : st.reg[qr]);      // b_gap  :484-491
+            U32 nv = W::imax3(subv[c], lft, rgt);                                              // :493-515
+            if (TRANS == 1) {
+                st.PV[q] = st.reg[q] + t_gain;
+                nv = W::imax(nv, tqv[c]);
+            }
+            st.reg[q] = nv;
+            if (AFFINE) {
+                U32 go = nv - P.sg;                    // open a gap from this cell
+                // or extend the gap that reached the cell: free on scores.  (L1: beyond the band's edge there is no such gap)
+                st.HA[q] = (L1 && PAR == 0 && c == 0) ? go : W::imax(go, lft);
+                st.HB[q] = (L1 && PAR == 1 && c == Dh - 1) ? go : W::imax(go, rgt);
+            }
+        }
+    }
+
     // a-window: every char moves one cell up (new row enters at cell 0) -- src/levenshtein.rs:1027-1031
+    // (the new char is byte BI of a_in: the hot loop reads the ring four bytes at a time and the intake's v_perm picks the byte)
+    template <int BI = 0>
     static TA_HD inline __attribute__((always_inline)) void advance_a(State &st, U32 a_in, Bool is_g0) {
         constexpr int sb = Dh;   // byte Dh = cell Dh-1 = the char the next lane needs
+        constexpr uint32_t BIe = L1 ? BI : 0;
         if (TRANS) {
 #pragma unroll
             for (int w = 0; w < NW; w++) st.AWp[w] = st.AW[w];
@@ -190,15 +248,16 @@ struct LevBand {
         if (!L1) {
             t = st.AW[sb >> 2] >> (8 * (sb & 3));
             t = W::from_lower0(t);
-            t = W::sel(is_g0, a_in, t);
+            t = W::sel(is_g0, BI ? a_in >> (8 * BI) : a_in, t);
         }
-        st.AW[0] = W::bfi(0xffu, t, st.AW[0]);
 #pragma unroll
         for (int w = NW - 1; w >= 1; w--) st.AW[w] = W::template alignbyte<3>(st.AW[w], st.AW[w - 1]);
-        st.AW[0] = st.AW[0] << 8;
+        st.AW[0] = W::template perm<0x0605000Cu | (BIe << 8)>(st.AW[0], t);      // bytes 1, 2 move up, the new char lands in byte 1, byte 0 = 0
     }
     // b-window: every char moves one cell down (new column enters at cell Dh-1) -- :1033-1037
+    template <int BI = 0>
     static TA_HD inline __attribute__((always_inline)) void advance_b(State &st, U32 b_in, Bool is_gl) {
+        constexpr uint32_t BIe = L1 ? BI : 0;
         if (TRANS) {
 #pragma unroll
             for (int w = 0; w < NW; w++) st.BWp[w] = st.BW[w];
@@ -207,13 +266,23 @@ struct LevBand {
         if (!L1) {
             t = st.BW[0] >> 8;   // byte 1 = cell 0
             t = W::from_upper0(t);
-            t = W::sel(is_gl, b_in, t);
+            t = W::sel(is_gl, BI ? b_in >> (8 * BI) : b_in, t);
         }
-        constexpr int ib = Dh + 1, iw = ib >> 2, ish = 8 * (ib & 3);
-        st.BW[iw] = W::bfi(0xffu << ish, t << ish, st.BW[iw]);
+        constexpr int ib = Dh + 1, ibm = ib & 3;     // the intake byte: byte ibm of the LAST window register (the bytes above it stay 0)
+        static_assert((ib >> 2) == NW - 1, "intake byte in the last window register");
+        if constexpr (ibm == 0) {
+            // the last register holds nothing but the intake: it goes straight into the register below
 #pragma unroll
-        for (int w = 0; w < NW - 1; w++) st.BW[w] = W::template alignbyte<1>(st.BW[w + 1], st.BW[w]);
-        st.BW[NW - 1] = st.BW[NW - 1] >> 8;
+            for (int w = 0; w < NW - 2; w++) st.BW[w] = W::template alignbyte<1>(st.BW[w + 1], st.BW[w]);
+            st.BW[NW - 2] = W::template perm<0x00070605u | (BIe << 24)>(st.BW[NW - 2], t);
+            static_assert(ibm != 0 || NW >= 2, "Dh + 1 = 0 mod 4 means at least two registers");
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW - 1; w++) st.BW[w] = W::template alignbyte<1>(st.BW[w + 1], st.BW[w]);
+            // one v_perm: the bytes below the intake move down, the new char lands in byte ibm - 1, zeros above
+            constexpr uint32_t s0 = ibm == 1 ? BIe : 0x05u, s1 = ibm == 1 ? 0x0Cu : (ibm == 2 ? BIe : 0x06u), s2 = ibm == 3 ? BIe : 0x0Cu;
+            st.BW[NW - 1] = W::template perm<(0x0Cu << 24) | (s2 << 16) | (s1 << 8) | s0>(st.BW[NW - 1], t);
+        }
     }
 
     // Stream chunk kc (iterations [kc*CH, kc*CH+CH)) of every pair's two strings into the LDS ring.  The 8 pieces
@@ -232,13 +301,16 @@ struct LevBand {
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
             auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, bptr, aptr), idx0), ok);
+            if (AX) q = W::qxor_v(q, W::sel(isb, W::splat(0), W::splat(0x0C0C0C0Cu)));
             U32 slot = grp + W::sel(isb, W::splat(P.PW), W::splat(0));   // all `a` rings, then all `b` rings
             W::lds_store16(lds, slot * lev_slot_bytes(CH) + (y0 & (2u * CH - 1u)), q, pred);
+            // the ring's first four bytes again behind its end (the slot's 4 spare bytes): a 4-byte read may start at any ring byte
+            W::lds_write32p(lds, slot * lev_slot_bytes(CH) + 2u * CH, W::qword(q, 0), pred & ((y0 & (2u * CH - 1u)) == 0u));
         }
     }
 
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
-        const U32 INF = W::splat(LEV_INF);
+        const U32 INF = W::splat(SCORE ? LEV_NEG : LEV_INF);
         const U32 lane = W::lane();
         const uint32_t L = P.L;
         const U32 grp = W::udiv(lane, L);
@@ -282,7 +354,7 @@ struct LevBand {
             if (TRANS) st.PV[q] = INF;
         }
 #pragma unroll
-        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(0); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(0); st.BWp[w] = W::splat(0); }
+        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(AX ? 0x0C0C0C0Cu : 0u); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(0); st.BWp[w] = W::splat(0); }
         {   // seed dp(0,0) = 0 on diagonal p = o  (:450-452 row 0 then grows through the a_gap chain)
             const U32 gs = W::udiv(o, (uint32_t)D), qs = o - gs * (uint32_t)D;
             const Bool seed_lane = (g == gs);
@@ -290,8 +362,8 @@ struct LevBand {
             for (int q = 1; q < D; q += 2) {
                 Bool hit = seed_lane & (qs == (uint32_t)q);
                 st.reg[q] = W::sel(hit, W::splat(0), st.reg[q]);
-                st.HA[q] = W::sel(hit, W::splat(AFFINE ? P.sg + P.gc : 2u * P.gc), st.HA[q]);
-                if (AFFINE) st.HB[q] = W::sel(hit, W::splat(P.sg + P.gc), st.HB[q]);
+                st.HA[q] = W::sel(hit, W::splat(SCORE ? 0u - P.sg : (AFFINE ? P.sg + P.gc : 2u * P.gc)), st.HA[q]);
+                if (AFFINE) st.HB[q] = W::sel(hit, W::splat(SCORE ? 0u - P.sg : P.sg + P.gc), st.HB[q]);
             }
         }
         U32 ans = W::sel(s_ans == 0u, W::splat(0), INF);
@@ -324,7 +396,30 @@ struct LevBand {
                 advance_b(st, b_in, is_gl);
                 advance_a(st, a_in, is_g0);
             }
-            // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase)
+            // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase).  Four iterations per
+            // pair of 4-byte ring reads while the chunk lasts (one address computation per four chars), single bytes for the rest.
+            auto capture = [&](uint32_t t_now) {
+                Bool cap = (t_cap == t_now);
+                if (W::any(cap)) {                 // the answer cell was written in this iteration
+                    U32 r = INF;
+#pragma unroll
+                    for (int q = 0; q < D; q++) r = W::sel(q_ans == (uint32_t)q, st.reg[q], r);
+                    if (!AFFINE && !SCORE) r = r - W::sel((q_ans & 1u) == 0u, W::splat(P.gc), W::splat(0));   // un-bias an even-q cell
+                    ans = W::sel(cap, r, ans);
+                }
+            };
+            for (; tp + 4u <= t_hi; tp += 4u) {
+                U32 a4 = W::lds_read32u(lds, a_slot + ((da + tp) & RMASK));
+                U32 b4 = W::lds_read32u(lds, b_slot + ((db + tp) & RMASK));
+#define TA_BAND_ITER(i) \
+                phase<0>(st, P, is_g0, is_gl, tp + i - Tw, lane); \
+                advance_b<i>(st, b4, is_gl); \
+                phase<1>(st, P, is_g0, is_gl, tp + i - Tw, lane); \
+                advance_a<i>(st, a4, is_g0); \
+                capture(tp + i);
+                TA_BAND_ITER(0) TA_BAND_ITER(1) TA_BAND_ITER(2) TA_BAND_ITER(3)
+#undef TA_BAND_ITER
+            }
             for (; tp < t_hi; tp++) {
                 U32 a_in = W::lds_u8(lds, a_slot + ((da + tp) & RMASK));
                 U32 b_in = W::lds_u8(lds, b_slot + ((db + tp) & RMASK));
@@ -332,20 +427,14 @@ struct LevBand {
                 advance_b(st, b_in, is_gl);
                 phase<1>(st, P, is_g0, is_gl, tp - Tw, lane);
                 advance_a(st, a_in, is_g0);
-                Bool cap = (t_cap == tp);
-                if (W::any(cap)) {                 // the answer cell was written in this iteration
-                    U32 r = INF;
-#pragma unroll
-                    for (int q = 0; q < D; q++) r = W::sel(q_ans == (uint32_t)q, st.reg[q], r);
-                    if (!AFFINE) r = r - W::sel((q_ans & 1u) == 0u, W::splat(P.gc), W::splat(0));   // un-bias an even-q cell
-                    ans = W::sel(cap, r, ans);
-                }
+                capture(tp);
             }
         }
 
         // the owning lane holds the distance; the pair's first lane writes the result
         U32 d = W::shfl(ans, grp * L + g_ans);
-        Bool some = inband & (d <= P.k) & (d < INF);          // :539-541, :1166-1168
+        if (SCORE) d = s_ans * P.gc - d;                       // dp = gc (n + m) - S; an unreachable cell comes out >= LEV_INF
+        Bool some = inband & (d <= P.k) & (d < W::splat(LEV_INF));          // :539-541, :1166-1168
         U32 res = W::sel(some, d, W::splat(0xFFFFFFFFu));
         W::store_u32(P.out, pair, res, valid & is_g0);
     }

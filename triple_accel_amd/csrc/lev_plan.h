@@ -156,6 +156,12 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
     return p;
 }
 
+// ---- score form of the DP band kernel (lev_band_body.h, SCORE): the cells hold gc (i+j) - dp, so the substitution adds the byte
+// 2 gc - mc [a != b]: both bytes must be in 0..255.  trans: 0 none, 1 dot4 penalty, 2 select form (cost form only).
+static inline bool lev_score_form_applies(uint32_t mc, uint32_t gc, int trans) {
+    return trans != 2 && 2u * gc <= 255u && mc <= 2u * gc;
+}
+
 // ---- small alphabets (lev_bitsq_body.h): fixed-length unit-cost batches whose band (+ the transposition test's two extra rows) fits
 // the 33-diagonal window; the caller names at most four symbols (the launcher checks that a code hash exists for them)
 constexpr uint32_t LEV_BITSQ_MIN_PAIRS = 16384;

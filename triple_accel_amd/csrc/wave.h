@@ -42,6 +42,11 @@ struct DevWave {
     static __device__ __forceinline__ Bool land(Bool a, Bool b) { return a && b; }   // per-lane AND of two predicates (s_and_b64)
     static __device__ __forceinline__ U32 umin(U32 a, U32 b) { return a < b ? a : b; }
     static __device__ __forceinline__ U32 umin3(U32 a, U32 b, U32 c) { return umin(umin(a, b), c); }
+    // signed maxima of values held in U32 (the band kernel's score form) -> v_max_i32 / v_max3_i32
+    static __device__ __forceinline__ U32 imax(U32 a, U32 b) { return (int32_t)a > (int32_t)b ? a : b; }
+    static __device__ __forceinline__ U32 imax3(U32 a, U32 b, U32 c) { return imax(imax(a, b), c); }
+    // a where the mask bit is set, b elsewhere -> v_bfi_b32
+    static __device__ __forceinline__ U32 sel_bits(U32 m, U32 a, U32 b) { return (a & m) | (b & ~m); }
     static __device__ __forceinline__ U32 udiv(U32 a, uint32_t d) { return a / d; }
     // ({hi,lo} >> 8*n)[31:0], n in 0..3  -> v_alignbyte_b32
     template <int N> static __device__ __forceinline__ U32 alignbyte(U32 hi, U32 lo) {
@@ -170,6 +175,7 @@ struct DevWave {
         return q;
     }
     static __device__ __forceinline__ U32 qword(const Q128 &q, int i) { return i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w; }
+    static __device__ __forceinline__ Q128 qxor_v(Q128 q, U32 c) { q.x ^= c; q.y ^= c; q.z ^= c; q.w ^= c; return q; }
     static __device__ __forceinline__ Q128 qxor(Q128 q, uint32_t c) { q.x ^= c; q.y ^= c; q.z ^= c; q.w ^= c; return q; }
     static __device__ __forceinline__ void lds_store16(uint8_t *lds, U32 off, Q128 q, Bool pred) {
         if (pred) {   // 4-byte aligned only (slot stride is an odd number of dwords)
@@ -220,6 +226,7 @@ struct DevWave {
     template <int N>
     static __device__ __forceinline__ Bool byte_eq(U32 x, U32 y) { return ((x >> (8 * N)) & 0xFFu) == ((y >> (8 * N)) & 0xFFu); }
     static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
+    static __device__ __forceinline__ void lds_write32p(uint8_t *lds, U32 off, U32 v, Bool pred) { if (pred) *(uint32_t *)(lds + off) = v; }
     static __device__ __forceinline__ void lds_or32(uint8_t *lds, U32 off, U32 v, Bool pred) {   // ds_or_b32, no return
         if (pred) (void)__hip_atomic_fetch_or((uint32_t *)(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
