@@ -36,7 +36,8 @@ HALF = 4.2
 KERNELS = [
     ("cfg2", "lev_bits.hip", r"_ZN2ta18lev_bits_s8_kernelILb0ELb1ELb0E\w*", "8 columns of 64 pairs (33-diagonal band, stride-8 window, line form)", "all_live"),
     ("cfg4", "lev_bits.hip", r"_ZN2ta16lev_bits2_kernelILb1ELb0E\w*", "the span loop: 16 columns of 128 pairs with their commits (11-diagonal band + transposition, two pairs per lane, stride-8 window)"),
-    ("cfg2w", "lev_band_score.hip", r"_ZN2ta21lev_band_score_kernelILi12ELb1ELi0ELb1E\w*", "one iteration = two anti-diagonals = one column of 64 pairs x 12 diagonals (affine gaps)"),
+    ("cfg2w", "lev_band_score.hip", r"_ZN2ta21lev_band_score_kernelILi12ELb1ELi0ELb1E\w*", "four iterations = eight anti-diagonals = four columns of 64 pairs x 12 diagonals (affine gaps, score form)"),
+    ("cfg4w", "lev_band_score.hip", r"_ZN2ta21lev_band_score_kernelILi6ELb1ELi1ELb1E\w*", "four iterations = eight anti-diagonals = four columns of 64 pairs x 6 diagonals (affine gaps, transposition)"),
     ("cfg2_dna", "lev_bitsq.hip", r"_ZN2ta16lev_bitsq_kernelILb0E\w*", "the span loop, full and cut-short copies: 2 x 16 columns of 64 pairs with their conversions (33-diagonal band, match vectors from per-symbol tables)"),
     ("cfg3", "lev_widebits.hip", r"_ZN2ta19lev_widebits_kernelILi2ELb0E\w*", "two steps of the sweep: 2 x (64 lanes x 64 rows) cells of one pair (one pair per wavefront)", "first_dpp"),
     ("cfg5", "lev_search.hip", r"_ZN2ta17lev_filter_kernelILb0ELb1ELb0E\w*", "haystack bytes per lane (bit-parallel filter scan)"),

@@ -75,9 +75,9 @@ struct LevBand {
     static_assert(!SCORE || (!TRACE && TRANS != 2), "the score form has no traceback and no select-form transposition");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
     static constexpr int NW = (Dh + 2 + 3) / 4;      // packed window registers (Dh+2 bytes used)
-    // without the transposition test the a-window holds a ^ 0x0C (XOR-ed once per 16 bytes on the way into LDS), so the byte test's
-    // operand a ^ b ^ 0x0C is ONE v_xor per window register
-    static constexpr bool AX = (TRANS == 0);
+    // the a-window holds a ^ 0x0C (XOR-ed once per 16 bytes on the way into LDS), so the byte test's operand a ^ b ^ 0x0C is
+    // ONE v_xor per window register
+    static constexpr uint32_t C12 = 0x0C0C0C0Cu;
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     using Ptr = typename W::Ptr;
@@ -111,11 +111,12 @@ struct LevBand {
 #pragma unroll
             for (int w = 0; w < NW; w++) {
                 // b[j-2] and a[i-2] are exactly what the windows held before their last advance: no re-alignment needed
-                Z[w] = (st.AW[w] ^ st.BWp[w]) | (st.AWp[w] ^ st.BW[w]);
+                // (both a-windows carry the 0x0C: taken off inside the OR, put back for the byte test -- three-input functions, v_bitop3)
+                Z[w] = ((st.AW[w] ^ st.BWp[w]) ^ C12) | ((st.AWp[w] ^ st.BW[w]) ^ C12);
                 if (TRANS == 1 && !SCORE)     // 1 per cell whose transposition test FAILS (non-zero byte; W::ne12: one v_perm_b32 byte test)
-                    Z[w] = W::ne12(Z[w] ^ 0x0C0C0C0Cu) & 0x01010101u;
+                    Z[w] = W::ne12(Z[w] ^ C12) & 0x01010101u;
                 if (TRANS == 1 && SCORE)      // 1 per cell whose test PASSES (one v_bfi_b32 instead of the v_and_b32)
-                    Z[w] = W::sel_bits(W::ne12(Z[w] ^ 0x0C0C0C0Cu), W::splat(0), W::splat(0x01010101u));
+                    Z[w] = W::sel_bits(W::ne12(Z[w] ^ C12), W::splat(0), W::splat(0x01010101u));
             }
         }
         // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
@@ -139,7 +140,7 @@ struct LevBand {
         }
 #pragma unroll
         for (int w = 0; w < NW; w++)                          // 1 per nonzero byte: x ^ 0x0C is 12 exactly where x is 0, and one
-            X[w] = W::ne12(AX ? X[w] : X[w] ^ 0x0C0C0C0Cu) & 0x01010101u;  // v_perm_b32 with all-ones sources maps 12 to 0x00, the rest to 0xFF
+            X[w] = W::ne12(X[w]) & 0x01010101u;                 // v_perm_b32 with all-ones sources maps 12 to 0x00, the rest to 0xFF
         // all substitution candidates first: a v_dot4 result needs 3 wait states before another VALU may read it,
         // so the mins below must not directly follow their own dot4
         U32 subv[Dh];
@@ -201,7 +202,7 @@ struct LevBand {
         // per byte: 2 gc where a == b, 2 gc - mc where not -- what S(i-1,j-1) gains on the way to step i+j   (:471-475)
         const U32 v_ne = W::splat((2u * P.gc - P.mc) * 0x01010101u), v_eq = W::splat(2u * P.gc * 0x01010101u);
 #pragma unroll
-        for (int w = 0; w < NW; w++) X[w] = W::sel_bits(W::ne12(AX ? X[w] : X[w] ^ 0x0C0C0C0Cu), v_ne, v_eq);
+        for (int w = 0; w < NW; w++) X[w] = W::sel_bits(W::ne12(X[w]), v_ne, v_eq);
         U32 subv[Dh];
 #pragma unroll
         for (int c = 0; c < Dh; c++) subv[c] = W::dot4_byte(X[(c + 1) >> 2], (c + 1) & 3, 1u, st.reg[2 * c + PAR]);
@@ -301,7 +302,7 @@ struct LevBand {
             Bool ok = pred & (y0 >= e) & ((y0 - e) < len);
             U32 idx0 = W::sel(ok, y0 - e, W::splat(0));
             auto q = W::gload16(W::ptr_add(W::sel_ptr(isb, bptr, aptr), idx0), ok);
-            if (AX) q = W::qxor_v(q, W::sel(isb, W::splat(0), W::splat(0x0C0C0C0Cu)));
+            q = W::qxor_v(q, W::sel(isb, W::splat(0), W::splat(C12)));
             U32 slot = grp + W::sel(isb, W::splat(P.PW), W::splat(0));   // all `a` rings, then all `b` rings
             W::lds_store16(lds, slot * lev_slot_bytes(CH) + (y0 & (2u * CH - 1u)), q, pred);
             // the ring's first four bytes again behind its end (the slot's 4 spare bytes): a 4-byte read may start at any ring byte
@@ -354,7 +355,7 @@ struct LevBand {
             if (TRANS) st.PV[q] = INF;
         }
 #pragma unroll
-        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(AX ? 0x0C0C0C0Cu : 0u); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(0); st.BWp[w] = W::splat(0); }
+        for (int w = 0; w < NW; w++) { st.AW[w] = W::splat(C12); st.BW[w] = W::splat(0); st.AWp[w] = W::splat(C12); st.BWp[w] = W::splat(0); }
         {   // seed dp(0,0) = 0 on diagonal p = o  (:450-452 row 0 then grows through the a_gap chain)
             const U32 gs = W::udiv(o, (uint32_t)D), qs = o - gs * (uint32_t)D;
             const Bool seed_lane = (g == gs);
@@ -400,7 +401,7 @@ struct LevBand {
             // pair of 4-byte ring reads while the chunk lasts (one address computation per four chars), single bytes for the rest.
             auto capture = [&](uint32_t t_now) {
                 Bool cap = (t_cap == t_now);
-                if (W::any(cap)) {                 // the answer cell was written in this iteration
+                if (__builtin_expect(W::any(cap), 0)) {      // the answer cell was written in this iteration (rare: keep it a branch)
                     U32 r = INF;
 #pragma unroll
                     for (int q = 0; q < D; q++) r = W::sel(q_ans == (uint32_t)q, st.reg[q], r);
