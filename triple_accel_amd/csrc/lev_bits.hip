@@ -47,8 +47,13 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(
         LevBits<DevWave, 8, TRANS, false, LINE, true, EARLY>::run(Q, w, lds + wave * P.lds_per_wave);
 }
 
+#ifdef TA_BITS2_WAVES_PER_SIMD        // A/B builds only: cap the registers for this many wavefronts per SIMD
+#define TA_BITS2_ATTR __attribute__((amdgpu_waves_per_eu(TA_BITS2_WAVES_PER_SIMD, TA_BITS2_WAVES_PER_SIMD)))
+#else
+#define TA_BITS2_ATTR
+#endif
 template <bool TRANS, bool EARLY = false>
-__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits2_kernel(LevParams P) {
+__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) TA_BITS2_ATTR void lev_bits2_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6;
     LevBits2<DevWave, TRANS, EARLY>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);

@@ -46,7 +46,10 @@ struct LevBits2 {
     static constexpr int32_t RA = 2, RB = 1;
     static constexpr uint32_t SLOT_A = 16u * RA + 4u, SLOT_B = 16u * RB + 4u;   // + a wrap copy of the ring's first dword
     static constexpr uint32_t LDS_PER_WAVE = 128u * (SLOT_A + SLOT_B);
-    static constexpr int BURST = 4;                            // pieces per request: half a line
+#ifndef TA_BITS2_BURST
+#define TA_BITS2_BURST 4
+#endif
+    static constexpr int BURST = TA_BITS2_BURST, LOGB = BURST == 4 ? 2 : (BURST == 2 ? 1 : 3);   // pieces per request: half a line (A/B builds: 2, 8)
 
     struct State {
         U32 VP, VN, PMp, D0p;        // both pairs: bits 0..14 pair A, 16..30 pair B
@@ -149,9 +152,9 @@ struct LevBits2 {
         };
         auto put = [&](const Q (&S)[2][BURST], int32_t piece, const U32 (&slot)[2], uint32_t at, uint32_t wrap_copy_at, uint32_t x) {
             switch (piece & (BURST - 1)) {                     // wave-uniform: one of four stores per pair
-#define TA_PUT(c) case c: _Pragma("unroll") for (int h = 0; h < 2; h++) { const Q q = x ? W::qxor(S[h][c], x) : S[h][c]; W::lds_store16(lds, slot[h] + at, q, active); \
+#define TA_PUT(c_) case c_: _Pragma("unroll") for (int h = 0; h < 2; h++) { constexpr int c = c_ < BURST ? c_ : 0; const Q q = x ? W::qxor(S[h][c], x) : S[h][c]; W::lds_store16(lds, slot[h] + at, q, active); \
                               if (wrap_copy_at) W::lds_write32(lds, slot[h] + at + wrap_copy_at, W::qword(q, 0)); } break;
-                TA_PUT(0) TA_PUT(1) TA_PUT(2) TA_PUT(3)
+                TA_PUT(0) TA_PUT(1) TA_PUT(2) TA_PUT(3) TA_PUT(4) TA_PUT(5) TA_PUT(6) TA_PUT(7)
 #undef TA_PUT
             }
         };
@@ -159,12 +162,12 @@ struct LevBits2 {
         auto commit_a = [&](int32_t piece) {
             const uint32_t slot = fmod(piece, RA);
             put(SA, piece, a_slot, 16u * slot, slot == 0u ? 16u * RA : 0u, 0x0C0C0C0Cu);
-            if ((piece & (BURST - 1)) == BURST - 1) fetch(SA, aptr, alen_u, (piece >> 2) + 1);
+            if ((piece & (BURST - 1)) == BURST - 1) fetch(SA, aptr, alen_u, (piece >> LOGB) + 1);
         };
         auto commit_b = [&](int32_t piece) {
             const uint32_t slot = fmod(piece, RB);
             put(SB, piece, b_slot, 16u * slot, slot == 0u ? 16u * RB : 0u, 0u);
-            if ((piece & (BURST - 1)) == BURST - 1) fetch(SB, bptr, blen_u, (piece >> 2) + 1);
+            if ((piece & (BURST - 1)) == BURST - 1) fetch(SB, bptr, blen_u, (piece >> LOGB) + 1);
         };
 
         // one block of 8 iterations starting at tp (a multiple of 8); `left` of its columns run (8 but for the batch's last block)
@@ -206,8 +209,8 @@ struct LevBits2 {
             // pieces the first span reads: a string offset x lives in piece x >> 4 (arithmetic shift: offsets before the string are
             // pieces < 0, delivered as zeros)
             int32_t qa = ((int32_t)tb0 - ca_s) >> 4, qb = ((int32_t)tb0 - (int32_t)T0) >> 4;
-            fetch(SA, aptr, alen_u, qa >> 2);
-            fetch(SB, bptr, blen_u, qb >> 2);
+            fetch(SA, aptr, alen_u, qa >> LOGB);
+            fetch(SB, bptr, blen_u, qb >> LOGB);
             for (int32_t x = qa; x < qa + RA - 1; x++) commit_a(x);
             for (int32_t x = qb; x < qb + RB - 1; x++) commit_b(x);
             for (uint32_t tb = tb0; tb < iters; tb += 16u, qa++, qb++) {
