@@ -13,11 +13,11 @@ using namespace ta;
 
 int g_emu_score = -1;   // -1: as the launcher (score form wherever lev_score_form_applies), 0: cost form always
 extern "C" void emu_lev_set_score(int v) { g_emu_score = v; }
-extern "C" int emu_lev_score_applies(uint32_t mc, uint32_t gc, int trans) { return lev_score_form_applies(mc, gc, trans) ? 1 : 0; }
+extern "C" int emu_lev_score_applies(uint32_t mc, uint32_t gc, int trans, uint32_t tc) { return lev_score_form_applies(mc, gc, trans, tc) ? 1 : 0; }
 
 template <int D, bool L1> static void run_dl(const LevParams &P, bool affine, int trans, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
-    const bool score = g_emu_score != 0 && lev_score_form_applies(P.mc, P.gc, trans);
+    const bool score = g_emu_score != 0 && lev_score_form_applies(P.mc, P.gc, trans, P.tc);
     for (uint32_t w = 0; w < waves; w++) {
         if (score) {
             if (affine) {

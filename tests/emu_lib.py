@@ -71,7 +71,7 @@ def lev_band_score_applies(costs, force_trans_select=False):
     """what the launcher decides: the score form of the band kernel for these costs?"""
     mc, gc, sg, tc = costs
     trans = 0 if tc is None else (1 if 2 * mc <= 255 + tc and not force_trans_select else 2)
-    return bool(lib().emu_lev_score_applies(mc, gc, trans))
+    return bool(lib().emu_lev_score_applies(mc, gc, trans, 0 if tc is None else tc))
 
 
 def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False,

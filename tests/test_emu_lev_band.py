@@ -208,8 +208,14 @@ def test_emu_score_form_rule():
     assert not E.lev_band_score_applies((1, 128, 0, None))        # 2 gc > 255
     assert not E.lev_band_score_applies((200, 130, 0, 255))
     assert not E.lev_band_score_applies((2, 2, 1, 3), force_trans_select=True)
+    assert not E.lev_band_score_applies((120, 100, 0, 100))      # the transposition's gain 4 gc - tc = 300 is not a byte
+    assert E.lev_band_score_applies((120, 100, 0, 145))
     assert E.lev_band_score_applies((254, 127, 0, None)) and E.lev_band_score_applies((2, 1, 9, 0 + 1))
     # and the costs the rule excludes still come out right (cost form)
     a, b = make_pairs(5, 90, 60, 5, False)
     for costs in [(3, 1, 0, None), (1, 128, 0, None), (255, 127, 3, None)]:
         assert E.lev_band(a, b, 900, costs)[0] == oracle(a, b, 900, costs)
+    a, b = make_pairs(6, 90, 60, 5, True)
+    for costs in [(120, 100, 0, 100), (120, 100, 0, 145), (120, 100, 7, 199)]:
+        assert O.costs_valid(costs)
+        assert E.lev_band(a, b, 2000, costs)[0] == oracle(a, b, 2000, costs)

@@ -44,7 +44,7 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     if (grid == 0) return hipSuccess;
     // cells as scores gc (i+j) - dp wherever the costs allow it (lev_plan.h): 5 instructions per affine cell instead of 7
     static const bool no_score = env_str("TA_NO_SCORE_FORM") != nullptr;       // tuning switch (TA_TUNING=1): the cost form always
-    if (!no_score && lev_score_form_applies(P.mc, P.gc, trans)) return lev_band_score_launch(P, pl, affine, trans, grid, lds, s);
+    if (!no_score && lev_score_form_applies(P.mc, P.gc, trans, P.tc)) return lev_band_score_launch(P, pl, affine, trans, grid, lds, s);
     set_last_kernel_name("lev_band_kernel<%d, %s, %d, %s>", pl.D, affine ? "true" : "false", trans, P.L == 1 ? "true" : "false");
     switch (pl.D) {
 #define TA_CASE(d) case d: return launch_d<d>(P, affine, trans, grid, lds, s);

@@ -115,8 +115,8 @@ struct LevBand {
                 Z[w] = ((st.AW[w] ^ st.BWp[w]) ^ C12) | ((st.AWp[w] ^ st.BW[w]) ^ C12);
                 if (TRANS == 1 && !SCORE)     // 1 per cell whose transposition test FAILS (non-zero byte; W::ne12: one v_perm_b32 byte test)
                     Z[w] = W::ne12(Z[w] ^ C12) & 0x01010101u;
-                if (TRANS == 1 && SCORE)      // 1 per cell whose test PASSES (one v_bfi_b32 instead of the v_and_b32)
-                    Z[w] = W::sel_bits(W::ne12(Z[w] ^ C12), W::splat(0), W::splat(0x01010101u));
+                if (TRANS == 1 && SCORE)      // the byte 4 gc - tc per cell whose test PASSES, 0 where it fails (one v_bfi_b32 instead of the v_and_b32)
+                    Z[w] = W::sel_bits(W::ne12(Z[w] ^ C12), W::splat(0), W::splat((4u * P.gc - P.tc) * 0x01010101u));
             }
         }
         // Linear gaps (!AFFINE): even-q cells are stored BIASED by +gc (they are only read as a gap source by odd
@@ -208,12 +208,13 @@ struct LevBand {
         for (int c = 0; c < Dh; c++) subv[c] = W::dot4_byte(X[(c + 1) >> 2], (c + 1) & 3, 1u, st.reg[2 * c + PAR]);
         U32 tqv[TRANS == 1 ? Dh : 1];
         if (TRANS == 1) {
-            // PV holds S(i-2,j-2) + 4 gc - tc - 255; a passed test gives the 255 back, a failed one leaves the candidate
-            // below nv (the cost form's argument, :523-525, through the same monotone map)
+            // PV holds S(i-2,j-2) itself; a passed test adds the byte 4 gc - tc (0 <= it: tc/2 < gc; <= 255: lev_score_form_applies),
+            // a failed one nothing -- and S(i-2,j-2) alone never beats nv: scores do not fall along a diagonal (every substitution
+            // byte is >= 0), so nv >= S(i-1,j-1) + .. >= S(i-2,j-2)   (:523-525).  PV is a plain copy of the diagonal's previous
+            // value: in the unrolled loop it is a register NAME, not an instruction.
 #pragma unroll
-            for (int c = 0; c < Dh; c++) tqv[c] = W::dot4_byte(Z[(c + 1) >> 2], (c + 1) & 3, 255u, st.PV[2 * c + PAR]);
+            for (int c = 0; c < Dh; c++) tqv[c] = W::dot4_byte(Z[(c + 1) >> 2], (c + 1) & 3, 1u, st.PV[2 * c + PAR]);
         }
-        const uint32_t t_gain = 4u * P.gc - P.tc - 255u;      // wraps: a signed constant
 #pragma unroll
         for (int c = 0; c < Dh; c++) {
             const int q = 2 * c + PAR;
@@ -222,7 +223,7 @@ struct LevBand {
             U32 rgt = (PAR == 1 && c == Dh - 1) ? xr : (AFFINE ? st.HB[qr] : st.reg[qr]);      // b_gap  :484-491
             U32 nv = W::imax3(subv[c], lft, rgt);                                              // :493-515
             if (TRANS == 1) {
-                st.PV[q] = st.reg[q] + t_gain;
+                st.PV[q] = st.reg[q];
                 nv = W::imax(nv, tqv[c]);
             }
             st.reg[q] = nv;

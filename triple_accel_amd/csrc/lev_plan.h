@@ -157,9 +157,10 @@ static inline LevBits2Plan lev_bits2_make_plan(uint32_t k, uint32_t mc, uint32_t
 }
 
 // ---- score form of the DP band kernel (lev_band_body.h, SCORE): the cells hold gc (i+j) - dp, so the substitution adds the byte
-// 2 gc - mc [a != b]: both bytes must be in 0..255.  trans: 0 none, 1 dot4 penalty, 2 select form (cost form only).
-static inline bool lev_score_form_applies(uint32_t mc, uint32_t gc, int trans) {
-    return trans != 2 && 2u * gc <= 255u && mc <= 2u * gc;
+// 2 gc - mc [a != b]: both bytes must be in 0..255, and so must the transposition's 4 gc - tc (>= 0 always: tc / 2 < gc).
+// trans: 0 none, 1 dot4 penalty, 2 select form (cost form only).
+static inline bool lev_score_form_applies(uint32_t mc, uint32_t gc, int trans, uint32_t tc = 0) {
+    return trans != 2 && 2u * gc <= 255u && mc <= 2u * gc && (trans == 0 || (tc <= 4u * gc && 4u * gc - tc <= 255u));
 }
 
 // ---- small alphabets (lev_bitsq_body.h): fixed-length unit-cost batches whose band (+ the transposition test's two extra rows) fits
