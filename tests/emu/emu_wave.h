@@ -209,6 +209,7 @@ struct EmuWave {
     static void append_u32(uint32_t *list, uint32_t *counter, const U32 &v, const Bool &pred) {
         for (int i = 0; i < 64; i++) if (pred.v[i]) list[(*counter)++] = v.v[i];
     }
+    static U32 bfi_k(uint32_t m, const U32 &a, const U32 &b) { return bfi(m, a, b); }
     static U32 and_or(const U32 &a, uint32_t m, const U32 &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m) | c.v[i]; return r; }
     template <int N>
     static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }

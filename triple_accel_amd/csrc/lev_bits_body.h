@@ -159,9 +159,15 @@ struct LevBits {
     static TA_HD inline __attribute__((always_inline)) void step8(State &st, U32 b_dw, U32 a_raw, U32 a_x, Bool live) {
         if (COLUMN) {
             const U32 Bs = W::template splat_byte_n<(C & 3)>(b_dw);
-            U32 t = W::ne12(st.AW[C] ^ Bs) & 0x01010101u;                    // register C holds bits 0, 8, 16, 24
+            // bit m of every byte from the byte masks of register (C + m) & 7 (register C holds bits 0, 8, 16, 24): a tree of seven
+            // v_bfi -- each takes the bits of its mask from one side and ALL the others from the other side, whose stray bits the
+            // next level drops (a chain of v_and_or needs eight)
+            U32 M[8];
 #pragma unroll
-            for (int m = 1; m < 8; m++) t = W::and_or(W::ne12(st.AW[(C + m) & 7] ^ Bs), 0x01010101u << m, t);
+            for (int m = 0; m < 8; m++) M[m] = W::ne12(st.AW[(C + m) & 7] ^ Bs);
+            const U32 q01 = W::bfi_k(0x01010101u, M[0], M[1]), q23 = W::bfi_k(0x04040404u, M[2], M[3]);
+            const U32 q45 = W::bfi_k(0x10101010u, M[4], M[5]), q67 = W::bfi_k(0x40404040u, M[6], M[7]);
+            const U32 t = W::bfi_k(0x0F0F0F0Fu, W::bfi_k(0x03030303u, q01, q23), W::bfi_k(0x30303030u, q45, q67));
             const Bool m_bot = W::template byte_eq<(C & 3)>(a_raw, b_dw);
             const U32 PM = ~t;
             Bool carry = W::bfalse();

@@ -222,6 +222,12 @@ struct DevWave {
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "v"(c));
         return d;
     }
+    // (a & m) | (b & ~m) with a constant mask -> v_bfi_b32, as written (hipcc would re-associate a tree of these into v_and + v_or3)
+    static __device__ __forceinline__ U32 bfi_k(uint32_t m, U32 a, U32 b) {
+        U32 d;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(m), "v"(a), "v"(b));
+        return d;
+    }
     // byte N of x == byte N of y (hipcc: v_bitop3 (x ^ y) & mask, v_cmp_eq 0)
     template <int N>
     static __device__ __forceinline__ Bool byte_eq(U32 x, U32 y) { return ((x >> (8 * N)) & 0xFFu) == ((y >> (8 * N)) & 0xFFu); }
