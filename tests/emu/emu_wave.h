@@ -211,6 +211,14 @@ struct EmuWave {
     }
     static U32 bfi_k(uint32_t m, const U32 &a, const U32 &b) { return bfi(m, a, b); }
     static U32 and_or(const U32 &a, uint32_t m, const U32 &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & m) | c.v[i]; return r; }
+    using Mask = VB;
+    static Mask add_carry_mask(const U32 &a, const U32 &b, U32 &sum) {
+        VB c;
+        for (int i = 0; i < 64; i++) { const uint64_t t = (uint64_t)a.v[i] + b.v[i]; sum.v[i] = (uint32_t)t; c.v[i] = (t >> 32) != 0; }
+        return c;
+    }
+    template <int N>
+    static U32 byte_eq_or(const U32 &x, const U32 &y, const Mask &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu) || c.v[i]) ? 1u : 0u; return r; }
     template <int N>
     static Bool byte_eq(const U32 &x, const U32 &y) { VB r; for (int i = 0; i < 64; i++) r.v[i] = ((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu); return r; }
     static U32 lds_read32(const uint8_t *lds, const U32 &off) { V32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], lds + off.v[i], 4); return r; }

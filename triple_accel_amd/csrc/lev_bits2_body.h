@@ -9,8 +9,8 @@
 //   * register m (0..7) holds, for BOTH pairs, the bytes of `a` (^ 0x0C) under window bits m and m + 8:
 //         byte 0 = pair A row m, byte 1 = pair A row m + 8, byte 2 = pair B row m, byte 3 = pair B row m + 8;
 //     the column characters are splatted pair-wise, Bs = (bA, bA, bB, bB) -- one v_perm_b32 of the two pairs' `b` dwords --
-//     so v_xor + v_perm (W::ne12) give the four mismatch flags of a register and ONE v_and_or_b32 with 0x01010101 << m drops them
-//     onto their window bits (m, m + 8 | 16 + m, 24 + m): 24 instructions per column for two pairs, no Horner shifts;
+//     so v_xor + v_perm (W::ne12) give the four mismatch flags of a register and a tree of seven v_bfi_b32 over the eight registers
+//     drops them onto their window bits (m, m + 8 | 16 + m, 24 + m): 23 instructions per column for two pairs, no Horner shifts;
 //   * the window moves one row down per column by RENAMING the registers (unrolled 8 columns): the register whose rows were
 //     (0, 8) becomes the one of rows (7, 15) by one v_perm_b32 that drops byte 0 / byte 2 and takes the two pairs' entering bytes
 //     (pre-interleaved, one v_perm_b32 per two columns).  Row 15 (bit 15 / bit 31) is a spare: a byte enters there one column

@@ -36,8 +36,8 @@ namespace ta {
 // kernel holds ONE copy of the column loop (two copies behind a wave-uniform branch cost 60 % more VGPRs and a wavefront per SIMD)
 // S8: the STRIDE-8 form of the 33-diagonal window (NA = 8, bands of up to 33 diagonals: cfg2).  The 32 bytes of `a` under window
 // bits 0..31 sit in 8 registers with register m holding the bytes of bits m, m + 8, m + 16, m + 24.  Then
-//   * the mismatch flags of register m (0x00 / 0xFF per byte, v_xor + v_perm as everywhere) only need masking with
-//     0x01010101 << m and OR-ing together -- one v_and_or_b32 per register -- to land on their window bits: no Horner shifts;
+//   * the mismatch flags of register m (0x00 / 0xFF per byte, v_xor + v_perm as everywhere) only need bit m of every byte taken
+//     from register m's mask -- a tree of seven v_bfi_b32 over the eight masks (step8) -- to land on their window bits: no Horner shifts;
 //   * the window moves one row down per column by RENAMING the registers (m <- m + 1) and pushing the new byte into the one
 //     register that wraps around (one v_perm_b32); the loop is unrolled 8 columns so the names are fixed: no moves at all;
 //   * the 33rd diagonal is the ONEBIT one (below): its byte is the one about to enter, its match a v_cmp on that byte.
@@ -168,24 +168,32 @@ struct LevBits {
             const U32 q01 = W::bfi_k(0x01010101u, M[0], M[1]), q23 = W::bfi_k(0x04040404u, M[2], M[3]);
             const U32 q45 = W::bfi_k(0x10101010u, M[4], M[5]), q67 = W::bfi_k(0x40404040u, M[6], M[7]);
             const U32 t = W::bfi_k(0x0F0F0F0Fu, W::bfi_k(0x03030303u, q01, q23), W::bfi_k(0x30303030u, q45, q67));
-            const Bool m_bot = W::template byte_eq<(C & 3)>(a_raw, b_dw);
             const U32 PM = ~t;
-            Bool carry = W::bfalse();
-            U32 sum;
-            W::addc(PM & st.VP[0], st.VP[0], carry, sum, carry);
-            U32 D0 = ((sum ^ st.VP[0]) | PM) | st.VN[0];
-            if (TRANS) {   // as column(): the bottom diagonal's own match bit of the column before is st.PMp[NW - 1] bit 0
+            U32 sum, D0, d0_bot;
+            if constexpr (TRANS) {
+                const Bool m_bot = W::template byte_eq<(C & 3)>(a_raw, b_dw);
+                Bool carry = W::bfalse();
+                W::addc(PM & st.VP[0], st.VP[0], carry, sum, carry);
+                D0 = ((sum ^ st.VP[0]) | PM) | st.VN[0];
+                // as column(): the bottom diagonal's own match bit of the column before is st.PMp[NW - 1] bit 0
                 const U32 pml = PM << 1, pmr = W::template alignbit<1>(st.PMp[NW - 1], st.PMp[0]);
                 D0 = D0 | (~st.D0p[0] & pml & pmr);
+                d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));          // ONEBIT: match | carry, in bit 0
+                st.PMp[NW - 1] = W::sel(m_bot, W::splat(1), W::splat(0));
+            } else {
+                // the carry stays a wavefront mask (SGPR pair) from the addition to the bottom diagonal's match | carry: the byte
+                // compare is one SDWA v_cmp, two VALU instructions for the 33rd diagonal instead of three
+                const typename W::Mask cm = W::add_carry_mask(PM & st.VP[0], st.VP[0], sum);
+                D0 = ((sum ^ st.VP[0]) | PM) | st.VN[0];
+                d0_bot = W::template byte_eq_or<(C & 3)>(a_raw, b_dw, cm);
             }
-            const U32 d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));          // ONEBIT: match | carry, in bit 0
             st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0, W::splat(0)) : D0, st.acc);
             const U32 HP = st.VN[0] | ~(D0 | st.VP[0]);
             const U32 HN = D0 & st.VP[0];
             const U32 D0s = W::template alignbit<1>(d0_bot, D0);
             st.VP[0] = HN | ~(D0s | HP);
             st.VN[0] = D0s & HP;
-            if (TRANS) { st.PMp[0] = PM; st.D0p[0] = D0; st.PMp[NW - 1] = W::sel(m_bot, W::splat(1), W::splat(0)); }
+            if (TRANS) { st.PMp[0] = PM; st.D0p[0] = D0; }
         }
         st.AW[C] = W::template slide_in_byte<(C & 3)>(a_x, st.AW[C]);
     }

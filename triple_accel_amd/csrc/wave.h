@@ -229,6 +229,27 @@ struct DevWave {
         return d;
     }
     // byte N of x == byte N of y (hipcc: v_bitop3 (x ^ y) & mask, v_cmp_eq 0)
+    // A carry that stays a wavefront mask in an SGPR pair (hipcc turns a `bool` that crosses an asm statement into a VGPR and back):
+    // sum = a + b, returns the carry-out mask -> v_add_co_u32
+    using Mask = uint64_t;
+    static __device__ __forceinline__ Mask add_carry_mask(U32 a, U32 b, U32 &sum) {
+        Mask cm;
+        asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(sum), "=s"(cm) : "v"(a), "v"(b));
+        return cm;
+    }
+    // 1 where byte N of x == byte N of y or the lane's bit of cm is set, else 0 -> v_cmp_eq_u32_sdwa (the byte selects do the
+    // extraction), s_or_b64, v_cndmask_b32: two VALU instructions (hipcc's own sequence for byte_eq() | c is v_bitop3, v_cmp_eq,
+    // s_or, v_cndmask: three)
+    template <int N>
+    static __device__ __forceinline__ U32 byte_eq_or(U32 x, U32 y, Mask cm) {
+        static_assert(N >= 0 && N < 4, "byte index");
+        U32 d;
+        if constexpr (N == 0) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\ts_or_b64 vcc, vcc, %3\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(d) : "v"(x), "v"(y), "s"(cm) : "vcc", "scc");      // (s_or_b64 sets SCC)
+        if constexpr (N == 1) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:BYTE_1\n\ts_or_b64 vcc, vcc, %3\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(d) : "v"(x), "v"(y), "s"(cm) : "vcc", "scc");      // (s_or_b64 sets SCC)
+        if constexpr (N == 2) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\ts_or_b64 vcc, vcc, %3\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(d) : "v"(x), "v"(y), "s"(cm) : "vcc", "scc");      // (s_or_b64 sets SCC)
+        if constexpr (N == 3) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\ts_or_b64 vcc, vcc, %3\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(d) : "v"(x), "v"(y), "s"(cm) : "vcc", "scc");      // (s_or_b64 sets SCC)
+        return d;
+    }
     template <int N>
     static __device__ __forceinline__ Bool byte_eq(U32 x, U32 y) { return ((x >> (8 * N)) & 0xFFu) == ((y >> (8 * N)) & 0xFFu); }
     static __device__ __forceinline__ void lds_write32(uint8_t *lds, U32 off, U32 v) { *(uint32_t *)(lds + off) = v; }
