@@ -217,6 +217,7 @@ struct EmuWave {
         for (int i = 0; i < 64; i++) { const uint64_t t = (uint64_t)a.v[i] + b.v[i]; sum.v[i] = (uint32_t)t; c.v[i] = (t >> 32) != 0; }
         return c;
     }
+    static U32 sel_mask(const Mask &m, const U32 &a, const U32 &b) { return sel(m, a, b); }
     template <int N>
     static U32 byte_eq_or(const U32 &x, const U32 &y, const Mask &c) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (((x.v[i] >> (8 * N)) & 0xffu) == ((y.v[i] >> (8 * N)) & 0xffu) || c.v[i]) ? 1u : 0u; return r; }
     template <int N>

@@ -46,24 +46,31 @@ struct LevBitsQ {
         U32 acc;                 // D0 of the window's top diagonal, the last columns' bits from bit 31 down
     };
 
-    // one column: PM = match bits of window bits 0..31, m_bot = the bottom diagonal's characters match
-    static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 PM, Bool m_bot) {
-        Bool carry = W::bfalse();
-        U32 sum;
-        W::addc(PM & st.VP, st.VP, carry, sum, carry);
-        U32 D0 = ((sum ^ st.VP) | PM) | st.VN;                 // Hyyro 2003 (lev_bits_body.h)
-        if (TRANS) {
+    // one column: PM = match bits of window bits 0..31, mb bit 0 = the bottom diagonal's characters match (the other bits: anything)
+    static TA_HD inline __attribute__((always_inline)) void column(State &st, U32 PM, U32 mb) {
+        U32 sum, D0, d0_bot;
+        if constexpr (TRANS) {
+            const Bool m_bot = (mb & 1u) != 0u;
+            Bool carry = W::bfalse();
+            W::addc(PM & st.VP, st.VP, carry, sum, carry);
+            D0 = ((sum ^ st.VP) | PM) | st.VN;                     // Hyyro 2003 (lev_bits_body.h)
             const U32 pml = PM << 1, pmr = W::template alignbit<1>(st.PMb, st.PMp);
             D0 = D0 | (~st.D0p & pml & pmr);
+            d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));      // the bottom diagonal: match | carry
+            st.PMb = W::sel(m_bot, W::splat(1), W::splat(0));
+        } else {
+            // the carry stays a wavefront mask: bit 0 of d0_bot (all the shift below takes) is one v_cndmask away
+            const typename W::Mask cm = W::add_carry_mask(PM & st.VP, st.VP, sum);
+            D0 = ((sum ^ st.VP) | PM) | st.VN;
+            d0_bot = W::sel_mask(cm, W::splat(1), mb);
         }
-        const U32 d0_bot = W::sel(carry | m_bot, W::splat(1), W::splat(0));      // the bottom diagonal: match | carry
         st.acc = W::template alignbit<1>(D0, st.acc);
         const U32 HP = st.VN | ~(D0 | st.VP);
         const U32 HN = D0 & st.VP;
         const U32 D0s = W::template alignbit<1>(d0_bot, D0);
         st.VP = HN | ~(D0s | HP);
         st.VN = D0s & HP;
-        if (TRANS) { st.PMp = PM; st.D0p = D0; st.PMb = W::sel(m_bot, W::splat(1), W::splat(0)); }
+        if (TRANS) { st.PMp = PM; st.D0p = D0; }
     }
 
     // (the launcher guarantees: fixed-length batch, unit costs, band + transposition rows <= 33, P.q_table / P.q_shift from
@@ -166,7 +173,7 @@ struct LevBitsQ {
             const uint32_t g = (t - dhi) & 127u, w4 = (g >> 5) << 2, s = g & 31u;
             U32 lo, hi;
             W::lds_read64(lds, ring + W::byte_of(bo_d, byte) + w4, lo, hi);
-            column(st, W::alignbit_rt(hi, lo, s), (W::shr_u(hi, s) & 1u) != 0u);
+            column(st, W::alignbit_rt(hi, lo, s), W::shr_u(hi, s));
         };
 
         fetch(SA, aptr, alen_u, 0);

@@ -237,6 +237,13 @@ struct DevWave {
         asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(sum), "=s"(cm) : "v"(a), "v"(b));
         return cm;
     }
+    // a where the lane's bit of m is set, else b.  The mask goes through VCC by an s_mov: a VALU instruction that reads an SGPR pair a VALU
+    // instruction wrote needs wait states the compiler cannot count across asm statements; SALU reads and writes are interlocked.
+    static __device__ __forceinline__ U32 sel_mask(Mask m, U32 a, U32 b) {
+        U32 d;
+        asm("s_mov_b64 vcc, %3\n\tv_cndmask_b32_e32 %0, %2, %1, vcc" : "=v"(d) : "v"(a), "v"(b), "s"(m) : "vcc");
+        return d;
+    }
     // 1 where byte N of x == byte N of y or the lane's bit of cm is set, else 0 -> v_cmp_eq_u32_sdwa (the byte selects do the
     // extraction), s_or_b64, v_cndmask_b32: two VALU instructions (hipcc's own sequence for byte_eq() | c is v_bitop3, v_cmp_eq,
     // s_or, v_cndmask: three)
