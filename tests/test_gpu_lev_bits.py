@@ -42,6 +42,23 @@ def test_bits_every_window_width(monkeypatch):
 
 
 @pytest.mark.parametrize("costs", [LEV, RDAM])
+def test_bits_stride8_every_tail_length(costs):
+    """Fixed-length batches whose length leaves 0..7 columns for the last block of eight (the partly run block is its own code path:
+    round 3's SDWA compare of the 33rd diagonal clobbered the scalar condition code there until its asm statement said so)."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    trans = costs[3] is not None
+    ec = T.EditCosts(*costs)
+    for L in range(296, 304):
+        fa, fb = Dg.pairs_mutated_fixed(0x60 + L, 2500, L, 30, trans)
+        for k in (32 - (2 if trans else 0), 27):
+            got = B.levenshtein_k_batch(B.Strings.from_fixed(fa), B.Strings.from_fixed(fb), k, ec).cpu().numpy().view(np.uint32)
+            assert kernel_id() == 3 and T.last_launch_info()["diags_per_lane"] == 33
+            want = O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), k, costs)
+            assert np.array_equal(got, want), (L, k, costs, np.flatnonzero(got != want)[:10])
+
+
+@pytest.mark.parametrize("costs", [LEV, RDAM])
 def test_bits_stride8_window_form(monkeypatch, costs):
     """The stride-8 form (bands of 25..33 diagonals by the planner's choice, narrower ones when forced) on ragged CSR batches -- the
     chunk form of the fetch, pairs ending inside a block of 8 columns while others run on -- and on fixed-length batches of 300-byte
