@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse_args():
@@ -42,9 +42,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "hsearch"],
                     help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
-                         "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel")
+                         "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel; hsearch = hamming_search of a --needle-len byte needle "
+                         "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
+    ap.add_argument("--needle-len", type=int, default=32, help="hsearch: needle bytes (8 / 32: shift-add scan; > 32: SWAR kernel)")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
     ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna"],
                     help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair; "
@@ -52,6 +54,10 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue the K timed passes one by one; default: captured once into ONE hipGraph (where the pass is a pure kernel "
+                         "launch: the fixed-length pair batches) and replayed inside the barrier-to-barrier region -- the same K passes, "
+                         "without K trips through Python / ctypes / the runtime's launch path while the clock runs")
     ap.add_argument("--early-out", action="store_true",
                     help="ta_set_option(TA_OPT_EARLY_OUT): wavefronts stop once none of their pairs can end at or below k -- same answers, "
                          "data-dependent work; NOT the headline (the reference evaluates its whole band): the line says so in config.early_out")
@@ -128,7 +134,10 @@ def main():
     local = local % ndev
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # a ONE-rank run under a launcher with TA_BENCH_BACKEND set also joins a process group: every collective of the multi-rank path
+    # (barrier, all_reduce, the sharded search's all-gathers) then executes on RCCL / gloo with world size 1
+    dist_on = world > 1 or ("WORLD_SIZE" in os.environ and "TA_BENCH_BACKEND" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         import datetime
         try:
@@ -152,13 +161,16 @@ def main():
 
     # ------------------------------------------------------------------ workload set-up
     # make(seed, lo, hi) -> (run, units, parity, extra): one rank's share of a batch
-    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w"):
+    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s"):
         n_cfg, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
                               "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM),
-                              "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3))}[wl]
+                              "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3)),
+                              # cfg2's geometry under weighted LINEAR-gap costs: (2, 3, 0) -- the DP band kernel, no affine term -- and
+                              # (2, 2, 0) = unit costs times two, which ride the bit-parallel kernel with k / 2
+                              "cfg2l": (1_000_000, 256, 32, (2, 3, 0, None)), "cfg2s": (1_000_000, 256, 32, (2, 2, 0, None))}[wl]
         n_cfg = args.pairs or n_cfg
         ragged = args.dist == "ragged"
-        assert not ragged or wl in ("cfg2", "cfg4", "cfg2w", "cfg4w"), "--dist ragged is a k-bounded batch distribution"
+        assert not ragged or wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s"), "--dist ragged is a k-bounded batch distribution"
         bytes_unit = 2 * L + 4
         if wl == "cfg1":
             cells_unit = L
@@ -171,14 +183,16 @@ def main():
             desc = {"cfg2": "levenshtein_simd_k k=32, 1M random 256B pairs, u8 cells",
                     "cfg4": "levenshtein_simd_k_with_opts RDAMERAU_COSTS k=8, 1M 128B pairs (transposition path)",
                     "cfg2w": "levenshtein_simd_k_with_opts EditCosts(2,3,1,None) k=32, 1M 256B pairs (general costs: DP band-wavefront kernel)",
-                    "cfg4w": "levenshtein_simd_k_with_opts EditCosts(2,2,1,Some(3)) k=8, 1M 128B pairs (general costs + transposition)"}[wl]
+                    "cfg4w": "levenshtein_simd_k_with_opts EditCosts(2,2,1,Some(3)) k=8, 1M 128B pairs (general costs + transposition)",
+                    "cfg2l": "levenshtein_simd_k_with_opts EditCosts(2,3,0,None) k=32, 1M 256B pairs (weighted linear gaps: DP band-wavefront kernel)",
+                    "cfg2s": "levenshtein_simd_k_with_opts EditCosts(2,2,0,None) k=32, 1M 256B pairs (unit costs x 2: bit-parallel kernel with k / 2)"}[wl]
             unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select); the kernel computes on 1-bit cells in u32 lanes
             # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
             #  -- about half of the credited reference band; reported beside the credited figure
             uk = min(max(min(k, L * max(costs[0], costs[1])) - costs[2], 0) // costs[1], 2 * L)
             evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
 
-        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14}[wl]
+        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14, "cfg2l": 22, "cfg2s": 32}[wl]
 
         def gen(seed, n):
             """-> ((blob_a, off_a), (blob_b, off_b)) as numpy CSR; fixed-length distributions also carry their (n, L) arrays"""
@@ -283,6 +297,55 @@ def main():
                     ts.append((time.perf_counter() - t1) * 1e3)
                 return float(np.median(ts[1:]))
             return run, n, parity, {"csr": csr, "oracle": oracle, "cells_total": cells_total, "bytes_total": bytes_total, "end_to_end": end_to_end}
+    elif wl == "hsearch":
+        # hamming_search over a haystack shard resident in HBM: every offset's mismatch count against the needle, reported when <= k.
+        # Algorithmic bytes: the haystack once (+ the few hit records); cells: needle_len byte comparisons per offset.
+        mib = args.pairs or 1024
+        nlen = args.needle_len
+        needle = Dg.random_bytes(Dg.rng(0x7A06), nlen).tobytes()
+        needle = bytes(c or 1 for c in needle)                      # (no NUL bytes: the reference panics on them)
+        k = max(1, nlen // 4)
+        cells_unit, bytes_unit = nlen, 1
+        desc = "hamming_search %dB needle over a %d MiB random haystack shard per GPU, k=%d" % (nlen, mib, k)
+        unit_name, dtype = "haystack bytes", "u8 counters (byte compares)"
+
+        def make(share_of_common_batch):
+            size = mib << 20
+            g = Dg.rng(0x7A06 + 1000 * rank)
+            hay_np = Dg.random_bytes(g, size)
+            hay_np[hay_np == 0] = 1
+            nd = np.frombuffer(needle, dtype=np.uint8)
+            for pos in range(1 << 16, hay_np.size - 2 * nlen, 1 << 20):     # ~1 planted copy per MiB with k/2 substitutions
+                hay_np[pos:pos + nlen] = nd
+                for q in g.integers(0, nlen, size=max(1, k // 2)):
+                    hay_np[pos + int(q)] = 7
+            hay = B.haystack_tensor(hay_np)
+            holder = {}
+
+            def run():
+                holder["hits"] = B.hamming_search_dev(needle, hay, k)
+
+            def parity():
+                run(); torch.cuda.synchronize()
+                ns = min(hay_np.size, 2 << 20)
+                want = O.hamming_search_naive_with_opts(needle, hay_np[:ns].tobytes(), k, O.ALL)
+                got = [tuple(int(v) for v in r) for r in holder["hits"] if r[1] <= ns]
+                assert got == [tuple(w) for w in want] and len(want) > 0, "parity gate failed: HIP hamming_search != oracle"
+                return ns
+
+            def end_to_end(reps=3):
+                pin = torch.from_numpy(hay_np).pin_memory()
+                ts = []
+                for _ in range(reps + 1):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    hay[0][: pin.numel()].copy_(pin, non_blocking=True)
+                    run()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                return float(np.median(ts[1:]))
+            return run, hay_np.size, parity, {"hay_np": hay_np, "cells_total": cells_unit * hay_np.size, "bytes_total": bytes_unit * hay_np.size,
+                                              "end_to_end": end_to_end}
     else:   # cfg5: levenshtein_search, 32 B needle over a 1 GiB random shard per GPU
         mib = args.pairs or 1024
         needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()     # same needle on every rank
@@ -303,7 +366,7 @@ def main():
                 hay_np[pos:pos + mm.size] = mm
             hay = B.haystack_tensor(hay_np)                         # resident in HBM from here on
             holder = {}
-            if world == 1:
+            if not dist_on:
                 def run():
                     hits = B.levenshtein_search_best_dev(needle, hay, k, costs)        # kernels + on-device selection of the best-k hits
                     holder["best"] = TD.fold_best(hits, k, True)                       # the sequential Best pass (host)
@@ -319,8 +382,10 @@ def main():
                 got = [tuple(int(v) for v in r) for r in allhits if r[1] <= ns]
                 assert got == [w for w in want if w[1] > 0], "parity gate failed: HIP search != oracle"
                 if world == 1:
-                    assert holder["best"] == TD.fold_best(allhits, k, True), "parity gate failed: on-device Best selection != fold over all hits"
-                else:          # every rank must hold the same answer (the sharded search itself is compared with the monolithic
+                    want_best = TD.fold_best(allhits, k, True)
+                    got_best = [tuple(int(v) for v in m) for m in holder["best"]] if dist_on else holder["best"]
+                    assert got_best == want_best, "parity gate failed: Best matches != fold over all hits"
+                if dist_on:          # every rank must hold the same answer (the sharded search itself is compared with the monolithic
                     # oracle across shard cuts in tests/test_gpu_dist.py and tests/test_dist_cpu.py)
                     mine = torch.tensor([hash(tuple(tuple(int(v) for v in m) for m in holder["best"])) & 0x7FFFFFFF], dtype=torch.int64)
                     mine = mine.cuda() if backend == "nccl" else mine
@@ -345,7 +410,7 @@ def main():
 
     # ------------------------------------------------------------------ timing helpers
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         # wait for the device by polling an event (no sleep / wake-up of the host thread inside the timed region: a 20-step region
         # is 8 ms long), then the synchronize the protocol asks for -- which has nothing left to wait for
@@ -358,6 +423,25 @@ def main():
     def timed_region(run, steps, warmup):
         """clock ramp (untimed, --prewarm-ms), W untimed warm-ups, then EXACTLY `steps` passes between barrier + synchronize;
         max over ranks.  -> (wall seconds, mean device ms per pass from HIP events on the launch stream, ramp passes run)"""
+        # The K timed passes as ONE hipGraph launch where a pass is nothing but kernel launches on the current stream (no scratch, no
+        # host round trip): captured FIRST (the capture leaves the device idle for milliseconds: the clock ramp and the warm-ups come after
+        # it), replayed inside the timed region.  Anything else -- or a failed capture -- enqueues the K passes one by one.
+        graph = None
+        if graphable and not args.no_graph:
+            try:
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(steps):
+                        run()
+                torch.cuda.synchronize()
+                graph.replay()                                # (once untimed: the first replay uploads the graph)
+                torch.cuda.synchronize()
+            except Exception as e:
+                print("bench.py: hipGraph capture failed (%s: %s): K separate launches" % (type(e).__name__, e), file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
         n_ramp = 0
         if args.prewarm_ms > 0:
             # the number of ramp passes is agreed between the ranks (a pass may hold collectives): one timed pass, the maximum over ranks
@@ -366,7 +450,7 @@ def main():
             run()
             torch.cuda.synchronize()
             n_ramp = int(min(4000, max(1, args.prewarm_ms / 1e3 / max(time.perf_counter() - t1, 1e-6))))
-            if world > 1:
+            if dist_on:
                 tn = torch.tensor([n_ramp], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
                 dist.all_reduce(tn, op=dist.ReduceOp.MAX)
                 n_ramp = int(tn.item())
@@ -376,17 +460,23 @@ def main():
             torch.cuda.synchronize()
         for _ in range(warmup):
             run()
+        launch_mode["mode"] = "one hipGraph of %d passes" % steps if graph is not None else "%d separate launches" % steps
         barrier()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        # two events around the region, on the stream the kernels are launched on (an event after every pass puts a barrier packet
+        # between consecutive kernels: 0.6 - 8.7 us of idle device per pass, depending on the box)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev[0].record()
-        for i in range(steps):
-            run()
-            ev[i + 1].record()                                # same stream as the kernel launches
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(steps):
+                run()
+        ev1.record()
         barrier()
         elapsed = time.perf_counter() - t0
-        dev_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]))
-        if world > 1:
+        dev_ms = ev0.elapsed_time(ev1) / steps
+        if dist_on:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -394,13 +484,17 @@ def main():
 
     def totals(*vals):
         """sums over the ranks"""
-        if world == 1:
+        if not dist_on:
             return [int(v) for v in vals]
         tt = torch.tensor([int(v) for v in vals], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt)
         return [int(v) for v in tt.tolist()]
 
     # ------------------------------------------------------------------ parity gate, warm-up, timed region
+    # a pass that is a pure kernel launch on the current stream can be captured into a hipGraph: the fixed-length pair batches
+    graphable = (not dist_on and wl in ("cfg1", "cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s") and args.dist in ("random", "mutated")
+                 and not args.early_out)
+    launch_mode = {}
     run, units, parity, extra = make(strong and world > 1)
     parity_n = parity()
     info = T.last_launch_info()
@@ -423,7 +517,7 @@ def main():
                           "units_total": tot_s, "units_this_rank": units_s, "device_ms_per_pass": dev_s_ms}
         extra = {"bytes_total": extra_bytes}
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -441,7 +535,7 @@ def main():
     traffic = None
     traffic_source = None
     valu_issue = None
-    tag = wl + ("" if args.dist in ("random", "mutated") else "_" + args.dist)       # the profile files of this workload / distribution
+    tag = wl + ("" if args.dist in ("random", "mutated") else "_" + args.dist) + ("%d" % args.needle_len if wl == "hsearch" else "")       # the profile files of this workload / distribution
     pmc = load_json(PROFILE_ROUND, "bench_%s_pmc.json" % tag)
     # a committed counter pass is only spliced into the line when it was recorded for the kernel this run launched
     # (T.last_kernel_name(): the dominant kernel of the pass, as rocprofv3 prints it) -- never for another build's kernel
@@ -492,7 +586,16 @@ def main():
                 dt = time.perf_counter() - t
                 if dt >= min_s or reps >= max_reps:
                     return dt / reps, reps
-        if wl == "cfg5":
+        if wl == "hsearch":
+            hay_np = extra["hay_np"]
+            cpu_sample = min(64 << 20, hay_np.size)
+            t1 = time.perf_counter()
+            O.hamming_search_naive_with_opts(needle, hay_np[:cpu_sample].tobytes(), k, O.ALL)
+            dt = time.perf_counter() - t1
+            cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+                   "sample": "first %d MiB of the shard, single thread, oracle/ta_oracle.c (restated scalar hamming_search_naive), %.1f s"
+                             % (cpu_sample >> 20, dt), "host": facts}
+        elif wl == "cfg5":
             hay_np = extra["hay_np"]
             cpu_sample = min(8 << 20, hay_np.size)
             t1 = time.perf_counter()
@@ -501,7 +604,7 @@ def main():
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread (the scalar search is one serial scan), oracle/ta_oracle.c "
                              "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt), "host": facts}
-        elif wl in ("cfg2", "cfg4", "cfg2w", "cfg4w"):
+        elif wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s"):
             # Inputs staged once (CSR blobs), outside the timed loops.  Three restatements: the hand-written AVX2 one with
             # saturating u8 cells (oracle/ta_oracle_avx2.c: 64 / 32 u8 lanes per anti-diagonal for cfg2 / cfg4 -- the reference's
             # own Avx2x32x8 / Avx1x32x8 classes), the compiler-vectorised u16 anti-diagonal one (ta_oracle_simd.c) and the scalar
@@ -578,9 +681,9 @@ def main():
         "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "units_total": all_units,
                    "unit": unit_name, "credited_cells_per_unit": all_cells / max(all_units, 1), "evaluated_band_cells_per_unit": evaluated_unit,
                    "parallelism": "independent units sharded x%d (%s), %s" % (
-                       world, args.scaling, "no collective" if wl != "cfg5" or world == 1 else
+                       world, args.scaling, "no collective" if wl != "cfg5" or not dist_on else
                        "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
-                   "backend": backend if world > 1 else None,
+                   "backend": backend if dist_on else None,
                    "early_out": bool(args.early_out)},
         "value_evaluated_cells": evaluated_value,
         "end_to_end_ms": e2e_ms,          # host buffers in, answers out (pinned H2D + pass + D2H); never the headline
@@ -592,10 +695,11 @@ def main():
                      "valu_issue": valu_issue,
                      "note": "integer VALU-issue-bound path (DESIGN.md section 5); the HBM fraction is reported because north_star asks for it"},
         "cpu_baseline": cpu,
+        "timed_region": launch_mode.get("mode"),
         "kernel": info, "parity_checked_units": parity_n,
     }
     print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,8 @@ using namespace ta;
 extern int g_emu_force_ch;
 static int g_emu_bits_fixed_chunk = 0;      // 1: fixed-length batches take the chunk form (as the launcher does up to one line per string)
 extern "C" void emu_bits_set_fixed_chunk(int on) { g_emu_bits_fixed_chunk = on; }
+static int g_emu_bits_vline = 0;            // 1: the VLINE form of the fetch (what the launcher gives CSR batches), whatever the batch's form
+extern "C" void emu_bits_set_vline(int on) { g_emu_bits_vline = on; }
 static uint32_t g_emu_bits_tune = 0;        // LevParams::tune bits (2: early out)
 extern "C" void emu_bits_set_tune(uint32_t bits) { g_emu_bits_tune = bits; }
 
@@ -20,9 +22,11 @@ extern "C" void emu_bits_set_tune(uint32_t bits) { g_emu_bits_tune = bits; }
 #include "lev_bits_body.h"
 
 template <int NA> static void run_bits(const LevParams &P, bool trans, bool stat, bool line, uint32_t waves) {
-    uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
+    uint8_t *lds = (uint8_t *)malloc(P.lds_per_wave + 64);
     for (uint32_t w = 0; w < waves; w++) {
-#define GO(T, S) do { if (line) LevBits<EmuWave, NA, T, S, true>::run(P, w, lds); else LevBits<EmuWave, NA, T, S, false>::run(P, w, lds); } while (0)
+        memset(lds, g_emu_bits_vline ? 0xA5 : 0, P.lds_per_wave + 64);
+#define GO(T, S) do { if (g_emu_bits_vline) LevBits<EmuWave, NA, T, S, false, false, false, true>::run(P, w, lds); \
+                      else if (line) LevBits<EmuWave, NA, T, S, true>::run(P, w, lds); else LevBits<EmuWave, NA, T, S, false>::run(P, w, lds); } while (0)
         if constexpr (NA >= 8) {
             if (stat) { if (trans) GO(true, true); else GO(false, true); continue; }
         }
@@ -57,15 +61,27 @@ extern "C" int emu_lev_bits_any(const uint8_t *a_blob, const uint64_t *a_off, ui
     P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
     P.u = pl.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
+    if (g_emu_bits_vline && P.lds_per_wave < LEV_BITS_VLINE_LDS) P.lds_per_wave = LEV_BITS_VLINE_LDS;
     P.tune = g_emu_bits_tune;
     if (plan_out) { plan_out[0] = pl.NA; plan_out[1] = pl.u; plan_out[2] = pl.Tw; plan_out[3] = pl.s8 ? 3 : pl.stat; }
     const uint32_t waves = (n + 63) / 64;
+    struct RangeGuard { ~RangeGuard() { EmuWave::clear_ranges(); } } range_guard;     // (the other drivers read unchecked)
+    EmuWave::clear_ranges();                               // VLINE reads whole lines: bytes outside the blobs (+ 16 of slack) read as 0xA5
+    if (g_emu_bits_vline && !subset) {                      // (checked reads only where whole lines are read; n = the batch then)
+        EmuWave::add_range(a_blob, (a_off ? a_off[n] : (uint64_t)n * a_len) + 16);
+        EmuWave::add_range(b_blob, (b_off ? b_off[n] : (uint64_t)n * b_len) + 16);
+    }
     // fixed-length batches take the line form here whatever their length (the launcher keeps the chunk form up to one line per
     // string -- a speed choice; the emulation covers the line form on short strings too)
     if (pl.s8) {
         uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
         const bool line = !a_off && !b_off && !g_emu_bits_fixed_chunk;
         for (uint32_t w = 0; w < waves; w++) {
+            if (g_emu_bits_vline) {
+                memset(lds, 0xA5, P.lds_per_wave + 64);
+                if (has_t) LevBits<EmuWave, 8, true, false, false, true, false, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, false, true, false, true>::run(P, w, lds);
+                continue;
+            }
             if (line && (P.tune & 2u)) {           // as the launcher: the early-out instantiation under the option
                 if (has_t) LevBits<EmuWave, 8, true, false, true, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, false, false, true, true, true>::run(P, w, lds);
             } else if (has_t) { if (line) LevBits<EmuWave, 8, true, false, true, true>::run(P, w, lds); else LevBits<EmuWave, 8, true, false, false, true>::run(P, w, lds); }

@@ -117,6 +117,7 @@ struct EmuWave {
     static U32 shfl(const U32 &x, const U32 &src) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[src.v[i] & 63]; return r; }
     static Ptr shfl_ptr(const Ptr &p, const U32 &src) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[src.v[i] & 63]; return r; }
     static bool any(const Bool &c) { for (int i = 0; i < 64; i++) if (c.v[i]) return true; return false; }
+    static uint32_t first_u32(const U32 &x, const Bool &c) { for (int i = 0; i < 64; i++) if (c.v[i]) return x.v[i]; return 0; }
     static uint32_t wave_max(const U32 &x) { uint32_t m = 0; for (int i = 0; i < 64; i++) if (x.v[i] > m) m = x.v[i]; return m; }
 
     static void load_str(const StrView &s, const U32 &idx, const Bool &valid, Ptr &p, U32 &len) {
@@ -151,11 +152,44 @@ struct EmuWave {
         Q128V q;
         for (int i = 0; i < 64; i++) {
             q.v[i] = Q128{0, 0, 0, 0};
-            if (pred.v[i]) memcpy(&q.v[i], p.v[i], 16);
+            if (pred.v[i]) {
+                if (n_ranges()) { uint8_t tmp[16]; for (int b = 0; b < 16; b++) tmp[b] = safe_byte(p.v[i] + b); memcpy(&q.v[i], tmp, 16); }
+                else memcpy(&q.v[i], p.v[i], 16);
+            }
         }
         return q;
     }
     static Q128V gload16_nt(const Ptr &p, const Bool &pred) { return gload16(p, pred); }
+    // ---- VLINE fetch form: whole 128-byte lines are read, also the bytes of a line that lie outside the string (on the device: the
+    // same line, mapped memory).  The drivers register the blobs; a byte outside every registered range reads as 0xA5.
+    struct Range { const uint8_t *lo, *hi; };
+    static Range *ranges() { static Range r[8]; return r; }
+    static int &n_ranges() { static int n = 0; return n; }
+    static void clear_ranges() { n_ranges() = 0; }
+    static void add_range(const uint8_t *lo, uint64_t bytes) { if (n_ranges() < 8) ranges()[n_ranges()++] = Range{lo, lo + bytes}; }
+    static uint8_t safe_byte(const uint8_t *p) {
+        if (n_ranges() == 0) return *p;                    // nothing registered: unchecked
+        for (int i = 0; i < n_ranges(); i++) if (p >= ranges()[i].lo && p < ranges()[i].hi) return *p;
+        return 0xA5;
+    }
+    static U32 ptr_lo32(const Ptr &p) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(uintptr_t)p.v[i]; return r; }
+    static Ptr ptr_sub(const Ptr &p, const U32 &off) { VP r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] - off.v[i]; return r; }
+    static Ptr ptr_piece(const Ptr &p) { VP r; for (int i = 0; i < 64; i++) r.v[i] = (const uint8_t *)((uintptr_t)p.v[i] & ~(uintptr_t)15); return r; }
+    static Ptr ptr_line(const Ptr &p) { VP r; for (int i = 0; i < 64; i++) r.v[i] = (const uint8_t *)((uintptr_t)p.v[i] & ~(uintptr_t)127); return r; }
+    static void wait_vm0() {}
+    template <int N> static void case_tag() {}
+    static Q128V qzero() { Q128V q; for (int i = 0; i < 64; i++) q.v[i] = Q128{0, 0, 0, 0}; return q; }
+    static void gload_line_keep(Q128V (&S)[8], const Ptr &line, const Bool &pred, uint32_t KAPPA) {
+        for (int i = 0; i < 64; i++) {
+            if (!pred.v[i]) continue;
+            for (int j = 0; j < 8; j++) {
+                uint8_t tmp[16];
+                const uint8_t *src = line.v[i] + 16 * ((j + KAPPA) & 7);
+                for (int b = 0; b < 16; b++) tmp[b] = safe_byte(src + b);
+                memcpy(&S[j].v[i], tmp, 16);
+            }
+        }
+    }
     static U32 qword(const Q128V &q, int i) {
         V32 r;
         for (int l = 0; l < 64; l++) r.v[l] = i == 0 ? q.v[l].x : i == 1 ? q.v[l].y : i == 2 ? q.v[l].z : q.v[l].w;

@@ -120,6 +120,12 @@ def bits_fixed_chunk(on):
     lib().emu_bits_set_fixed_chunk(1 if on else 0)
 
 
+def bits_vline(on):
+    """The VLINE form of the fetch (whole 128-byte lines per lane, per-lane geometry and alignment: what the launcher gives CSR batches)
+    for every following lev_bits / lev_bits_fixed call; LDS starts out as 0xA5 garbage, bytes outside the blobs read as 0xA5."""
+    lib().emu_bits_set_vline(1 if on else 0)
+
+
 def lev_bits_fixed(a2d, b2d, k, trans=False, force_NA=0, static=0, subset=None):
     """The same body on a fixed-length (strided) batch -- (n, La) and (n, Lb) uint8 arrays -- which takes the COALESCED fetch
     form; subset: optional pair indices (results land at out[pair], other entries stay 0xDEADBEEF -> 'untouched')."""

@@ -285,6 +285,48 @@ def test_ragged_100k_length_ordered(costs, k, monkeypatch):
     assert np.array_equal(gpu_k(a, b, k, costs), want)
 
 
+@pytest.mark.parametrize("costs", [(2, 2, 0, None), (3, 3, 0, 3), (7, 7, 0, None), (2, 2, 0, 2)])
+def test_unit_costs_times_g_ride_the_bit_parallel_kernels(costs):
+    """EditCosts(g, g, 0, None | Some(g)): every alignment costs g times its unit cost, so the pass runs the unit-cost kernels with k / g
+    and multiplies the answers (lev_plan.h: lev_unit_scale) -- same Option as the oracle for every k, multiples of g or not; batches,
+    fixed-length batches, single calls and levenshtein_exp."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = costs[0]
+    a, b = ragged_pairs(31 + g, 6000, 120, 9, costs[3] is not None)
+    for k in (0, 1, g - 1, g, g + 1, 3 * g + 1, 10 * g, 40 * g + g // 2, 0xFFFFFFFF):
+        got, want = gpu_k(a, b, k, costs), oracle_k(a, b, k, costs)
+        assert np.array_equal(got, want), (k, costs, np.flatnonzero(got != want)[:10])
+        assert T.last_launch_info()["kernel"] in (3, 4), T.last_launch_info()      # bit-parallel kernels, not the DP band kernel
+    am, bm = Dg.pairs_mutated_fixed(0x7A90 + g, 20_000, 128, 12, swaps=costs[3] is not None)
+    out = B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), 13 * g, costs).cpu().numpy().view(np.uint32)
+    assert np.array_equal(out, O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 13 * g, costs))
+    gg = Dg.rng(g)
+    for _ in range(30):
+        x = Dg.rand_str(gg, int(gg.integers(0, 300)))
+        y = Dg.mutate(gg, x, 7)
+        for k in (g, 5 * g + 1, 1000):
+            assert T.levenshtein_simd_k_with_opts(x, y, k, False, T.EditCosts(*costs))[0] == O.levenshtein_simd_k_with_opts(x, y, k, False, costs)[0]
+        assert T.levenshtein_exp_with_opts(x, y, False, T.EditCosts(*costs))[0] == O.levenshtein_exp_with_opts(x, y, False, costs)[0]
+    outx = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), costs).cpu().numpy().view(np.uint32)
+    assert np.array_equal(outx, O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), costs))
+
+
+@pytest.mark.parametrize("costs,k", [((1, 1, 0, None), 32), ((1, 1, 0, 1), 30), ((1, 1, 0, None), 27)])
+def test_ragged_vline_fetch_form(costs, k, monkeypatch):
+    """The VLINE form of the bit-parallel band kernel's fetch (TA_BITS_VLINE=1: whole 128-byte lines per lane, per-lane geometry and
+    alignment, one column count per pass over pairs ordered by b's exact length; lev_bits_body.h) on a ragged CSR batch -- pairs
+    outside the band, near pairs, every alignment -- against the oracle, and the launcher really took it."""
+    import triple_accel_amd as T
+    monkeypatch.setenv("TA_BITS_VLINE", "1")
+    a, b = _ragged_csr(0x7A70 + k, 60_000, 1, 300, 40, kmut=20)
+    want = oracle_k(a, b, k, costs)
+    got = gpu_k(a, b, k, costs)
+    assert "s8v" in T.last_kernel_name(), T.last_kernel_name()
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert (want != 0xFFFFFFFF).mean() > 0.01 and (want == 0xFFFFFFFF).mean() > 0.1
+
+
 def test_length_order_edge_shapes():
     """Length ordering on batches with empty strings, one giant string among short ones, and all pairs outside the band."""
     g = Dg.rng(5)

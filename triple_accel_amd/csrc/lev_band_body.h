@@ -47,7 +47,7 @@ struct LevParams {
     uint32_t lds_per_wave;    // bytes
     uint32_t Tw;              // warm-up iterations (>= L*D/2; padded so the streamed chunks start on 64-byte lines)
     uint32_t ch;              // bytes per string per streamed chunk
-    uint32_t tune = 0;        // bit 0: chunk form of the bit-parallel band kernel's fetch also for fixed-length batches (set by the launcher)
+    uint32_t tune = 0;        // bit 2 (4): `subset` is ordered by exact column count (VLINE form); bit 0: chunk form of the bit-parallel band kernel's fetch also for fixed-length batches (set by the launcher)
                               // bit 1: early out of the bit-parallel band kernels (ta_set_option(TA_OPT_EARLY_OUT, 1))
     uint32_t q_table = 0, q_shift = 0;       // lev_bitsq: byte c of q_table = the symbol with code c, code = (byte >> q_shift) & 3
     uint32_t *q_bad_count = nullptr, *q_bad_list = nullptr;   // lev_bitsq: the pairs that hold a byte outside the alphabet

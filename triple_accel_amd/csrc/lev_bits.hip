@@ -113,6 +113,12 @@ static hipError_t launch_na(const LevParams &P, bool trans, bool stat, bool line
 
 hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out) {
+    // CSR batches whose band fits the stride-8 window, under TA_BITS_VLINE=1: the VLINE form (every line of a string requested once, per-lane
+    // geometry and alignment; lev_bits_vline.hip).  It runs one column count per pass, so it takes the batches ta_levenshtein_k_batch has
+    // ordered by their exact column count (tune bit 2).  Measured, not the default: 0.72 x the chunk form's fabric-side bytes on the ragged
+    // cfg2 batch but 8 % more time -- ten times the load instructions (eight lane classes burst in turn) on an issue-bound kernel
+    // (profiles/r04/ab_ragged.md).
+    if ((P0.a.off || P0.b.off) && pl.s8 && (P0.tune & 4u) && P0.subset && env_int("TA_BITS_VLINE")) return lev_bits_vline_launch(P0, pl, trans, s, grid_out, lds_out);
     LevParams P = P0;
     // fixed-length batches of strings longer than one 128-byte line take the line form of the fetch (lev_bits_body.h); up to one
     // line the chunk form has nothing to refetch and its coarser events (one per 64 columns, not per 16) are cheaper:

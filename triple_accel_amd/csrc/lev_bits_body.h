@@ -42,8 +42,11 @@ namespace ta {
 //     register that wraps around (one v_perm_b32); the loop is unrolled 8 columns so the names are fixed: no moves at all;
 //   * the 33rd diagonal is the ONEBIT one (below): its byte is the one about to enter, its match a v_cmp on that byte.
 // 39 VALU instructions per column instead of 48 (static form).
-template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false>
+// VLINE: the line form for batches whose pairs have their OWN geometry and alignment (CSR batches): every 128-byte line of memory that
+// holds bytes of a string is requested once, whole, by the pair's lane -- see run().
+template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false, bool VLINE = false>
 struct LevBits {
+    static_assert(!(LINE && VLINE), "one fetch form per instantiation");
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static_assert(!S8 || (NA == 8 && !STATIC), "the stride-8 form is its own window layout: 8 registers, 33 diagonals");
     static constexpr int WB = S8 ? 33 : STATIC ? 4 * NA - 3 : 4 * NA;   // window bits (diagonals)
@@ -200,16 +203,39 @@ struct LevBits {
 
     static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
         const U32 lane = W::lane();
-        const U32 grp = lane;
-        const Bool active = (lane == lane);
         const U32 slot_idx = lane + wave_index * 64u;
-        const Bool valid = slot_idx < P.n;
-        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, valid, 0u) : slot_idx;
+        const Bool in_batch = slot_idx < P.n;
+        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, in_batch, 0u) : slot_idx;
 
         Ptr aptr, bptr;
         U32 alen, blen;
-        W::load_str(P.a, pair, valid, aptr, alen);     // rows
-        W::load_str(P.b, pair, valid, bptr, blen);     // columns
+        W::load_str(P.a, pair, in_batch, aptr, alen);     // rows
+        W::load_str(P.b, pair, in_batch, bptr, blen);     // columns
+        if constexpr (VLINE) {
+            // The VLINE form runs ONE column count per pass: every event of the column loop is then wave-uniform (no capped blocks, the
+            // way down taken once), only the rows' geometry and the alignments are per lane.  The launcher hands it batches ordered
+            // by b's exact length (util_kernels.hip), so a wavefront is one pass -- two where a length class ends inside it.  Pairs
+            // outside the band (None before any cell, src/levenshtein.rs:426-428; first in the order, any length) never start a pass.
+            const U32 diff0 = W::sel(blen >= alen, blen - alen, alen - blen);
+            const Bool out_of_band = in_batch & (diff0 > P.u);
+            W::store_u32(P.out, pair, W::splat(0xFFFFFFFFu), out_of_band);
+            Bool todo = in_batch & !out_of_band;
+            while (W::any(todo)) {
+                const uint32_t cols = W::first_u32(blen, todo);
+                const Bool mine = todo & (blen == cols);
+                run_pass(P, lds, lane, mine, pair, aptr, alen, bptr, blen, cols);
+                todo = todo & !mine;
+            }
+        } else {
+            run_pass(P, lds, lane, in_batch, pair, aptr, alen, bptr, blen, 0u);
+        }
+    }
+
+    // `valid`: the lanes whose pair this pass answers; VLINE: all of them have blen == cols
+    static TA_HD inline void run_pass(const LevParams &P, uint8_t *lds, const U32 &lane, const Bool &valid, const U32 &pair,
+                                      const Ptr &aptr, const U32 &alen, const Ptr &bptr, const U32 &blen, uint32_t cols) {
+        const U32 grp = lane;
+        const Bool active = (lane == lane);
 
         // the pair's band (lev_plan.h): diagonals d = j - i in [-nlo, d_hi]; window bit i <-> diagonal d_hi - i
         const U32 diff = W::sel(blen >= alen, blen - alen, alen - blen);
@@ -268,13 +294,15 @@ struct LevBits {
         const U32 da = (W::splat(16u) - (ca & 15u)) & 15u, db = W::splat(0);   // T0 is a multiple of 64 (lev_plan.h)
         const U32 ea = ca + da, eb = cb + db;
         const uint32_t tp0 = T0 - W::wave_max(W::sel(valid, nlo, W::splat(0)));
-        const uint32_t iters = T0 + W::wave_max(blen);
+        const uint32_t iters = T0 + (VLINE ? cols : W::wave_max(blen));
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
         // ---- one span of iterations [tp, p_hi) on LDS-resident characters; addr_a(tp) / addr_b(tp) = LDS byte address of the
         // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3).
         // A pair whose last column has just run takes its way down from the state as it is now:
         auto finished = [&](Bool fin) { if (W::any(fin)) tail = W::sel(fin, way_down(), tail); };
+        // (VLINE: the rings carry 8 bytes of wrap copy, so the second dword of an 8-iteration block is the first one's address + 4 --
+        // a ds_read offset, not a second per-lane address computation)
         auto run_span = [&](uint32_t tp, uint32_t p_hi, auto addr_a, auto addr_b, auto uniform_tag) -> uint32_t {
             // UNI = line form = one geometry for the wavefront: every pair runs to the last column, none is capped, and the way
             // down is taken once after the last span
@@ -284,7 +312,8 @@ struct LevBits {
                 // string, eight steps with their register names fixed.  One loop per kind of block -- warm-up, whole, capped /
                 // cut short -- so that no loop body has paths to join (joins cost a copy per window register).
                 for (; tp < p_hi && tp < T0; tp += 8u) {   // warm-up: rows 1..nlo slide in (whole blocks: T0 is a multiple of 64)
-                    const U32 x0 = W::lds_read32u(lds, addr_a(tp)) ^ 0x0C0C0C0Cu, x1 = W::lds_read32u(lds, addr_a(tp + 4u)) ^ 0x0C0C0C0Cu;
+                    const U32 pa_w = addr_a(tp);
+                    const U32 x0 = W::lds_read32u(lds, pa_w) ^ 0x0C0C0C0Cu, x1 = W::lds_read32u(lds, VLINE ? pa_w + 4u : addr_a(tp + 4u)) ^ 0x0C0C0C0Cu;
                     step8<false, 0, false>(st, x0, x0, x0, active); step8<false, 1, false>(st, x0, x0, x0, active);
                     step8<false, 2, false>(st, x0, x0, x0, active); step8<false, 3, false>(st, x0, x0, x0, active);
                     step8<false, 4, false>(st, x1, x1, x1, active); step8<false, 5, false>(st, x1, x1, x1, active);
@@ -300,9 +329,10 @@ struct LevBits {
                                 if (!W::any(valid & inband & (top <= W::bcnt(st.VN[0], W::splat(P.k))))) { dead = true; return tp; }
                             }
                         }
-                        const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
+                        const U32 pa_h = addr_a(tp), pb_h = addr_b(tp);
+                        const U32 r0 = W::lds_read32u(lds, pa_h), r1 = W::lds_read32u(lds, VLINE ? pa_h + 4u : addr_a(tp + 4u));
                         const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
-                        const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
+                        const U32 b0 = W::lds_read32u(lds, pb_h), b1 = W::lds_read32u(lds, VLINE ? pb_h + 4u : addr_b(tp + 4u));
                         step8<false, 0, true>(st, b0, r0, x0, active); step8<false, 1, true>(st, b0, r0, x0, active);
                         step8<false, 2, true>(st, b0, r0, x0, active); step8<false, 3, true>(st, b0, r0, x0, active);
                         step8<false, 4, true>(st, b1, r1, x1, active); step8<false, 5, true>(st, b1, r1, x1, active);
@@ -313,9 +343,10 @@ struct LevBits {
                 }
                 for (; tp < p_hi; tp += 8u) {              // capped blocks, and the last one when the columns end inside it
                     if (nacc > 24u) flush();
-                    const U32 r0 = W::lds_read32u(lds, addr_a(tp)), r1 = W::lds_read32u(lds, addr_a(tp + 4u));
+                    const U32 pa_c = addr_a(tp), pb_c = addr_b(tp);
+                    const U32 r0 = W::lds_read32u(lds, pa_c), r1 = W::lds_read32u(lds, VLINE ? pa_c + 4u : addr_a(tp + 4u));
                     const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
-                    const U32 b0 = W::lds_read32u(lds, addr_b(tp)), b1 = W::lds_read32u(lds, addr_b(tp + 4u));
+                    const U32 b0 = W::lds_read32u(lds, pb_c), b1 = W::lds_read32u(lds, VLINE ? pb_c + 4u : addr_b(tp + 4u));
                     const uint32_t left = p_hi - tp;       // >= 1 columns of this block run
                     Bool l = t_stop > tp, n;               // (a pair's last column: live now, not in the next one)
 #define TA_STEP8(c, bw, rw, xw) if (left > (uint32_t)c) { n = t_stop > (tp + (uint32_t)c + 1u); step8<true, c, true>(st, bw, rw, xw, l); finished(l & !n); l = n; }
@@ -393,7 +424,108 @@ struct LevBits {
         };
 
         const U32 a_slot = grp * BITS_SLOT_A, b_slot = grp * BITS_SLOT_B + 64u * BITS_SLOT_A;
-        if constexpr (LINE) {
+        if constexpr (VLINE) {
+            // ---- VLINE form (CSR batches: every pair has its own lengths, band geometry AND alignment).  A string is read in
+            // the units the memory system moves: the lane requests each 128-byte LINE that holds bytes of its string exactly once, whole
+            // (eight 16-byte loads in one burst, parked in registers), so the fabric side of the L2 sees every such line once --
+            // the chunk form's 64-byte pieces of unaligned strings, 64 columns apart, made it see them 3.5 times.
+            //   * Stream.  Iteration t needs the byte at address  ptr - c + t  (c = ca for `a`: per lane, cb for `b`); its low 32 bits
+            //     y = s + t  place it in the lane's stream of 16-byte-aligned PIECES: piece y >> 4, line y >> 7.
+            //   * Ring.  LDS holds the last four pieces per string (64 bytes + an 8-byte copy of its start behind the end); ring byte
+            //     = y & 63, a per-lane address.  Block u (iterations 16u .. 16u + 15) reads at most pieces (s >> 4) + u .. + 2 and
+            //     the step in front of it commits piece  P(u) = (s >> 4) + u + 2  into the slot of the piece that died a block ago.
+            //   * Registers.  The commit must name its source register in the instruction, the same in every lane, while P(u) & 7
+            //     differs from lane to lane.  So the lanes are in eight CLASSES  kappa = ((s >> 4) + 2) & 7  and a burst of class
+            //     kappa loads piece c of its line into register (c - kappa) & 7: step u then commits register u & 7 in EVERY lane.
+            //     A lane's burst for its next line follows the commit of its piece 7 -- step u serves the class (7 - u) & 7, eight
+            //     loads under that class's lane mask -- and its first piece is due at the next step, 16 iterations later.
+            //   * Lines that hold no byte of the string are not requested; bytes of a line outside the string are whatever memory
+            //     holds there (rows above the matrix and below a_len need no particular value -- see the file header -- and `b` is
+            //     only read inside its columns).
+            // per pair: a 64 + 8, b 64 + 8, an 8-byte dump (where the wrap copy of a piece that is not the ring's first goes: an
+            // unconditional store to a selected address instead of a store under a lane mask -- no branch), 4 spare: 39 dwords (odd)
+            constexpr uint32_t VSLOT = 156u, VB_OFF = 72u, VDUMP = 144u;
+            const U32 va_slot = grp * VSLOT, vb_slot = va_slot + VB_OFF;
+            uint32_t tp = S8 ? (tp0 & ~7u) : STATIC ? (tp0 & ~3u) : tp0;
+            const uint32_t tb0 = tp & ~15u;
+            const U32 s_a = W::ptr_lo32(aptr) - ca, s_b = W::ptr_lo32(bptr) - cb;
+            const U32 e2a = (s_a >> 4) + 2u, e2b = (s_b >> 4) + 2u;
+            // Block u0 = tb0 >> 4 reads the pieces P(u0 - 2), P(u0 - 1), P(u0): these three come straight from memory (three 16-byte loads
+            // per string, in flight together with the first line bursts: ONE memory latency in front of the first column -- taking them
+            // through the register file cost up to two more, a tenth of a 144-column wavefront's life); the register file delivers from
+            // P(u0 + 1) on.  ap0 / bp0 = the piece of iteration tb0's byte (address ptr - (c - tb0): c >= tb0), al / bl = the line of
+            // P(u0 + 1), also relative to the string's start.
+            const Ptr ap0 = W::ptr_piece(W::ptr_sub(aptr, ca - tb0)), bp0 = W::ptr_piece(W::ptr_sub(bptr, cb - tb0));
+            Ptr al = W::ptr_line(W::ptr_add(ap0, W::splat(48u))), bl = W::ptr_line(W::ptr_add(bp0, W::splat(48u)));
+            U32 rel_a = W::ptr_lo32(al) - W::ptr_lo32(aptr), rel_b = W::ptr_lo32(bl) - W::ptr_lo32(bptr);
+            // a line [rel, rel + 128) holds bytes of the string [0, len)  <=>  rel + 127 < len + 127 (unsigned); nothing for lanes
+            // without a pair or with an empty string
+            const U32 lim_a = W::sel(valid & (alen > 0u), alen + 127u, W::splat(0)), lim_b = W::sel(valid & (blen > 0u), blen + 127u, W::splat(0));
+            Q SA[8], SB[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) { SA[c] = W::qzero(); SB[c] = W::qzero(); }
+            // the eight loads of class kappa's lanes: register j <- piece (j + kappa) & 7 of the line (W::gload_line_keep)
+            auto burst_class = [&](Q (&S)[8], const Ptr &line, const Bool &pred, uint32_t kappa) __attribute__((always_inline)) { W::gload_line_keep(S, line, pred, kappa); };
+            auto vput = [&](const Q (&S)[8], uint32_t reg, U32 dst, U32 mirror_at, uint32_t x) __attribute__((always_inline)) {
+                // (case_tag, LAST in every case: the tails of eight cases that differ only in the index of S get sunk into one block that reads
+                // S through a pointer phi -- and S, 64 registers, moves to scratch memory)
+                switch (reg & 7u) {                                // wave-uniform: one of eight stores
+#define TA_VPUT(c) case c: { const Q q = x ? W::qxor(S[c], x) : S[c]; W::lds_store16(lds, dst, q, active); \
+                             W::lds_write32(lds, mirror_at, W::qword(q, 0)); W::lds_write32(lds, mirror_at + 4u, W::qword(q, 1)); W::template case_tag<c>(); } break;
+                    TA_VPUT(0) TA_VPUT(1) TA_VPUT(2) TA_VPUT(3) TA_VPUT(4) TA_VPUT(5) TA_VPUT(6) TA_VPUT(7)
+#undef TA_VPUT
+                }
+            };
+            // step u: commit piece P(u) of both strings; the lanes whose piece was the last of its line request the next line
+            auto vstep = [&](uint32_t u) __attribute__((always_inline)) {      // (not inlined, the parked registers live in scratch memory)
+                W::wait_vm0();                                 // the bursts of the step before (16 iterations ago)
+                const U32 pa = e2a + u, pb = e2b + u;
+                vput(SA, u, va_slot + ((pa & 3u) << 4), W::sel((pa & 3u) == 0u, va_slot + 64u, va_slot + VDUMP), PREX ? 0x0C0C0C0Cu : 0u);
+                vput(SB, u, vb_slot + ((pb & 3u) << 4), W::sel((pb & 3u) == 0u, vb_slot + 64u, va_slot + VDUMP), 0u);
+                const Bool na = (pa & 7u) == 7u, nb = (pb & 7u) == 7u;
+                al = W::sel_ptr(na, W::ptr_add(al, W::splat(128u)), al);  rel_a = W::sel(na, rel_a + 128u, rel_a);
+                bl = W::sel_ptr(nb, W::ptr_add(bl, W::splat(128u)), bl);  rel_b = W::sel(nb, rel_b + 128u, rel_b);
+                burst_class(SA, al, na & ((rel_a + 127u) < lim_a), 7u - (u & 7u));
+                burst_class(SB, bl, nb & ((rel_b + 127u) < lim_b), 7u - (u & 7u));
+            };
+            const uint32_t u0 = tb0 >> 4;
+            {
+                // a piece [rel, rel + 16) holds bytes of the string  <=>  rel + 15 < len + 15 (unsigned); the others are never looked at
+                const U32 ra0 = W::ptr_lo32(ap0) - W::ptr_lo32(aptr), rb0 = W::ptr_lo32(bp0) - W::ptr_lo32(bptr);
+                const U32 pla = W::sel(valid & (alen > 0u), alen + 15u, W::splat(0)), plb = W::sel(valid & (blen > 0u), blen + 15u, W::splat(0));
+                Q FA[3], FB[3];
+#pragma unroll
+                for (uint32_t i = 0; i < 3u; i++) {
+                    FA[i] = W::gload16(W::ptr_add(ap0, W::splat(16u * i)), (ra0 + (16u * i + 15u)) < pla);
+                    FB[i] = W::gload16(W::ptr_add(bp0, W::splat(16u * i)), (rb0 + (16u * i + 15u)) < plb);
+                }
+                // first lines: every class loads the line of P(u0 + 1)
+                const Bool oka = (rel_a + 127u) < lim_a, okb = (rel_b + 127u) < lim_b;
+#pragma unroll
+                for (uint32_t kappa = 0; kappa < 8u; kappa++) {
+                    burst_class(SA, al, oka & ((e2a & 7u) == kappa), kappa);
+                    burst_class(SB, bl, okb & ((e2b & 7u) == kappa), kappa);
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 3u; i++) {
+                    const U32 pa = e2a + (u0 - 2u + i), pb = e2b + (u0 - 2u + i);
+                    const Q qa = PREX ? W::qxor(FA[i], 0x0C0C0C0Cu) : FA[i];
+                    W::lds_store16(lds, va_slot + ((pa & 3u) << 4), qa, active);
+                    W::lds_write32p(lds, va_slot + 64u, W::qword(qa, 0), (pa & 3u) == 0u); W::lds_write32p(lds, va_slot + 68u, W::qword(qa, 1), (pa & 3u) == 0u);
+                    W::lds_store16(lds, vb_slot + ((pb & 3u) << 4), FB[i], active);
+                    W::lds_write32p(lds, vb_slot + 64u, W::qword(FB[i], 0), (pb & 3u) == 0u); W::lds_write32p(lds, vb_slot + 68u, W::qword(FB[i], 1), (pb & 3u) == 0u);
+                }
+            }
+            for (uint32_t tb = tb0; tb < iters; tb += 16u) {
+                if (tb != tb0) vstep(tb >> 4);
+                W::lds_wave_sync();
+                const uint32_t b_hi = tb + 16u < iters ? tb + 16u : iters;
+                tp = run_span(tp, b_hi,
+                              [&](uint32_t t) { return va_slot + ((s_a + t) & 63u); },
+                              [&](uint32_t t) { return vb_slot + ((s_b + t) & 63u); }, std::true_type());
+            }
+            tail = way_down();                                  // every pair of the pass ended with the last column run
+        } else if constexpr (LINE) {
             // ---- LINE form (fixed-length batches, with or without a subset list): every 128-byte line of a string is requested
             // ONCE, whole -- eight 16-byte loads of the lane's own pair in one burst, parked in registers (2 x 8 x 16 bytes per
             // lane) -- and handed to LDS piece by piece: LDS holds a ring of 5 pieces of `a` and 4 pieces of `b` per pair, each followed by

@@ -89,9 +89,17 @@ static inline LevPlan lev_make_plan(uint32_t k, uint32_t mc, uint32_t gc, uint32
     return p;
 }
 
+// ---- costs that are a unit-cost family times g: EditCosts(g, g, 0, None) or (g, g, 0, Some(g)), g >= 2.  Every alignment then costs g
+// times its unit cost, so  d = g d_unit  and  d <= k  <=>  d_unit <= k / g: the pass runs the unit-cost (bit-parallel) kernels with
+// k / g and multiplies the answers -- the one family of weighted costs that rides the bit-vector kernels as it is.  0: not such costs.
+static inline uint32_t lev_unit_scale(uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc) {
+    return (sg == 0 && mc == gc && gc >= 2 && (!has_t || tc == gc)) ? gc : 0u;
+}
+
 // ---- bit-parallel band kernel (lev_bits_body.h): unit costs only, one pair per lane, window of 4*NA diagonals
 static const int LEV_BITS_MAX_NA = 32;      // kernels exist for NA = 1..16 and the even NA up to 32
 static const uint32_t LEV_BITS_S8_MIN = 25; // narrowest band (diagonals) the planner gives to the stride-8 form
+static const uint32_t LEV_BITS_VLINE_LDS = 64u * 156u;   // VLINE fetch form: per pair two rings of 64 + 8 bytes, an 8-byte dump (+ 4: an odd dword stride)
 
 struct LevBitsPlan {
     bool ok;                 // false: costs are not a unit-cost family, or the band is wider than the window

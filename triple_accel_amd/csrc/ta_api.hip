@@ -171,15 +171,31 @@ static int side_max_len(const ta_strings *s, uint32_t n, hipStream_t st, uint64_
 }
 
 // One k-bounded distance pass over the batch (or over `subset`); the heart of every distance entry point.
+// columns_ordered: `subset` lists the pairs by their exact column count (length_order_launch): 64 consecutive ones share it -- what
+// the VLINE form of the bit-parallel band kernel wants (one pass per wavefront)
 static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, const uint32_t *subset, uint32_t k,
-                    const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st) {
+                    const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st, bool columns_ordered = false) {
     const uint32_t gc = c->gap_cost, sg = c->start_gap_cost;
+    // unit costs times g: the unit-cost kernels with k / g, then the answers times g (lev_plan.h: lev_unit_scale)
+    if (const uint32_t g = lev_unit_scale(c->mismatch_cost, gc, sg, c->has_transpose != 0, c->transpose_cost);
+        g && !env_int("TA_NO_BITS") && !env_int("TA_NO_UNIT_SCALE") && !env_int("TA_FORCE_D") && !env_int("TA_FORCE_L")) {
+        const ta_edit_costs uc = {1, 1, 0, (uint8_t)(c->has_transpose ? 1 : 0), (uint8_t)(c->has_transpose ? 1 : 0)};
+        int rc = lev_pass(a, b, n_work, subset, k / g, &uc, max_len, out_dev, st, columns_ordered);
+        if (rc) return rc;
+        TA_HIP(scale_results_launch(out_dev, subset, n_work, g, st));
+        g_answer_single_store = false;                 // two stores to the result slot: the single-call path waits for the stream
+        ta_lev_select sel;
+        ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
+        g_last_launch.cell_bits = sel.cell_bits;       // (the reference's width class is that of the caller's costs and k)
+        return TA_OK;
+    }
     LevPlan pl = lev_make_plan(k, c->mismatch_cost, gc, sg, max_len, env_int("TA_FORCE_D"), env_int("TA_FORCE_L"), env_int("TA_FORCE_CH"));
     LevParams P;
     P.a = view_of(a); P.b = view_of(b);
     P.subset = subset; P.trace = nullptr; P.out = out_dev; P.n = n_work; P.k = k;
     P.mc = c->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = c->has_transpose ? c->transpose_cost : 0;
     P.u = pl.u; P.o = pl.o;
+    if (columns_ordered && subset) P.tune |= 4u;
     const bool affine = sg > 0 || env_int("TA_FORCE_AFFINE"), trans = c->has_transpose != 0;
     ta_launch_info li = {};
     li.band_offset = pl.o; li.affine = affine; li.transpose = trans;
@@ -437,6 +453,7 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     // order of a counting sort on their length class (util_kernels.hip: three small launches, ~20 us per million pairs) --
     // every wavefront then sees pairs within 8 bytes of each other.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
     const uint32_t *order = nullptr;
+    bool exact_columns = false;
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
         Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
         constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;                    // histogram + cursors: 1024 bins x 32 counters each
@@ -444,10 +461,14 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
         if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
         if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));   // once: every pass leaves the histogram zeroed behind it
         const uint32_t u = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
-        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u, max_len, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
+        // the key counts what the kernel of this pass iterates over: columns (bit-parallel kernels) or anti-diagonal steps (DP band kernel)
+        const bool unit = (costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1)) ||
+                          lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, costs->transpose_cost);
+        const bool by_steps = !unit || env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L");
+        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u, max_len, by_steps, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st, env_int("TA_BITS_VLINE") != 0, &exact_columns));
         order = (const uint32_t *)ord.dev;
     }
-    return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st);
+    return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st, exact_columns);
 }
 
 /* ta_levenshtein_k_batch for strings written in a SMALL ALPHABET the caller names (at most four distinct byte values: DNA, RNA):
@@ -552,7 +573,8 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
         if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));
         const uint32_t u0 = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
-        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u0, max_len, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
+        const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1);
+        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u0, max_len, !unit || env_int("TA_NO_BITS"), (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
         sub_in = (uint32_t *)ord.dev;
     }
     int flip = 0;
@@ -577,6 +599,8 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
             work = (const uint32_t *)wrk.dev;
         }
         if (n_work > 0) {
+            // (the compacted lists keep the order block by block only -- a wavefront may straddle two blocks' shares: the chunk form,
+            // which takes any mix of lengths in one pass, stays the rounds' kernel)
             rc = lev_pass(a, b, n_work, work, k, costs, max_len, out_dev, st);
             g_exp_passes++;
             if (rc) return rc;

@@ -76,6 +76,8 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s);
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
+// the VLINE fetch form (lev_bits_vline.hip): CSR batches through the stride-8 window
+hipError_t lev_bits_vline_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bitsq_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipStream_t s, uint32_t *lds_out);
@@ -95,6 +97,7 @@ hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, 
 hipError_t strings_maxlen_launch(const StrView &s, uint32_t n, uint32_t *out_max /*device, pre-zeroed*/, hipStream_t st);
 hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out,
                                uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
+hipError_t scale_results_launch(uint32_t *out, const uint32_t *list /*pairs, or nullptr: 0..n*/, uint32_t n, uint32_t g, hipStream_t st);
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
                                 uint32_t *list_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st);
@@ -102,9 +105,9 @@ hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*
                             uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 // counting sort of the pairs of a ragged batch by length class (util_kernels.hip): subset_out = the pairs (of subset_in, or
 // 0..n) ordered so that 64 consecutive ones are within a few bytes of each other; bins = 2 x 32768 u32 of device scratch, the
-// first half zero on entry (it is zero again on exit)
-hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
-                               uint32_t *bins, uint32_t *subset_out, hipStream_t st);
+// first half zero on entry (it is zero again on exit); *exact_columns: 64 consecutive pairs of the order share their exact column count
+hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len, bool by_steps,
+                               uint32_t *bins, uint32_t *subset_out, hipStream_t st, bool exact = false, bool *exact_columns = nullptr);
 
 struct SearchParams {
     const uint8_t *hay;       // device

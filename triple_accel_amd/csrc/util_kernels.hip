@@ -96,6 +96,20 @@ hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, u
     return hipGetLastError();
 }
 
+// costs that are the unit costs times g (lev_unit_scale, lev_plan.h): the pass ran on unit costs with k / g, its answers times g
+__global__ void scale_results_kernel(uint32_t *out, const uint32_t *list, uint32_t n, uint32_t g) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pair = list ? list[i] : i;
+    const uint32_t d = out[pair];
+    if (d != 0xFFFFFFFFu) out[pair] = d * g;
+}
+hipError_t scale_results_launch(uint32_t *out, const uint32_t *list, uint32_t n, uint32_t g, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_results_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, list, n, g);
+    return hipGetLastError();
+}
+
 // exp search with a lower bound: next round's work list = unresolved pairs whose bound admits the next threshold
 __global__ void compact_bound_kernel(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
                                      uint32_t *list_out, uint32_t *count) {
@@ -112,22 +126,32 @@ hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint
 }
 
 // ---- ragged batches: the pairs ordered by length ("bucket by length first if lengths vary so waves are uniform").
-// The band kernels run a wavefront to the longest of its pairs; with the pairs of a CSR batch taken in the order of a counting
-// sort on  key = 0 for a pair outside the band (|len_a - len_b| > unit_k: None before any cell, src/levenshtein.rs:426-428),
-// else 1 + (max(len_a, len_b) >> shift)  every wavefront's pairs are within 2^shift bytes of each other.  Three small launches:
+// The band kernels run a wavefront to the longest of its pairs: 64 pairs of 8 different lengths cost the longest one's columns plus
+// the capped blocks at the end (+8 % on the ragged cfg2 batch, profiles/r04/ab_ragged.md).  The pairs of a CSR batch are therefore
+// taken in the order of a counting sort on
+//     key = 0 for a pair outside the band (|len_a - len_b| > unit_k: None before any cell, src/levenshtein.rs:426-428), else
+//     LEN_BINS - 1 - (w >> shift),   w = len_b (LEN_BY_COLUMNS: the bit-parallel kernels run one column per byte of b) or
+//                                     w = len_a + len_b (LEN_BY_STEPS: the DP band kernel runs one step per anti-diagonal)
+// with shift = 3 (8-byte classes) or the smallest one that fits LEN_BINS bins, and the LONGEST pairs first: the launch's tail is then made
+// of the shortest wavefronts (the ragged cfg2 batch: 0.227 ms against 0.243 shortest-first, profiles/r04/ab_ragged.md).  `exact`
+// (the VLINE fetch form asks for it) takes shift 0 where that fits: every wavefront's pairs then run EXACTLY the same number of columns;
+// it is not the default because eight times as many non-empty bins are eight times as many global atomics in the histogram and
+// scatter kernels (26.4 us against 23.0 per million pairs) and the chunk-form kernel gains nothing from it.  Three small launches:
 // histogram (per-block counters in LDS, one global atomic per non-empty bin and block), exclusive scan of <= LEN_BINS bins,
 // scatter (a block reserves its share of every bin with one atomic, its pairs take their places through LDS counters).  The
 // order inside a bin is whatever the atomics make it -- the results are per pair and do not depend on it.
 constexpr uint32_t LEN_BINS = 1024, LEN_PAIRS_PER_BLOCK = 2048, LEN_PPT = LEN_PAIRS_PER_BLOCK / 256;
 // every bin has LEN_SUB counters (a block uses the one of its index mod LEN_SUB): hundreds of blocks bumping the same ~30 addresses
 // serialise at the L2 (18 us per million pairs with one counter per bin, 15.7 with 8)
-constexpr uint32_t LEN_SUB = 32;     // counters laid out [sub][bin]: the scan reads them coalesced
+constexpr uint32_t LEN_SUB = 32, LEN_ASC = 0x80000000u, LEN_BY_STEPS = 0x40000000u;     // counters laid out [sub][bin]: the scan reads them coalesced
 __device__ __forceinline__ uint32_t len_key(const StrView &a, const StrView &b, uint32_t pair, uint32_t u, uint32_t shift) {
     const uint64_t la = a.off ? a.off[pair + 1] - a.off[pair] : a.len, lb = b.off ? b.off[pair + 1] - b.off[pair] : b.len;
     const uint64_t mx = la > lb ? la : lb, mn = la > lb ? lb : la;
     if (mx - mn > u) return 0u;
-    const uint64_t key = 1u + (mx >> shift);
-    return key < LEN_BINS ? (uint32_t)key : LEN_BINS - 1u;
+    const uint64_t w = (shift & LEN_BY_STEPS) ? la + lb : lb;
+    const uint64_t key = 1u + (w >> (shift & 31u));
+    const uint32_t kk = key < LEN_BINS ? (uint32_t)key : LEN_BINS - 1u;
+    return (shift & LEN_ASC) ? kk : LEN_BINS - kk;            // the longest pairs first (keys 1..LEN_BINS-1 mirrored); LEN_ASC: A/B only
 }
 // the block's pairs and their keys, all loads in flight before the first LDS atomic (a load -> atomic chain per pair made
 // the kernels latency-bound: 13.5 us per million pairs each)
@@ -194,11 +218,17 @@ __global__ __launch_bounds__(256) void len_scatter_kernel(StrView a, StrView b, 
 }
 // bins: 2 * LEN_BINS * LEN_SUB u32 (256 KiB) of device scratch whose first half is ZERO on entry (and again on exit: zero it once, when it is
 // allocated); subset_out: n u32.  max_len = the batch's longest string.
+// by_steps: the key counts anti-diagonal steps (len_a + len_b: the DP band kernel) instead of columns (len_b: the bit-parallel kernels)
 hipError_t length_order_launch(const StrView &a, const StrView &b, const uint32_t *subset_in, uint32_t n, uint32_t u, uint64_t max_len,
-                               uint32_t *bins, uint32_t *subset_out, hipStream_t st) {
+                               bool by_steps, uint32_t *bins, uint32_t *subset_out, hipStream_t st, bool exact, bool *exact_columns) {
+    if (exact_columns) *exact_columns = false;
     if (n == 0) return hipSuccess;
-    uint32_t shift = 3;                                               // 8-byte classes while 1022 of them cover the longest string
-    while ((max_len >> shift) + 2 > LEN_BINS) shift++;
+    const uint64_t w_max = by_steps ? 2 * max_len : max_len;
+    uint32_t shift = exact ? 0u : 3u;                                 // 8-byte (or exact) classes while LEN_BINS - 2 of them cover the longest pair
+    while ((w_max >> shift) + 2 > LEN_BINS) shift++;
+    if (exact_columns) *exact_columns = !by_steps && shift == 0;
+    if (by_steps) shift |= LEN_BY_STEPS;
+    if (env_int("TA_ORDER_ASC")) shift |= LEN_ASC;
     const uint32_t blocks = (n + LEN_PAIRS_PER_BLOCK - 1) / LEN_PAIRS_PER_BLOCK;
     hipLaunchKernelGGL(len_hist_kernel, dim3(blocks), dim3(256), 0, st, a, b, subset_in, n, u, shift, bins);
     hipLaunchKernelGGL(len_scan_kernel, dim3(1), dim3(LEN_BINS), 0, st, bins, bins + LEN_BINS * LEN_SUB);

@@ -115,6 +115,10 @@ struct DevWave {
         return (Ptr)(((uint64_t)hi << 32) | lo);
     }
     static __device__ __forceinline__ bool any(Bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+    // x of the first lane where c holds (c must hold somewhere) -> s_ff1 + v_readlane
+    static __device__ __forceinline__ uint32_t first_u32(U32 x, Bool c) {
+        return __builtin_amdgcn_readlane(x, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(c)));
+    }
     // wave-wide unsigned maximum in six DPP steps (no LDS round trips): row_shr 1, 2, 4, 8 leave a row's maximum in its
     // lane 15 (a lane without a source reads 0, the identity), row_bcast:15 / row_bcast:31 carry it on to lane 63
     static __device__ __forceinline__ uint32_t wave_max(U32 x) {
@@ -152,6 +156,138 @@ struct DevWave {
     }
     static __device__ __forceinline__ Ptr ptr_add(Ptr p, U32 off) { return p + off; }
     static __device__ __forceinline__ Ptr ptr_splat(const uint8_t *p) { return p; }
+    // the pieces of pointer arithmetic the VLINE fetch form needs (lev_bits_body.h): low 32 bits of an address, p - off, the 128-byte line of p
+    static __device__ __forceinline__ U32 ptr_lo32(Ptr p) { return (uint32_t)(uintptr_t)p; }
+    static __device__ __forceinline__ Ptr ptr_sub(Ptr p, U32 off) { return p - off; }
+    static __device__ __forceinline__ Ptr ptr_piece(Ptr p) { return p - ((uint32_t)(uintptr_t)p & 15u); }                 // its 16-byte piece
+    static __device__ __forceinline__ Ptr ptr_line(Ptr p) { return p - ((uint32_t)(uintptr_t)p & 127u); }   // (no int -> pointer cast: the loads stay global_load)
+    static __device__ __forceinline__ Q128 qzero() { return Q128{0u, 0u, 0u, 0u}; }
+    // the eight 16-byte pieces of the 128-byte line at `line` (128-byte aligned) into S, rotated by the wave-uniform kappa:
+    // S[j] <- piece (j + kappa) & 7; the lanes where !pred keep what they hold.  ONE asm statement -- the lane mask into EXEC, a scalar
+    // jump to one of eight runs of eight global_load_dwordx4 (immediate offsets, destinations TIED to the registers S lives in), EXEC
+    // restored.  Written as `if (pred) S[j] = load` under a switch, hipcc keeps a second set of 32 registers and copies the old values over
+    // before every burst (191 VGPRs instead of 124).  The loads are invisible to the compiler's s_waitcnt bookkeeping: the caller waits
+    // for them with wait_vm0() before it reads S.  (Called with all 64 lanes active; the mask comes from a VALU compare and is read
+    // by a SALU instruction: interlocked.)
+    static __device__ __forceinline__ void gload_line_keep(Q128 (&S)[8], Ptr line, Bool pred, uint32_t kappa) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t0 = {S[0].x, S[0].y, S[0].z, S[0].w}, t1 = {S[1].x, S[1].y, S[1].z, S[1].w}, t2 = {S[2].x, S[2].y, S[2].z, S[2].w},
+              t3 = {S[3].x, S[3].y, S[3].z, S[3].w}, t4 = {S[4].x, S[4].y, S[4].z, S[4].w}, t5 = {S[5].x, S[5].y, S[5].z, S[5].w},
+              t6 = {S[6].x, S[6].y, S[6].z, S[6].w}, t7 = {S[7].x, S[7].y, S[7].z, S[7].w};
+        const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+        const uint32_t k = __builtin_amdgcn_readfirstlane(kappa & 7u);
+        uint64_t save;
+        uint32_t k7;
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                     "s_cbranch_execz .Lvl%=_end\n\t"
+                     "s_getpc_b64 vcc\n"
+                     ".Lvl%=_pc:\n\t"
+                     "s_lshl_b32 %[k7], %[k], 7\n\t"
+                     "s_add_u32 %[k7], %[k7], .Lvl%=_0-.Lvl%=_pc\n\t"
+                     "s_add_u32 vcc_lo, vcc_lo, %[k7]\n\t"
+                     "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                     "s_setpc_b64 vcc\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_0:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:112\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_1:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:0\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_2:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:16\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_3:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:32\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_4:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:48\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_5:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:64\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_6:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:96\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:80\n\t"
+                     "s_branch .Lvl%=_end\n\t"
+                     ".p2align 7\n"
+                     ".Lvl%=_7:\n\t"
+                     "global_load_dwordx4 %[t0], %[p], off offset:112\n\t"
+                     "global_load_dwordx4 %[t1], %[p], off offset:0\n\t"
+                     "global_load_dwordx4 %[t2], %[p], off offset:16\n\t"
+                     "global_load_dwordx4 %[t3], %[p], off offset:32\n\t"
+                     "global_load_dwordx4 %[t4], %[p], off offset:48\n\t"
+                     "global_load_dwordx4 %[t5], %[p], off offset:64\n\t"
+                     "global_load_dwordx4 %[t6], %[p], off offset:80\n\t"
+                     "global_load_dwordx4 %[t7], %[p], off offset:96\n\t"
+                     "\n.Lvl%=_end:\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [t4] "+v"(t4), [t5] "+v"(t5), [t6] "+v"(t6), [t7] "+v"(t7),
+                       [sv] "=&s"(save), [k7] "=&s"(k7)
+                     : [p] "v"(line), [m] "s"(m), [k] "s"(k)
+                     : "memory", "scc", "vcc");
+        S[0] = Q128{t0.x, t0.y, t0.z, t0.w}; S[1] = Q128{t1.x, t1.y, t1.z, t1.w}; S[2] = Q128{t2.x, t2.y, t2.z, t2.w}; S[3] = Q128{t3.x, t3.y, t3.z, t3.w};
+        S[4] = Q128{t4.x, t4.y, t4.z, t4.w}; S[5] = Q128{t5.x, t5.y, t5.z, t5.w}; S[6] = Q128{t6.x, t6.y, t6.z, t6.w}; S[7] = Q128{t7.x, t7.y, t7.z, t7.w};
+    }
+    // marks a switch case as its own (an empty asm statement whose text holds N): keeps the optimiser from merging cases that differ only
+    // in a register array's index into one body with a run-time index
+    template <int N> static __device__ __forceinline__ void case_tag() { asm volatile("; case %0" : : "n"(N)); }
+    // every global load of this wavefront has delivered (the loads of gload_line_keep are not tracked by the compiler)
+    static __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     static __device__ __forceinline__ Ptr sel_ptr(Bool c, Ptr a, Ptr b) { return c ? a : b; }
     // 16 bytes from an arbitrarily aligned global address (zeros where !pred)
     static __device__ __forceinline__ Q128 gload16(Ptr p, Bool pred) {
