@@ -54,6 +54,7 @@ mod ffi {
                                                  search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
         pub fn ta_thread_release();
+        pub fn ta_device_count() -> c_int;
         pub fn ta_queue_create(k: u32, costs: *const TaEditCosts, out: *mut *mut c_void) -> c_int;
         pub fn ta_queue_push(q: *mut c_void, a: *const u8, a_len: usize, b: *const u8, b_len: usize, ticket: *mut usize) -> c_int;
         pub fn ta_queue_flush(q: *mut c_void, results: *mut *const u32, n: *mut usize) -> c_int;
@@ -62,11 +63,13 @@ mod ffi {
     /// Frees what a thread holds inside the library (its stream, pinned buffers, device scratch) when the thread ends: the
     /// library itself frees nothing from a thread-exit hook.  Touched by every call through `check`.
     pub struct ThreadGuard;
-    impl Drop for ThreadGuard { fn drop(&mut self) { unsafe { ta_thread_release() } } }
+    /// `ta_thread_release` blocks on all device work of the process (hipDeviceSynchronize) and frees the thread's stream, pinned buffer and
+    /// scratch.  It is skipped when no device is reachable any more (process teardown: the HIP runtime may already be gone).
+    impl Drop for ThreadGuard { fn drop(&mut self) { unsafe { if ta_device_count() > 0 { ta_thread_release() } } } }
     thread_local! { pub static THREAD_GUARD: ThreadGuard = ThreadGuard; }
     /// status codes -> the reference's panics (src/hamming.rs:318, src/lib.rs:240, src/levenshtein.rs:44-52,69)
     pub fn check(rc: c_int) {
-        THREAD_GUARD.with(|_| ());
+        let _ = THREAD_GUARD.try_with(|_| ());      // (try_with: a call from another thread-local's destructor must not panic)
         match rc {
             0 => (),
             1 => panic!("assertion failed: a.len() == b.len()"),

@@ -169,6 +169,50 @@ static void ham_n(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_
     }
 }
 
+// ---- SWAR form (ham_swar_body.h): the per-lane function over every 16-byte-aligned lane position, as the kernel walks them
+#include "ham_swar_body.h"
+template <int NW>
+static void ham_swar_all(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint32_t delta, std::vector<Hit> &hits) {
+    uint32_t nd12[NW], tail_mask, tail_pad;
+    ham_swar_needle<NW>(needle, n, nd12, tail_mask, tail_pad);
+    const uint64_t last = h - n, end = (uint64_t)delta + h;
+    for (uint64_t byte0 = 0; byte0 < end; byte0 += 16) {
+        uint32_t w[4 + NW];
+        for (int i = 0; i < 4 + NW; i++) {                  // the kernel's loads: 16 bytes at a time, zeros when the load starts past the end
+            uint32_t v = 0;
+            const uint64_t q0 = byte0 + 16u * (uint64_t)(i >> 2);
+            if (q0 <= end)
+                for (int b = 0; b < 4; b++) {
+                    const uint64_t x = byte0 + 4u * (uint64_t)i + (uint64_t)b;
+                    // bytes in front of the haystack (x < delta) and its 16 bytes of slack: whatever memory holds -- garbage here
+                    v |= (uint32_t)((x >= delta && x < end) ? hay[x - delta] : (uint8_t)(0x5A + x)) << (8 * b);
+                }
+            w[i] = v;
+        }
+        uint32_t cnt[16];
+        ham_swar_lane<NW>(w, nd12, tail_mask, tail_pad, cnt);
+        for (uint32_t o = 0; o < 16; o++) {
+            const uint64_t x = byte0 + o;
+            if (cnt[o] > k || x < delta || x - delta > last) continue;
+            hits.push_back(Hit{x - delta, x - delta + n, cnt[o], 0u});
+        }
+    }
+}
+extern "C" int emu_ham_search_swar(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint32_t delta,
+                                   Hit *out, uint64_t cap, uint64_t *count) {
+    if (n == 0 || n > 32 || n > h || delta > 15) return 1;
+    std::vector<Hit> hits;
+    switch ((n + 3) / 4) {
+        case 1: ham_swar_all<1>(needle, n, hay, h, k, delta, hits); break; case 2: ham_swar_all<2>(needle, n, hay, h, k, delta, hits); break;
+        case 3: ham_swar_all<3>(needle, n, hay, h, k, delta, hits); break; case 4: ham_swar_all<4>(needle, n, hay, h, k, delta, hits); break;
+        case 5: ham_swar_all<5>(needle, n, hay, h, k, delta, hits); break; case 6: ham_swar_all<6>(needle, n, hay, h, k, delta, hits); break;
+        case 7: ham_swar_all<7>(needle, n, hay, h, k, delta, hits); break; default: ham_swar_all<8>(needle, n, hay, h, k, delta, hits); break;
+    }
+    *count = hits.size();
+    for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];
+    return 0;
+}
+
 extern "C" int emu_ham_search(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, int words,
                               Hit *out, uint64_t cap, uint64_t *count) {
     if (n == 0 || n > 32 || n > h || tile == 0) return 1;

@@ -34,3 +34,24 @@ def test_shift_add_small_alphabet_and_edges():
             assert E.ham_search(needle, hay, k, tile=96) == O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
     assert E.ham_search(b"abc", b"abc", 0) == [(0, 3, 0)]
     assert E.ham_search(b"abc", b"abd", 1) == [(0, 3, 1)]
+
+
+def test_swar16_equals_oracle():
+    """The SWAR form (one lane per 16 offsets, windows shifted once and shared; ham_swar_body.h): every needle length 1..32, every start
+    alignment of the haystack, k from 0 to n; NUL bytes in the needle's padding positions must not match haystack zeros."""
+    g = Dg.rng(0x4C)
+    for n in list(range(1, 33)):
+        needle = bytes(g.integers(1, 256, size=n).astype(np.uint8))
+        hay = bytearray(g.integers(0, 256, size=700).astype(np.uint8).tobytes())      # zeros included: the kernel counts, the contract check is separate
+        for pos in range(5, 650, 53):
+            m = bytearray(needle)
+            for _ in range(int(g.integers(0, 4))):
+                m[int(g.integers(0, n))] = int(g.integers(0, 256))
+            hay[pos:pos + n] = m
+        hay = bytes(hay)
+        for k in sorted({0, 1, n // 2, n}):
+            want = O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+            for delta in (0, 1, 7, 15) if n % 5 else range(16):
+                assert sorted(E.ham_search_swar(needle, hay, k, delta)) == want, (n, k, delta)
+    assert E.ham_search_swar(b"abc", b"abc", 0) == [(0, 3, 0)]
+    assert E.ham_search_swar(b"abc", b"xxabd", 1, 3) == [(2, 5, 1)]

@@ -238,6 +238,11 @@ class _LazyMatches:
     asked for (the same sequence as the eager list, element for element)."""
 
     def __init__(self, needle, haystack, k, costs, anchored):
+        # what the eager search reports at the call is reported at the call here too (not inside next()): needle length, device
+        if len(needle) > 65535:
+            _raise(_n.TA_ERR_ARG)
+        if _n.lib().ta_device_count() <= 0:
+            _raise(_n.TA_ERR_HIP)
         self._args, self._state, self._rest = (needle, haystack, k, costs, anchored), 0, None
 
     def __iter__(self):

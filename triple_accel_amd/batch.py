@@ -23,6 +23,13 @@ class Strings:
         else:
             self.n = n if n is not None else (blob.numel() - SLACK) // max(stride, 1)
 
+    def __setattr__(self, name, value):
+        # the C view is built once per batch side (_c); changing a field drops it
+        if name in ("blob", "off", "stride", "length", "max_len"):
+            self.__dict__.pop("_cview", None)
+            self.__dict__.pop("_cref", None)
+        object.__setattr__(self, name, value)
+
     @classmethod
     def from_list(cls, strings, device="cuda"):
         import numpy as np

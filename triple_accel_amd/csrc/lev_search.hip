@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "ham_search_body.h"
+#include "ham_swar_body.h"
 #include "lev_filter_body.h"
 #include "lev_search_body.h"
 #include "lev_search_wave_body.h"
@@ -540,6 +541,56 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uin
     }
 }
 
+// needles of up to 32 bytes, SWAR form (ham_swar_body.h): one lane per 16 consecutive offsets, three 16-byte loads per lane in flight
+// together, the windows of a lane shifted once and shared by its offsets.  The NUL-byte scan of the SIMD contract (src/lib.rs:237-243)
+// rides along: every haystack dword is the first of exactly one lane's four.  delta = hay & 15 (the loads are 16-byte aligned).
+template <int NW>
+__global__ __launch_bounds__(256) void hamming_search_swar16_kernel(SearchParams P, uint32_t delta, uint32_t *nul_flag) {
+    const uint64_t lane_id = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t byte0 = lane_id * 16u;                       // in the address space of hay - delta
+    const uint32_t n = P.needle_len, k = P.k;
+    const uint64_t h = P.hay_len, last = h - n, end = (uint64_t)delta + h;   // bytes [delta, end) are the haystack; 16 bytes of slack follow
+    if (byte0 >= end) return;                                   // (the lanes behind the last offset still check their bytes for NUL)
+    uint32_t nd12[NW], tail_mask, tail_pad;
+    ham_swar_needle<NW>(P.needle, n, nd12, tail_mask, tail_pad);
+    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(16)));
+    const u32x4a *src = (const u32x4a *)(P.hay - delta + byte0);
+    constexpr int NQ = (4 + NW + 3) / 4;
+    u32x4a q[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) q[t] = (byte0 + 16u * (uint64_t)t <= end) ? src[t] : u32x4a{0u, 0u, 0u, 0u};
+    uint32_t w[4 + NW];
+#pragma unroll
+    for (int i = 0; i < 4 + NW; i++) w[i] = q[i >> 2][i & 3];
+    if (nul_flag) {                                             // bytes byte0 .. byte0 + 15 are this lane's to check
+        bool z;
+        if (byte0 >= delta && byte0 + 16u <= end) {
+            z = (ham_ne12(w[0] ^ 0x0C0C0C0Cu) & ham_ne12(w[1] ^ 0x0C0C0C0Cu) & ham_ne12(w[2] ^ 0x0C0C0C0Cu) & ham_ne12(w[3] ^ 0x0C0C0C0Cu)) != 0xFFFFFFFFu;
+        } else {
+            z = false;
+            for (uint32_t b = 0; b < 16u; b++) {
+                const uint64_t x = byte0 + b;
+                if (x >= delta && x < end) z |= ((w[b >> 2] >> (8u * (b & 3u))) & 0xFFu) == 0u;
+            }
+        }
+        if (z) atomicOr(nul_flag, 1u);
+    }
+    uint32_t cnt[16];
+    ham_swar_lane<NW>(w, nd12, tail_mask, tail_pad, cnt);
+    bool any = false;
+#pragma unroll
+    for (int o = 0; o < 16; o++) any |= cnt[o] <= k;
+    if (!any) return;
+#pragma unroll 1
+    for (uint32_t o = 0; o < 16u; o++) {
+        const uint64_t x = byte0 + o;
+        if (cnt[o] > k || x < delta || x - delta > last) continue;
+        const uint64_t pos = x - delta;
+        unsigned long long idx = atomicAdd(P.count, 1ull);
+        if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt[o], 0u};
+    }
+}
+
 // needles of up to 32 bytes: shift-add scan (ham_search_body.h), one lane per tile of P.tile offsets, table in LDS,
 // haystack requested 64 bytes per lane one block ahead
 template <int NWS>
@@ -597,9 +648,24 @@ __global__ __launch_bounds__(256) void hamming_search_sa_kernel(SearchParams P) 
     }
 }
 
-hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s) {
+// nul_flag: where the kernel reports a zero byte in the haystack (nullptr: no check wanted); *nul_done = the launch did the check
+hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t *nul_flag, bool *nul_done) {
     SearchParams P = P0;
+    if (nul_done) *nul_done = false;
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
+    if (P.needle_len <= 32 && !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA")) {
+        const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 15u);
+        const uint64_t lanes = (P.hay_len + delta + 15) / 16;
+        const dim3 grid((uint32_t)((lanes + 255) / 256)), block(256);
+        if (nul_done) *nul_done = nul_flag != nullptr;
+        set_last_kernel_name("hamming_search_swar16_kernel<%u>", (P.needle_len + 3) / 4);
+        switch ((P.needle_len + 3) / 4) {
+#define TA_HS(NW) case NW: hipLaunchKernelGGL(hamming_search_swar16_kernel<NW>, grid, block, 0, s, P, delta, nul_flag); break;
+            TA_HS(1) TA_HS(2) TA_HS(3) TA_HS(4) TA_HS(5) TA_HS(6) TA_HS(7) TA_HS(8)
+#undef TA_HS
+        }
+        return hipGetLastError();
+    }
     if (P.needle_len <= 32 && !env_str("TA_HAMMING_SEARCH_SWAR")) {
         const uint64_t offsets = P.hay_len - P.needle_len + 1;
         uint64_t tile = (offsets + 262143) / 262144;              // two sets of resident lanes

@@ -316,6 +316,25 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     return TA_OK;
 }
 
+// The pairs of a ragged batch in length order (util_kernels.hip: length_order_launch) into thread-local scratch; *order_out = the list.
+// The histogram scratch must be zero on entry and every complete pass leaves it zero: `clean` says the last pass of this thread was
+// complete -- after one that failed midway the histogram is zeroed again instead of trusted.
+static int order_pairs(const ta_strings *a, const ta_strings *b, uint32_t n, uint32_t u, uint64_t max_len, bool by_steps, bool exact,
+                       hipStream_t st, const uint32_t **order_out, bool *exact_columns) {
+    static thread_local bool clean = false;
+    Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
+    constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;                    // histogram + cursors: 1024 bins x 32 counters each
+    const bool fresh = bins.cap < BINS_BYTES || !clean;
+    int rc;
+    if ((rc = ord.ensure((size_t)n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
+    if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));
+    clean = false;
+    TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, n, u, max_len, by_steps, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st, exact, exact_columns));
+    clean = true;
+    *order_out = (const uint32_t *)ord.dev;
+    return TA_OK;
+}
+
 static int batch_max_len(const ta_strings *a, const ta_strings *b, uint32_t n, hipStream_t st, uint64_t *out) {
     uint64_t ma = 0, mb = 0;
     int rc = side_max_len(a, n, st, &ma);
@@ -455,18 +474,12 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     const uint32_t *order = nullptr;
     bool exact_columns = false;
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
-        Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
-        constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;                    // histogram + cursors: 1024 bins x 32 counters each
-        const bool fresh = bins.cap < BINS_BYTES;
-        if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
-        if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));   // once: every pass leaves the histogram zeroed behind it
         const uint32_t u = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
         // the key counts what the kernel of this pass iterates over: columns (bit-parallel kernels) or anti-diagonal steps (DP band kernel)
         const bool unit = (costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1)) ||
                           lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, costs->transpose_cost);
         const bool by_steps = !unit || env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L");
-        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u, max_len, by_steps, (uint32_t *)bins.dev, (uint32_t *)ord.dev, st, env_int("TA_BITS_VLINE") != 0, &exact_columns));
-        order = (const uint32_t *)ord.dev;
+        if ((rc = order_pairs(a, b, (uint32_t)n, u, max_len, by_steps, env_int("TA_BITS_VLINE") != 0, st, &order, &exact_columns))) return rc;
     }
     return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st, exact_columns);
 }
@@ -498,10 +511,14 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     Scratch &bad = tls_scratch(15), &cnt = tls_scratch(16);
     // two counters taken in turn: this pass appends to one and zeroes the other for the next pass (no fill per call; both are
     // zeroed once, when the scratch is allocated)
+    // (`clean`: the last pass of this thread ran to its last launch -- the counter it left behind is zero.  A pass that failed midway leaves
+    // it unknown: both counters are zeroed again and the turn restarts.)
     static thread_local uint32_t turn = 0;
-    const bool fresh = cnt.cap < 64;
+    static thread_local bool clean = false;
+    const bool fresh = cnt.cap < 64 || !clean;
     if ((rc = bad.ensure(n * 4)) || (rc = cnt.ensure(64))) return rc;
     if (fresh) { TA_HIP(hipMemsetAsync(cnt.dev, 0, 64, st)); turn = 0; }
+    clean = false;
     uint32_t *counters = (uint32_t *)cnt.dev;
     const uint32_t mine = turn & 1u;
     turn++;
@@ -534,6 +551,7 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=%zu k=%u u=%u kernel=7 (small alphabet, shift %u table %08x) grid=%u lds=%u\n", n, k, u, q_shift, q_table, grid, lds);
     g_last_launch = li;
     g_answer_single_store = false;
+    clean = true;
     return TA_OK;
 }
 
@@ -567,15 +585,12 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     // ragged (CSR) batches: the rounds take their pairs in length order, as ta_levenshtein_k_batch does (the list of the still
     // unresolved pairs is compacted from the ordered one, which keeps it ordered block by block)
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
-        Scratch &ord = tls_scratch(13), &bins = tls_scratch(14);
-        constexpr size_t BINS_BYTES = 2 * 1024 * 32 * 4;
-        const bool fresh = bins.cap < BINS_BYTES;
-        if ((rc = ord.ensure(n * 4)) || (rc = bins.ensure(BINS_BYTES))) return rc;
-        if (fresh) TA_HIP(hipMemsetAsync(bins.dev, 0, BINS_BYTES / 2, st));
         const uint32_t u0 = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
-        const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1);
-        TA_HIP(length_order_launch(view_of(a), view_of(b), nullptr, (uint32_t)n, u0, max_len, !unit || env_int("TA_NO_BITS"), (uint32_t *)bins.dev, (uint32_t *)ord.dev, st));
-        sub_in = (uint32_t *)ord.dev;
+        const bool unit = (costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1)) ||
+                          lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, costs->transpose_cost);
+        const uint32_t *ordered = nullptr;
+        if ((rc = order_pairs(a, b, (uint32_t)n, u0, max_len, !unit || env_int("TA_NO_BITS"), false, st, &ordered, nullptr))) return rc;
+        sub_in = (uint32_t *)ordered;
     }
     int flip = 0;
     const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
@@ -672,12 +687,22 @@ int ta_queue_push(ta_queue *q, const uint8_t *a, size_t a_len, const uint8_t *b,
     return TA_OK;
 }
 
+// A flush that fails (an over-wide band, an allocation failure) DROPS the queued pairs: the queue is empty afterwards and accepts new
+// pairs -- a queue that kept them would fail the same way on every later flush.
+static int queue_flush_impl(ta_queue *q, const uint32_t **results, size_t n);
 int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n_out) {
     if (!q || !results || !n_out) return TA_ERR_ARG;
     const size_t n = q->off[0].size() - 1;
     *results = nullptr; *n_out = n;
     q->results.assign(n, 0);
     if (n == 0) return TA_OK;
+    const int rc = queue_flush_impl(q, results, n);
+    for (int s = 0; s < 2; s++) { q->blob[s].clear(); q->off[s].assign(1, 0); }
+    q->max_len = 0;
+    if (rc) { *n_out = 0; *results = nullptr; }
+    return rc;
+}
+static int queue_flush_impl(ta_queue *q, const uint32_t **results, size_t n) {
     auto pad = [](size_t x) { return (x + TA_BLOB_SLACK + 255) & ~(size_t)255; };
     const size_t sa = pad(q->blob[0].size()), sb = pad(q->blob[1].size()), so = pad((n + 1) * 8), sr = pad(n * 4);
     const size_t need = sa + sb + 2 * so + sr;
@@ -699,8 +724,6 @@ int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n_out) {
     if (rc) return rc;
     TA_HIP(hipMemcpyAsync(q->results.data(), dr, n * 4, hipMemcpyDeviceToHost, st));
     TA_HIP(hipStreamSynchronize(st));
-    for (int s = 0; s < 2; s++) { q->blob[s].clear(); q->off[s].assign(1, 0); }
-    q->max_len = 0;
     *results = q->results.data();
     return TA_OK;
 }

@@ -175,6 +175,6 @@ PinBox &search_report_box();
 hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
                                   SearchCtl *ctl, SearchSlot *slots /* SEARCH_SLOT_CAP of them; Best passes */, uint8_t *report_dev,
                                   hipStream_t s);
-hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s);
+hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s, uint32_t *nul_flag = nullptr, bool *nul_done = nullptr);
 
 }  // namespace ta

@@ -283,7 +283,6 @@ static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len
     int rc = cnt.ensure(16);
     if (rc) return rc;
     TA_HIP(hipMemsetAsync(cnt.dev, 0, 16, st));
-    if (check_nul) TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, (uint32_t *)((uint8_t *)cnt.dev + 8), st));   // :463
     SearchParams P;
     fill_params(P, needle_host, needle_len, haystack_dev, haystack_len, k, nullptr, 0, base, 0, hits_dev, cap,
                 (unsigned long long *)cnt.dev);
@@ -291,7 +290,11 @@ static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len
     if ((rc = nd.ensure(needle_len + 16))) return rc;
     TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
     P.needle_dev = (const uint8_t *)nd.dev;
-    TA_HIP(hamming_search_launch(P, st));
+    // the NUL-byte scan of the SIMD contract (:463) rides inside the search kernel where that kernel reads every byte anyway
+    uint32_t *nul_flag = (uint32_t *)((uint8_t *)cnt.dev + 8);
+    bool nul_done = false;
+    TA_HIP(hamming_search_launch(P, st, check_nul ? nul_flag : nullptr, &nul_done));
+    if (check_nul && !nul_done) TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, nul_flag, st));
     unsigned long long c[2] = {0, 0};
     TA_HIP(hipMemcpyAsync(c, cnt.dev, 16, hipMemcpyDeviceToHost, st));
     TA_HIP(hipStreamSynchronize(st));
@@ -519,6 +522,8 @@ int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const 
         return TA_OK;
     }
     if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;     // :1965
+    if (needle_len > 65535) { set_last_error_msg("needle longer than 65535 bytes"); return TA_ERR_ARG; }   // (before any 32-bit arithmetic on it)
+    if (!device_ready()) return TA_ERR_HIP;
     const uint32_t whole_gap = (uint32_t)needle_len * costs->gap_cost + costs->start_gap_cost;
     if (whole_gap <= k) { *out = ta_match{0, 0, whole_gap, 0}; *found = 1; return TA_OK; }     // the end == 0 match comes first (:1693-1706)
     if (haystack_len == 0) return TA_OK;
