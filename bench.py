@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "hsearch"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "hsearch"],
                     help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
                          "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel; hsearch = hamming_search of a --needle-len byte needle "
                          "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
@@ -161,13 +161,16 @@ def main():
 
     # ------------------------------------------------------------------ workload set-up
     # make(seed, lo, hi) -> (run, units, parity, extra): one rank's share of a batch
-    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s"):
+    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t"):
         n_cfg, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
                               "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM),
                               "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3)),
                               # cfg2's geometry under weighted LINEAR-gap costs: (2, 3, 0) -- the DP band kernel, no affine term -- and
                               # (2, 2, 0) = unit costs times two, which ride the bit-parallel kernel with k / 2
-                              "cfg2l": (1_000_000, 256, 32, (2, 3, 0, None)), "cfg2s": (1_000_000, 256, 32, (2, 2, 0, None))}[wl]
+                              "cfg2l": (1_000_000, 256, 32, (2, 3, 0, None)), "cfg2s": (1_000_000, 256, 32, (2, 2, 0, None)),
+                              # cfg2's geometry with trace_on = true for every pair (mutated pairs: every pair has a script):
+                              # argmin codes from the DP band kernel + the walk kernel, scripts written to HBM as ta_edit runs
+                              "cfg2t": (1_000_000, 256, 32, LEV)}[wl]
         n_cfg = args.pairs or n_cfg
         ragged = args.dist == "ragged"
         assert not ragged or wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s"), "--dist ragged is a k-bounded batch distribution"
@@ -185,14 +188,15 @@ def main():
                     "cfg2w": "levenshtein_simd_k_with_opts EditCosts(2,3,1,None) k=32, 1M 256B pairs (general costs: DP band-wavefront kernel)",
                     "cfg4w": "levenshtein_simd_k_with_opts EditCosts(2,2,1,Some(3)) k=8, 1M 128B pairs (general costs + transposition)",
                     "cfg2l": "levenshtein_simd_k_with_opts EditCosts(2,3,0,None) k=32, 1M 256B pairs (weighted linear gaps: DP band-wavefront kernel)",
-                    "cfg2s": "levenshtein_simd_k_with_opts EditCosts(2,2,0,None) k=32, 1M 256B pairs (unit costs x 2: bit-parallel kernel with k / 2)"}[wl]
+                    "cfg2s": "levenshtein_simd_k_with_opts EditCosts(2,2,0,None) k=32, 1M 256B pairs (unit costs x 2: bit-parallel kernel with k / 2)",
+                    "cfg2t": "levenshtein_simd_k_with_opts k=32 trace_on=true, 1M mutated 256B pairs: distances + edit scripts (ta_levenshtein_trace_batch)"}[wl]
             unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select); the kernel computes on 1-bit cells in u32 lanes
             # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
             #  -- about half of the credited reference band; reported beside the credited figure
             uk = min(max(min(k, L * max(costs[0], costs[1])) - costs[2], 0) // costs[1], 2 * L)
             evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
 
-        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14, "cfg2l": 22, "cfg2s": 32}[wl]
+        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14, "cfg2l": 22, "cfg2s": 32, "cfg2t": 42}[wl]
 
         def gen(seed, n):
             """-> ((blob_a, off_a), (blob_b, off_b)) as numpy CSR; fixed-length distributions also carry their (n, L) arrays"""
@@ -208,7 +212,7 @@ def main():
                     blob[:int(off[-1])] = Dg.random_bytes(g, int(off[-1]))
                     csr.append((blob, off))
                 return csr[0], csr[1], None
-            if args.dist == "random":
+            if args.dist == "random" and wl != "cfg2t":
                 a, b = Dg.pairs_random(seed, n, L)
             elif args.dist == "dna":
                 sym = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -261,7 +265,13 @@ def main():
                 cells_total, bytes_total = int(sum(memo.values())), int(la.sum() + lb.sum() + 4 * n)
                 host_blobs = [(sa.blob, ca[0]), (sb.blob, cb[0]), (sa.off, ca[1].astype(np.int64)), (sb.off, cb[1].astype(np.int64))]
             out = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
-            if wl == "cfg1":
+            if wl == "cfg2t":
+                cap = 2 * k + 1
+                ed = torch.empty((max(n, 1), cap, 2), dtype=torch.int64, device="cuda")[:n]
+                ne = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
+                run = lambda: B.levenshtein_trace_batch(sa, sb, k, costs, cap=cap, out=out, edits=ed, n_edits=ne)
+                oracle = lambda l, h, th: O.levenshtein_k_batch(*csr(l, h), k, costs, threads=th)
+            elif wl == "cfg1":
                 run = lambda: B.hamming_batch(sa, sb, out=out)
                 oracle = lambda l, h, th: O.hamming_batch(*csr(l, h), threads=th)
             elif wl == "cfg3":
@@ -279,6 +289,12 @@ def main():
                 ns = min(n, 4000 if wl != "cfg3" else 48)
                 got = out[:ns].cpu().numpy().view(np.uint32)
                 assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
+                if wl == "cfg2t":                           # the scripts, edit for edit, against the scalar traceback; their bytes
+                    scripts = B.edits_to_lists(ed[:600], ne[:600])
+                    for i in range(min(n, 600)):
+                        wd, we = O.levenshtein_simd_k_with_opts(fixed[0][lo + i].tobytes(), fixed[1][lo + i].tobytes(), k, True, costs)
+                        assert scripts[i] == (we if wd is not None else []), "parity gate failed: edit script != oracle's traceback"
+                    extra_t["runs_total"] = int(ne.to(torch.int64).sum().item())
                 return ns
 
             def end_to_end(reps=5):
@@ -296,7 +312,8 @@ def main():
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
                 return float(np.median(ts[1:]))
-            return run, n, parity, {"csr": csr, "oracle": oracle, "cells_total": cells_total, "bytes_total": bytes_total, "end_to_end": end_to_end}
+            extra_t = {"csr": csr, "oracle": oracle, "cells_total": cells_total, "bytes_total": bytes_total, "end_to_end": end_to_end}
+            return run, n, parity, extra_t
     elif wl == "hsearch":
         # hamming_search over a haystack shard resident in HBM: every offset's mismatch count against the needle, reported when <= k.
         # Algorithmic bytes: the haystack once (+ the few hit records); cells: needle_len byte comparisons per offset.
@@ -497,6 +514,8 @@ def main():
     launch_mode = {}
     run, units, parity, extra = make(strong and world > 1)
     parity_n = parity()
+    if wl == "cfg2t":      # algorithmic bytes of a traceback pass: the strings, the distance and run count per pair, the runs written (16 B each)
+        extra["bytes_total"] += 4 * units + 16 * extra["runs_total"]
     info = T.last_launch_info()
     kernel_name = T.last_kernel_name()
     elapsed, dev_ms, n_ramp = timed_region(run, args.steps, args.warmup)
@@ -604,6 +623,17 @@ def main():
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread (the scalar search is one serial scan), oracle/ta_oracle.c "
                              "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt), "host": facts}
+        elif wl == "cfg2t":
+            a_np, b_np = extra["csr"](0, min(units, 2000))
+            sample = min(units, 2000)
+            sa_l = [bytes(a_np[0][int(a_np[1][i]):int(a_np[1][i + 1])]) for i in range(sample)]
+            sb_l = [bytes(b_np[0][int(b_np[1][i]):int(b_np[1][i + 1])]) for i in range(sample)]
+            t1 = time.perf_counter()
+            for x, y in zip(sa_l, sb_l):
+                O.levenshtein_simd_k_with_opts(x, y, k, True, costs)
+            dt = time.perf_counter() - t1
+            cpu = {"value": cells_unit * sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+                   "sample": "first %d pairs, one thread, oracle/ta_oracle.c (restated scalar banded path with its traceback), %.2f s" % (sample, dt), "host": facts}
         elif wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s"):
             # Inputs staged once (CSR blobs), outside the timed loops.  Three restatements: the hand-written AVX2 one with
             # saturating u8 cells (oracle/ta_oracle_avx2.c: 64 / 32 u8 lanes per anti-diagonal for cfg2 / cfg4 -- the reference's

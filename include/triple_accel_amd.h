@@ -230,6 +230,14 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
  * subset (src/levenshtein.rs:1480-1494).  Synchronises the stream between rounds. */
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
                              const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
+/* Batch form of ta_levenshtein_trace (no reference analogue: the reference's trace_on is per call, src/levenshtein.rs:714-720, :561-606):
+ * out_dev[i] = distance | TA_NONE, n_edits_dev[i] = runs of pair i's script (0 for None), edits_dev[i * cap .. i * cap + n_edits_dev[i]) =
+ * the script front to back -- edit for edit the reference's Vec<Edit>.  All buffers are device memory; the call enqueues kernels on
+ * `stream` and returns (no synchronisation).  2 k + 1 records per pair always suffice; a longer script is cut at `cap` records and
+ * n_edits_dev[i] says how many it has.  TA_ERR_UNSUPPORTED for bands beyond the register kernel (> 4222 diagonals). */
+int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                               uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, void *stream);
+
 /* N x hamming(a_i, b_i); out[i] = TA_NONE where the lengths differ (Rust: panic). */
 int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out_dev, void *stream);
 

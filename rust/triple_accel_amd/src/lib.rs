@@ -53,6 +53,8 @@ mod ffi {
         pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                  search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
+        pub fn ta_levenshtein_trace_batch(a: *const TaStrings, b: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
+                                          out_dev: *mut u32, edits_dev: *mut c_void, n_edits_dev: *mut u32, cap: usize, stream: *mut c_void) -> c_int;
         pub fn ta_thread_release();
         pub fn ta_device_count() -> c_int;
         pub fn ta_queue_create(k: u32, costs: *const TaEditCosts, out: *mut *mut c_void) -> c_int;

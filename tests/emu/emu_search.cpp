@@ -193,20 +193,25 @@ static void ham_swar_all(const uint8_t *needle, uint32_t n, const uint8_t *hay, 
         ham_swar_lane<NW>(w, nd12, tail_mask, tail_pad, cnt);
         for (uint32_t o = 0; o < 16; o++) {
             const uint64_t x = byte0 + o;
-            if (cnt[o] > k || x < delta || x - delta > last) continue;
-            hits.push_back(Hit{x - delta, x - delta + n, cnt[o], 0u});
+            if ((cnt[o] >> 3) > k || x < delta || x - delta > last) continue;
+            hits.push_back(Hit{x - delta, x - delta + n, cnt[o] >> 3, 0u});
         }
     }
 }
 extern "C" int emu_ham_search_swar(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint32_t delta,
                                    Hit *out, uint64_t cap, uint64_t *count) {
-    if (n == 0 || n > 32 || n > h || delta > 15) return 1;
+    if (n == 0 || n > 64 || n > h || delta > 15) return 1;
     std::vector<Hit> hits;
     switch ((n + 3) / 4) {
+        case 9: ham_swar_all<9>(needle, n, hay, h, k, delta, hits); break; case 10: ham_swar_all<10>(needle, n, hay, h, k, delta, hits); break;
+        case 11: ham_swar_all<11>(needle, n, hay, h, k, delta, hits); break; case 12: ham_swar_all<12>(needle, n, hay, h, k, delta, hits); break;
+        case 13: ham_swar_all<13>(needle, n, hay, h, k, delta, hits); break; case 14: ham_swar_all<14>(needle, n, hay, h, k, delta, hits); break;
+        case 15: ham_swar_all<15>(needle, n, hay, h, k, delta, hits); break; case 16: ham_swar_all<16>(needle, n, hay, h, k, delta, hits); break;
         case 1: ham_swar_all<1>(needle, n, hay, h, k, delta, hits); break; case 2: ham_swar_all<2>(needle, n, hay, h, k, delta, hits); break;
         case 3: ham_swar_all<3>(needle, n, hay, h, k, delta, hits); break; case 4: ham_swar_all<4>(needle, n, hay, h, k, delta, hits); break;
         case 5: ham_swar_all<5>(needle, n, hay, h, k, delta, hits); break; case 6: ham_swar_all<6>(needle, n, hay, h, k, delta, hits); break;
-        case 7: ham_swar_all<7>(needle, n, hay, h, k, delta, hits); break; default: ham_swar_all<8>(needle, n, hay, h, k, delta, hits); break;
+        case 7: ham_swar_all<7>(needle, n, hay, h, k, delta, hits); break; case 8: ham_swar_all<8>(needle, n, hay, h, k, delta, hits); break;
+        default: return 1;
     }
     *count = hits.size();
     for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];

@@ -37,10 +37,10 @@ def test_shift_add_small_alphabet_and_edges():
 
 
 def test_swar16_equals_oracle():
-    """The SWAR form (one lane per 16 offsets, windows shifted once and shared; ham_swar_body.h): every needle length 1..32, every start
+    """The SWAR form (one lane per 16 offsets, windows shifted once and shared; ham_swar_body.h): every needle length 1..32 and some up to 64, every start
     alignment of the haystack, k from 0 to n; NUL bytes in the needle's padding positions must not match haystack zeros."""
     g = Dg.rng(0x4C)
-    for n in list(range(1, 33)):
+    for n in list(range(1, 33)) + [33, 40, 47, 48, 49, 63, 64]:
         needle = bytes(g.integers(1, 256, size=n).astype(np.uint8))
         hay = bytearray(g.integers(0, 256, size=700).astype(np.uint8).tobytes())      # zeros included: the kernel counts, the contract check is separate
         for pos in range(5, 650, 53):

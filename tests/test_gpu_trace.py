@@ -82,3 +82,56 @@ def test_trace_beyond_the_register_band():
             want = O.levenshtein_simd_k_with_opts(x, y, 0xFFFFFFFF, True, costs)
             assert prod(x, y, 0xFFFFFFFF, costs) == want, costs
     assert prod(s1, s2, 0xFFFFFFFF, (2, 2, 0, 2)) == O.levenshtein_simd_k_with_opts(s1, s2, 0xFFFFFFFF, True, (2, 2, 0, 2))
+
+
+@pytest.mark.parametrize("costs,k", [((1, 1, 0, None), 32), ((1, 1, 0, 1), 12), ((2, 3, 1, None), 40), ((2, 2, 1, 3), 20), ((3, 1, 0, None), 25)])
+def test_trace_batch_equals_scalar(costs, k):
+    """ta_levenshtein_trace_batch: distances and edit scripts of a whole ragged batch from the device (argmin codes + the walk kernel),
+    edit for edit the oracle's scalar traceback -- near pairs, unrelated pairs (None), swapped roles (a longer than b), empty strings,
+    small alphabets (ties); n_edits = 0 exactly where the distance is None."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(41 + k)
+    a, b = [], []
+    for i in range(3000):
+        t = i % 6
+        if t == 5:
+            x = g.integers(97, 99, size=int(g.integers(0, 30)), dtype=np.uint8).tobytes()
+            y = g.integers(97, 99, size=int(g.integers(0, 30)), dtype=np.uint8).tobytes()
+        else:
+            x = Dg.rand_str(g, int(g.integers(0, 200)))
+            y = Dg.rand_str(g, int(g.integers(0, 200))) if t == 0 else Dg.mutate(g, x, 9, costs[3] is not None)
+            if t == 1:
+                x, y = y, x
+        a.append(x); b.append(y)
+    out, edits, ne = B.levenshtein_trace_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs)
+    got_d = out.cpu().numpy().view(np.uint32)
+    got_e = B.edits_to_lists(edits, ne)
+    n_some = 0
+    for i in range(len(a)):
+        wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+        if wd is None:
+            assert got_d[i] == 0xFFFFFFFF and got_e[i] == [], i
+        else:
+            n_some += 1
+            assert got_d[i] == wd and got_e[i] == we, (i, a[i], b[i], got_e[i], we)
+    assert n_some > 1000
+
+
+def test_trace_batch_fixed_length_cfg2_shape_and_cap():
+    """cfg2's geometry (256-byte strings, k = 32, mutated pairs), a fixed-length batch large enough for several chunks of records is not
+    needed here -- 20,000 pairs; plus the cap: a script longer than `cap` runs is cut and n_edits says how long it is."""
+    from triple_accel_amd import batch as B
+    am, bm = Dg.pairs_mutated_fixed(0x7AA2, 20_000, 256, 24)
+    out, edits, ne = B.levenshtein_trace_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), 32)
+    d = out.cpu().numpy().view(np.uint32)
+    want_d = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), 32)
+    assert np.array_equal(d, want_d)
+    got = B.edits_to_lists(edits, ne)
+    for i in range(0, 20_000, 97):
+        wd, we = O.levenshtein_simd_k_with_opts(am[i].tobytes(), bm[i].tobytes(), 32, True)
+        assert (got[i] == we) if wd is not None else (got[i] == []), i
+    out2, edits2, ne2 = B.levenshtein_trace_batch(B.Strings.from_fixed(am[:500]), B.Strings.from_fixed(bm[:500]), 32, cap=3)
+    assert np.array_equal(ne2.cpu().numpy(), ne[:500].cpu().numpy())
+    got2 = B.edits_to_lists(edits2, ne2)
+    for i in range(500):
+        assert got2[i] == got[i][:3], i

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
     "ta_hamming_search", "ta_hamming_search_naive_with_opts", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
-    "ta_levenshtein_search_best_dev",
+    "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
     sig("ta_levenshtein_k_batch", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_k_batch_alphabet", i32, [sp, sp, sz, u32, cp, u8p, sz, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_exp_batch", i32, [sp, sp, sz, cp, C.c_void_p, C.c_void_p])
+    sig("ta_levenshtein_trace_batch", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p])
     sig("ta_hamming_batch", i32, [sp, sp, sz, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_search_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, i32, C.c_uint64, C.c_uint64,
                                            C.c_void_p, sz, C.POINTER(C.c_uint64), C.c_void_p])

@@ -106,6 +106,34 @@ def levenshtein_exp_batch(a: Strings, b: Strings, costs=LEVENSHTEIN_COSTS, out=N
     return out
 
 
+_EDIT_NAMES = ("Match", "Mismatch", "AGap", "BGap", "Transpose")
+
+
+def levenshtein_trace_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, cap=None, out=None, edits=None, n_edits=None):
+    """levenshtein_simd_k_with_opts(a_i, b_i, k, trace_on=True, costs) for every pair, on the device: -> (out, edits, n_edits) with
+    out[i] = distance (int32, -1 == None), n_edits[i] = runs of pair i's script, edits[i, t] = (edit type, count) of run t (int64 pairs;
+    edit types as triple_accel_amd.EditType).  cap = runs kept per pair (default 2 k + 1: every script of cost <= k fits)."""
+    assert a.n == b.n
+    n, dev = a.n, a.blob.device
+    if cap is None:
+        cap = min(2 * int(k) + 1, 2 * max(a.max_len or a.length, b.max_len or b.length, 1) + 1)
+    out = _out(n, dev) if out is None else out
+    edits = torch.empty((n, cap, 2), dtype=torch.int64, device=dev) if edits is None else edits
+    n_edits = torch.empty(n, dtype=torch.int32, device=dev) if n_edits is None else n_edits
+    cc = _costs(costs)._c()
+    rc = _n.lib().ta_levenshtein_trace_batch(a._ref(), b._ref(), n, k, _C.byref(cc), out.data_ptr(), edits.data_ptr(), n_edits.data_ptr(),
+                                              cap, _stream())
+    if rc:
+        _raise(rc)
+    return out, edits, n_edits
+
+
+def edits_to_lists(edits, n_edits):
+    """the device result of levenshtein_trace_batch as Python lists [(name, count), ...] per pair (host copy)"""
+    e, ne = edits.cpu().numpy(), n_edits.cpu().numpy()
+    return [[(_EDIT_NAMES[int(e[i, t, 0]) & 0xFFFFFFFF], int(e[i, t, 1])) for t in range(min(int(ne[i]), e.shape[1]))] for i in range(len(ne))]
+
+
 def hamming_batch(a: Strings, b: Strings, out=None):
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out

@@ -1,4 +1,4 @@
-// ham_swar_body.h -- hamming_search for needles of up to 32 bytes, SWAR form: one lane owns 16 consecutive haystack offsets.
+// ham_swar_body.h -- hamming_search for needles of up to 64 bytes, SWAR form: one lane owns 16 consecutive haystack offsets.
 //
 // Contract (src/hamming.rs:454-554, scalar text :89-145): for every offset p in [0, h - n] the number of mismatching bytes between
 // needle and haystack[p .. p+n); reported when <= k.
@@ -42,7 +42,7 @@ TA_HD inline uint32_t ham_popc(uint32_t x) {
 }
 
 // w: the aligned dwords of haystack bytes [B, B + 16 + 4 NW); nd12[j] = needle dword j ^ 0x0C0C0C0C, the bytes past the needle's end in the
-// last dword forced to 12 by tail_mask / tail_pad (they compare equal).  cnt[4 g + r] = mismatches of the window at byte B + 4 g + r.
+// last dword forced to 12 by tail_mask / tail_pad (they compare equal).  cnt[4 g + r] = EIGHT TIMES the mismatches of the window at byte B + 4 g + r.
 template <int NW>
 TA_HD inline void ham_swar_lane(const uint32_t (&w)[4 + NW], const uint32_t (&nd12)[NW], uint32_t tail_mask, uint32_t tail_pad,
                                 uint32_t (&cnt)[16]) {
@@ -68,8 +68,7 @@ TA_HD inline void ham_swar_lane(const uint32_t (&w)[4 + NW], const uint32_t (&nd
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < 16; q++) cnt[q] >>= 3;
+    // (cnt[q] = 8 x the mismatches: the caller compares against 8 k + 7 and shifts only what it reports)
 }
 
 // the needle as the lane wants it

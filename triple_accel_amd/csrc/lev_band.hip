@@ -55,7 +55,8 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
     }
 }
 
-// Trace kernels (single-pair traceback, trace_on = true): D = 16 (bands up to 1024 diagonals) or D = 66.
+// Trace kernels (trace_on = true): D = 16 (bands up to 1024 diagonals), 34 (batches: a band of up to 34 diagonals in ONE lane, 64 pairs per
+// wavefront) or 66.
 template <int D, bool AFFINE, int TRANS>
 __global__ __launch_bounds__(64) void lev_band_trace_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -72,9 +73,115 @@ hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool aff
     else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 2>), g, b, lds, s, P); \
            else hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 0>), g, b, lds, s, P); }
     if (pl.D == 16) { TA_T(16) }
+    else if (pl.D == 34) { TA_T(34) }
     else if (pl.D == 66) { TA_T(66) }
     else return hipErrorInvalidValue;
 #undef TA_T
+    return hipGetLastError();
+}
+
+// ---- batch tracebacks: the walk on the device (src/levenshtein.rs:561-606).  One wavefront per wavefront of the trace kernel: its lanes
+// are that wavefront's pairs (PW of them), and ALL its lanes stream the wavefront's records -- one contiguous region, walked from the
+// last anti-diagonal down -- through LDS, a window of WIN iterations (both phases, 64 lanes) at a time: a step of the walk is then an
+// LDS read (the first version followed the codes through HBM, one dependent load per step: 18 ms per million 256-byte pairs against
+// 3.6 for the kernel that computes them).  Phase A: every lane follows the 2-bit argmin codes of its pair from (n, m) back to (0, 0) and
+// packs the codes it takes, sixteen per word, into `path` (scratch).  Phase B: the same lane replays its path FORWARD from (0, 0) --
+// reading the two strings front to back to tell Match from Mismatch -- and writes the runs as it closes them: ta_edit records {edit, count},
+// the reference's Vec<Edit> in its final order, into the pair's slot of `cap` records.  n_edits[pair] = the runs of the script (0 for
+// None); a script longer than `cap` is cut (the caller sees n_edits > cap).
+__global__ __launch_bounds__(64) void lev_trace_walk_kernel(StrView a, StrView b, const uint32_t *dist, const uint32_t *trace, uint64_t wave_words,
+                                                            uint32_t D, uint32_t L, uint32_t PW, uint32_t tw, uint32_t u, uint32_t pair_base,
+                                                            uint32_t n_chunk, uint32_t win, ta_edit *edits, uint32_t *n_edits, uint64_t cap,
+                                                            uint32_t *path, uint32_t path_words) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t rows[];     // win iterations x 2 phases x 64 lanes x tw words
+    const uint32_t lane = threadIdx.x, idx = blockIdx.x * PW + lane;
+    const bool mine = lane < PW && idx < n_chunk;
+    const uint32_t pair = pair_base + (mine ? idx : 0u);
+    const uint8_t *x = a.blob, *y = b.blob;
+    uint64_t n = 0, m = 0;
+    bool some = false;
+    if (mine) {
+        if (a.off) { x = a.blob + a.off[pair]; n = a.off[pair + 1] - a.off[pair]; } else { x = a.blob + (uint64_t)pair * a.stride; n = a.len; }
+        if (b.off) { y = b.blob + b.off[pair]; m = b.off[pair + 1] - b.off[pair]; } else { y = b.blob + (uint64_t)pair * b.stride; m = b.len; }
+        some = dist[pair] != 0xFFFFFFFFu;
+        if (!some) n_edits[pair] = 0;
+    }
+    const bool swap = n > m;                                   // the kernel ran the shorter string along the rows (:386-390)
+    if (swap) { const uint8_t *t = x; x = y; y = t; const uint64_t tl = n; n = m; m = tl; }
+    const uint64_t dlen = m - n, tb = dlen <= u ? (u - dlen) >> 1 : 0;            // lev_pair_offset (lev_plan.h) with n <= m
+    const uint32_t o_pair = (uint32_t)tb | 1u;
+    const uint32_t *tr = trace + (uint64_t)blockIdx.x * wave_words;
+    const uint32_t lane0 = lane * L;
+    uint32_t *my_path = path + (uint64_t)(mine ? idx : 0u) * path_words;
+    // ---- phase A: backwards through the records, window by window
+    uint32_t i = some ? (uint32_t)n : 0u, j = some ? (uint32_t)m : 0u, steps = 0, acc = 0;
+    uint32_t top = (i + j) ? (i + j - 1u) >> 1 : 0u;
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)top, off, 64); top = o2 > top ? o2 : top; }
+    const uint32_t row_words = 2u * 64u * tw;
+    for (int64_t hi = (int64_t)top; hi >= 0; hi -= (int64_t)win) {
+        const uint32_t lo = hi + 1 >= (int64_t)win ? (uint32_t)(hi + 1 - (int64_t)win) : 0u;
+        const uint32_t nwords = ((uint32_t)hi - lo + 1u) * row_words;                 // a multiple of 128
+        __syncthreads();
+        {
+            typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(16)));
+            const u32x4a *src = (const u32x4a *)(tr + (uint64_t)lo * row_words);
+            u32x4a *dst = (u32x4a *)rows;
+            for (uint32_t q = lane; q < nwords / 4u; q += 64u) dst[q] = src[q];
+        }
+        __syncthreads();
+        while (i + j > 0u) {
+            const uint32_t s = i + j, tau = (s - 1u) >> 1;
+            if (tau < lo) break;
+            const uint32_t p = j + o_pair - i, g = p / D, q = p % D, par = q & 1u, c = q >> 1;
+            const uint32_t word = rows[(((tau - lo) * 2u + par) * 64u + lane0 + g) * tw + ((2u * c) >> 5)];
+            const uint32_t code = (word >> ((2u * c) & 31u)) & 3u;
+            if (code == 0u) { i--; j--; } else if (code == 1u) { j--; } else if (code == 2u) { i--; } else { i -= 2u; j -= 2u; }
+            acc |= code << (2u * (steps & 15u));
+            if ((steps & 15u) == 15u) { my_path[steps >> 4] = acc; acc = 0; }
+            steps++;
+        }
+        if (lo == 0u) break;
+    }
+    if (!some) return;
+    if (steps & 15u) my_path[steps >> 4] = acc;
+    // ---- phase B: the path forwards, runs written as they close
+    ta_edit *slot = edits + (uint64_t)pair * cap;
+    uint32_t runs = 0, cur = 0xFFFFFFFFu, fi = 0, fj = 0, wcache = 0;
+    uint64_t cnt = 0;
+    // the strings eight bytes at a time (the blobs carry 16 bytes of slack): a load per eight steps instead of two per step
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    uint64_t xc = 0, yc = 0;
+    uint32_t xb = 0xFFFFFFFFu, yb = 0xFFFFFFFFu;                 // which 8-byte group the caches hold
+    for (uint32_t t = steps; t-- > 0u;) {
+        if ((t & 15u) == 15u || t == steps - 1u) wcache = my_path[t >> 4];
+        const uint32_t code = (wcache >> (2u * (t & 15u))) & 3u;
+        uint32_t e;
+        if (code == 0u) {
+            if ((fi >> 3) != xb) { xb = fi >> 3; xc = *(const u64u *)(x + 8u * (uint64_t)xb); }
+            if ((fj >> 3) != yb) { yb = fj >> 3; yc = *(const u64u *)(y + 8u * (uint64_t)yb); }
+            e = (((xc >> (8u * (fi & 7u))) ^ (yc >> (8u * (fj & 7u)))) & 0xFFu) == 0u ? TA_EDIT_MATCH : TA_EDIT_MISMATCH; fi++; fj++;
+        }
+        else if (code == 1u) { e = swap ? TA_EDIT_BGAP : TA_EDIT_AGAP; fj++; }
+        else if (code == 2u) { e = swap ? TA_EDIT_AGAP : TA_EDIT_BGAP; fi++; }
+        else { e = TA_EDIT_TRANSPOSE; fi += 2u; fj += 2u; }
+        if (e == cur) { cnt++; continue; }
+        if (cur != 0xFFFFFFFFu) { if (runs < cap) slot[runs] = ta_edit{cur, 0u, cnt}; runs++; }
+        cur = e; cnt = 1;
+    }
+    if (cur != 0xFFFFFFFFu) { if (runs < cap) slot[runs] = ta_edit{cur, 0u, cnt}; runs++; }
+    n_edits[pair] = runs;
+}
+
+// a chunk of a batch: pairs [pair_base, pair_base + n_chunk) through the trace kernel (records into `trace`), then the walk
+hipError_t lev_band_trace_batch_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, ta_edit *edits, uint32_t *n_edits,
+                                       uint64_t cap, uint32_t *path, uint32_t path_words, hipStream_t s) {
+    if (P.n == 0) return hipSuccess;
+    hipError_t e = lev_band_trace_launch(P, pl, affine, trans, s);
+    if (e != hipSuccess) return e;
+    const uint32_t tw = (uint32_t)lev_trace_words(pl.D), waves = (P.n + pl.PW - 1) / pl.PW;
+    const uint32_t win = tw >= 4u ? 4u : 16u / tw;                     // <= 8 KB of rows per wavefront: twenty of them per CU
+    hipLaunchKernelGGL(lev_trace_walk_kernel, dim3(waves), dim3(64), (size_t)win * 2u * 64u * tw * 4u, s, P.a, P.b, P.out, P.trace, P.trace_wave_words,
+                       (uint32_t)pl.D, pl.L, pl.PW, tw, pl.u, P.pair_base, P.n, win, edits, n_edits, cap, path, path_words);
     return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ struct LevParams {
     uint64_t trace_cols = 0;  // lev_widebits TRACE: columns per stripe in P.trace (>= b_len + 64)
     uint32_t *trace;          // TRACE kernels: 2-bit argmin codes, word w of (iteration tau, phase, lane) at
                               // ((tau*2 + phase)*64 + lane)*LEV_TRACE_WORDS(D) + w, cell c in bits [2c, 2c+2)
+    uint64_t trace_wave_words = 0;   // TRACE kernels on a batch: wavefront w's records start at trace + w * trace_wave_words
+    uint32_t pair_base = 0;          // TRACE kernels on a batch: the launch's first pair (batches go in chunks that bound the records)
 };
 
 constexpr int lev_trace_words(int D) { return (D + 31) / 32; }   // 2 bits x D/2 cells per phase
@@ -311,7 +313,9 @@ struct LevBand {
         }
     }
 
-    static TA_HD inline void run(const LevParams &P, uint32_t wave_index, uint8_t *lds) {
+    static TA_HD inline void run(const LevParams &P0, uint32_t wave_index, uint8_t *lds) {
+        LevParams P = P0;
+        if (TRACE) P.trace = P0.trace + (uint64_t)wave_index * P0.trace_wave_words;     // this wavefront's records
         const U32 INF = W::splat(SCORE ? LEV_NEG : LEV_INF);
         const U32 lane = W::lane();
         const uint32_t L = P.L;
@@ -320,13 +324,21 @@ struct LevBand {
         const Bool active = grp < P.PW;
         const U32 slot_idx = grp + wave_index * P.PW;
         const Bool valid = active & (slot_idx < P.n);
-        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, valid, 0u) : slot_idx;
+        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, valid, 0u) : (TRACE ? slot_idx + P.pair_base : slot_idx);
         const Bool is_g0 = (g == 0u), is_gl = (g == L - 1);
 
         Ptr aptr, bptr;
         U32 alen, blen;
         W::load_str(P.a, pair, valid, aptr, alen);
         W::load_str(P.b, pair, valid, bptr, blen);
+        if (TRACE) {
+            // the reference walks its matrix with the SHORTER string along the rows (src/levenshtein.rs:386-390): the argmin codes --
+            // and with them the tie order of the script -- are those of that orientation (the walk relabels the gaps)
+            const Bool sw = alen > blen;
+            const Ptr pa = W::sel_ptr(sw, bptr, aptr), pb = W::sel_ptr(sw, aptr, bptr);
+            const U32 la = W::sel(sw, blen, alen), lb = W::sel(sw, alen, blen);
+            aptr = pa; bptr = pb; alen = la; blen = lb;
+        }
 
         // the pair's band (lev_plan.h): diagonals [min(0,delta) - t, max(0,delta) + t], slot p = d + o, o odd
         const U32 s_ans = alen + blen;

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void hamming_search_kernel(SearchParams P, uin
     }
 }
 
-// needles of up to 32 bytes, SWAR form (ham_swar_body.h): one lane per 16 consecutive offsets, three 16-byte loads per lane in flight
+// needles of up to 64 bytes, SWAR form (ham_swar_body.h): one lane per 16 consecutive offsets, three 16-byte loads per lane in flight
 // together, the windows of a lane shifted once and shared by its offsets.  The NUL-byte scan of the SIMD contract (src/lib.rs:237-243)
 // rides along: every haystack dword is the first of exactly one lane's four.  delta = hay & 15 (the loads are 16-byte aligned).
 template <int NW>
@@ -577,17 +577,19 @@ __global__ __launch_bounds__(256) void hamming_search_swar16_kernel(SearchParams
     }
     uint32_t cnt[16];
     ham_swar_lane<NW>(w, nd12, tail_mask, tail_pad, cnt);
-    bool any = false;
-#pragma unroll
-    for (int o = 0; o < 16; o++) any |= cnt[o] <= k;
-    if (!any) return;
+    // the counts are 8 x the mismatches: one minimum over the sixteen (v_min3) against 8 k + 7 decides whether the lane reports at all
+    const uint32_t thr = k >= 0x1FFFFFFFu ? 0xFFFFFFFFu : 8u * k + 7u;
+    auto min3 = [](uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; };
+    const uint32_t m0 = min3(cnt[0], cnt[1], cnt[2]), m1 = min3(cnt[3], cnt[4], cnt[5]), m2 = min3(cnt[6], cnt[7], cnt[8]),
+                   m3 = min3(cnt[9], cnt[10], cnt[11]), m4 = min3(cnt[12], cnt[13], cnt[14]);
+    if (min3(min3(m0, m1, m2), min3(m3, m4, cnt[15]), 0xFFFFFFFFu) > thr) return;
 #pragma unroll 1
     for (uint32_t o = 0; o < 16u; o++) {
         const uint64_t x = byte0 + o;
-        if (cnt[o] > k || x < delta || x - delta > last) continue;
+        if (cnt[o] > thr || x < delta || x - delta > last) continue;
         const uint64_t pos = x - delta;
         unsigned long long idx = atomicAdd(P.count, 1ull);
-        if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt[o], 0u};
+        if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt[o] >> 3, 0u};
     }
 }
 
@@ -653,7 +655,7 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     SearchParams P = P0;
     if (nul_done) *nul_done = false;
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
-    if (P.needle_len <= 32 && !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA")) {
+    if (P.needle_len <= 64 && !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA")) {
         const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 15u);
         const uint64_t lanes = (P.hay_len + delta + 15) / 16;
         const dim3 grid((uint32_t)((lanes + 255) / 256)), block(256);
@@ -662,6 +664,7 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
         switch ((P.needle_len + 3) / 4) {
 #define TA_HS(NW) case NW: hipLaunchKernelGGL(hamming_search_swar16_kernel<NW>, grid, block, 0, s, P, delta, nul_flag); break;
             TA_HS(1) TA_HS(2) TA_HS(3) TA_HS(4) TA_HS(5) TA_HS(6) TA_HS(7) TA_HS(8)
+            TA_HS(9) TA_HS(10) TA_HS(11) TA_HS(12) TA_HS(13) TA_HS(14) TA_HS(15) TA_HS(16)
 #undef TA_HS
         }
         return hipGetLastError();

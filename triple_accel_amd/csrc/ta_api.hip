@@ -1032,6 +1032,71 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
     return TA_OK;
 }
 
+/* levenshtein_simd_k_with_opts(a_i, b_i, k, trace_on = true, costs) for a whole batch, everything on the device: out_dev[i] = the distance or
+ * TA_NONE, n_edits_dev[i] = the runs of pair i's script (0 for None), edits_dev[i * cap ..] = the script, front to back, as ta_edit records --
+ * edit for edit what the reference returns (its tie order, its swap of the shorter string onto the rows, its gap relabelling).  Nothing
+ * comes back to the host and nothing synchronises: the DP band kernel stores 2-bit argmin codes (the records: scratch, bounded by
+ * working through the batch in chunks), a second kernel walks them, one lane per pair.  A script of more than `cap` runs is cut
+ * (n_edits_dev[i] > cap says so); 2 k + 1 runs always hold a script of cost <= k.  Bands beyond the register kernel (more than 4222
+ * diagonals) are TA_ERR_UNSUPPORTED here -- ta_levenshtein_trace serves those pairs one by one. */
+int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                               uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, void *stream) {
+    int rc = check_batch_args(a, b, n, out_dev);
+    if (rc) return rc;
+    if (n && (!edits_dev || !n_edits_dev || cap == 0)) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
+    if (!device_ready()) return TA_ERR_HIP;
+    if (n == 0) return TA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    StreamGuard guard(st);
+    uint64_t max_len = 0;
+    if ((rc = batch_max_len(a, b, (uint32_t)n, st, &max_len))) return rc;
+    const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
+    // the trace kernels exist for 16, 34 and 66 diagonals per lane: the cheapest layout per pair that holds the band
+    LevPlan pl = {};
+    pl.ok = false;
+    double best = 1e300;
+    for (int D : {34, 16, 66}) {
+        const LevPlan c = lev_make_plan(k, costs->mismatch_cost, gc, sg, max_len, D, 0);
+        const double cost = c.ok ? (5.0 * c.D + 24.0) / c.PW * (c.D > 40 ? 1.25 : 1.0) : 1e300;
+        if (c.ok && cost < best) { best = cost; pl = c; }
+    }
+    if (!pl.ok) { set_last_error_msg("batch traceback: band wider than the register kernel (4222 diagonals)"); return TA_ERR_UNSUPPORTED; }
+    const uint32_t tw = (uint32_t)lev_trace_words(pl.D);
+    const uint64_t taus = (2 * max_len + 1) / 2 + 1;
+    const uint64_t wave_words = taus * 2 * 64 * tw;
+    // the records of one chunk: at most ~4 GiB (or one wavefront's, if that is more)
+    uint64_t waves_per_chunk = ((4ull << 30) / 4) / wave_words;
+    if (waves_per_chunk == 0) waves_per_chunk = 1;
+    const uint64_t waves_all = (n + pl.PW - 1) / pl.PW;
+    if (waves_per_chunk > waves_all) waves_per_chunk = waves_all;
+    if (wave_words * waves_per_chunk * 4 > (48ull << 30)) { set_last_error_msg("batch traceback: more than 48 GB of records for one wavefront"); return TA_ERR_UNSUPPORTED; }
+    Scratch &ts = tls_scratch(6), &ps = tls_scratch(9);
+    const uint32_t path_words = (uint32_t)((2 * max_len) / 16 + 2);                  // 2-bit codes of a pair's path, sixteen per word
+    if ((rc = ts.ensure((size_t)(wave_words * waves_per_chunk * 4))) || (rc = ps.ensure((size_t)(waves_per_chunk * pl.PW) * path_words * 4))) return rc;
+    LevParams P;
+    P.a = view_of(a); P.b = view_of(b);
+    P.subset = nullptr; P.out = out_dev; P.k = k;
+    P.mc = costs->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = costs->has_transpose ? costs->transpose_cost : 0;
+    P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;
+    P.trace = (uint32_t *)ts.dev; P.trace_wave_words = wave_words;
+    const uint64_t pairs_per_chunk = waves_per_chunk * pl.PW;
+    for (uint64_t lo = 0; lo < n; lo += pairs_per_chunk) {
+        P.pair_base = (uint32_t)lo;
+        P.n = (uint32_t)((n - lo) < pairs_per_chunk ? (n - lo) : pairs_per_chunk);
+        TA_HIP(lev_band_trace_batch_launch(P, pl, sg > 0, costs->has_transpose != 0, edits_dev, n_edits_dev, cap, (uint32_t *)ps.dev, path_words, st));
+    }
+    ta_launch_info li = {};
+    li.kernel = 1; li.diags_per_lane = pl.D; li.lanes_per_pair = pl.L; li.pairs_per_wave = pl.PW; li.band_offset = pl.o;
+    li.affine = sg > 0; li.transpose = costs->has_transpose != 0; li.grid = (uint32_t)waves_per_chunk; li.lds_bytes = pl.lds_per_wave;
+    ta_lev_select sel;
+    ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
+    li.cell_bits = sel.cell_bits;
+    g_last_launch = li;
+    set_last_kernel_name("lev_band_trace_kernel<%d, %s, %d>", pl.D, sg > 0 ? "true" : "false", costs->has_transpose ? 2 : 0);
+    return TA_OK;
+}
+
 /* levenshtein_exp_with_opts(..., trace_on = true), src/levenshtein.rs:1480-1494 */
 int ta_levenshtein_exp_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                              const ta_edit_costs *costs, uint32_t *out, ta_edit **edits, size_t *n_edits) {

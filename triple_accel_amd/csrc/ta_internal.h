@@ -74,6 +74,10 @@ bool device_ready();
 hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, int trans, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s);
+// batch tracebacks (lev_band.hip): trace kernel over the pairs [P.pair_base, P.pair_base + P.n), then the device-side walk
+// (path: n x path_words u32 of scratch, path_words >= (a_len + b_len) / 16 + 1 for every pair)
+hipError_t lev_band_trace_batch_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, ta_edit *edits, uint32_t *n_edits,
+                                       uint64_t cap, uint32_t *path, uint32_t path_words, hipStream_t s);
 hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, uint64_t max_len, hipStream_t s,
                            uint32_t *grid_out, uint32_t *lds_out);
 // the VLINE fetch form (lev_bits_vline.hip): CSR batches through the stride-8 window
