@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (default at N = 1 when rocprofv3 is on the box: two short counter passes of "
+                         "the same workload -- L2 fabric-side read requests, WRITE_SIZE -- after the timed region; without them the line replays "
+                         "the committed counter pass of profiles/<round>/ and says so)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue the K timed passes one by one; default: captured once into ONE hipGraph (where the pass is a pure kernel "
                          "launch: the fixed-length pair batches) and replayed inside the barrier-to-barrier region -- the same K passes, "
@@ -562,7 +566,28 @@ def main():
         print("bench.py: profiles/%s counter pass was recorded for %r, this run launched %r: not spliced"
               % (PROFILE_ROUND, pmc.get("_dominant"), kernel_name), file=sys.stderr)
         pmc = None
-    if pmc:
+    # measured in THIS run where rocprofv3 is on the box: scripts/pmc_collect.py (separate --pmc passes around this same command, 3 steps)
+    if not args.no_pmc and world == 1 and not dist_on:
+        import shutil
+        import tempfile
+        if shutil.which("rocprofv3"):
+            try:
+                tmp_json = os.path.join(tempfile.mkdtemp(prefix="ta_pmc_"), "pmc.json")
+                flags = ["--dist", args.dist] + (["--pairs", str(args.pairs)] if args.pairs else []) + \
+                        (["--needle-len", str(args.needle_len)] if wl == "hsearch" else []) + (["--early-out"] if args.early_out else []) + \
+                        ["--prewarm-ms", "0"]
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_collect.py"), "--out", tmp_json, "--workload", wl,
+                                    "--sets", "rd_b,write", "--steps", "3", "--extra", " ".join(flags)],
+                                   capture_output=True, text=True, timeout=240)
+                live = json.load(open(tmp_json))
+                if kernel_name and kernel_name in str(live.get("_dominant", "")):
+                    traffic = int(live["_traffic"]["bytes_per_pass"])
+                    traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_64B/128B, WRITE_SIZE (separate passes, "
+                                      "3 steps each, same workload) after the timed region; 128 x RDREQ_128B + 64 x RDREQ_64B + WRITE_SIZE, "
+                                      "all kernels of one pass")
+            except Exception as e:
+                print("bench.py: live counter pass failed (%s: %s): replaying the committed one" % (type(e).__name__, e), file=sys.stderr)
+    if pmc and traffic is None:
         try:
             traffic = int(pmc["_traffic"]["bytes_per_pass"])      # size-resolved L2 fabric-side requests, all kernels of one pass
             traffic_source = ("replayed from the committed counter pass profiles/%s/bench_%s_pmc.json (rocprofv3 --pmc, separate passes, "

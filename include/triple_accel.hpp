@@ -125,6 +125,19 @@ public:
 private:
     ta_queue *q_ = nullptr;
 };
+// what a caller's loop over levenshtein_simd_k_with_opts(a, b, k, false, costs) computes, answered by one batch pass per 65536 pairs
+template <class PairRange>
+inline std::vector<std::optional<std::uint32_t>> levenshtein_simd_k_with_opts_many(const PairRange &pairs, std::uint32_t k, const EditCosts &costs) {
+    Queue q(k, costs);
+    std::vector<std::optional<std::uint32_t>> out;
+    std::size_t pending = 0;
+    for (const auto &pr : pairs) {
+        q.push(pr.first, pr.second);
+        if (++pending >= (std::size_t(1) << 16)) { auto r = q.flush(); out.insert(out.end(), r.begin(), r.end()); pending = 0; }
+    }
+    if (pending) { auto r = q.flush(); out.insert(out.end(), r.begin(), r.end()); }
+    return out;
+}
 // `.next()` on the reference's lazy All-mode iterator (src/levenshtein.rs:2282-2420): the first match, found without scanning the rest
 inline std::optional<Match> levenshtein_search_first(bytes needle, bytes haystack, std::uint32_t k, const EditCosts &costs, bool anchored) {
     ta_match m; int found = 0;

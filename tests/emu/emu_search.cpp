@@ -169,6 +169,45 @@ static void ham_n(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_
     }
 }
 
+// ---- bit-sliced counters (ham_bits_body.h): the kernel's tile walk -- n - 1 bytes in front of the tile, verdict per byte, recount of hits
+#include "ham_bits_body.h"
+template <int B>
+static void ham_bits_all(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, std::vector<Hit> &hits) {
+    uint32_t mis[256], bias[B];
+    for (uint32_t c = 0; c < 256; c++) mis[c] = ham_bits_mis(needle, n, c);
+    ham_bits_bias<B>(k, n, bias);
+    const uint64_t last = h - n;
+    for (uint64_t b0 = 0; b0 < h; b0 += tile) {
+        const uint64_t b1 = b0 + tile < h ? b0 + tile : h;
+        HamBitsState<B> st;
+        ham_bits_reset<B>(st, n);
+        for (uint64_t i = b0 > n - 1u ? b0 - (n - 1u) : 0; i < b0; i++) ham_bits_step<B>(st, mis[hay[i]], bias);
+        for (uint64_t i = b0; i < b1; i++) {
+            if (ham_bits_step<B>(st, mis[hay[i]], bias) >> 31) continue;
+            if (i < n - 1u) continue;
+            const uint64_t pos = i - (n - 1u);
+            if (pos > last) continue;
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != needle[j];
+            hits.push_back(Hit{pos, pos + n, cnt, 0u});
+        }
+    }
+}
+extern "C" int emu_ham_search_bits(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile,
+                                   Hit *out, uint64_t cap, uint64_t *count) {
+    const int B = ham_bits_planes(k);
+    if (n == 0 || n > 32 || n > h || tile == 0 || !B || k >= n) return 1;
+    std::vector<Hit> hits;
+    switch (B) {
+        case 1: ham_bits_all<1>(needle, n, hay, h, k, tile, hits); break; case 2: ham_bits_all<2>(needle, n, hay, h, k, tile, hits); break;
+        case 3: ham_bits_all<3>(needle, n, hay, h, k, tile, hits); break; case 4: ham_bits_all<4>(needle, n, hay, h, k, tile, hits); break;
+        default: ham_bits_all<5>(needle, n, hay, h, k, tile, hits); break;
+    }
+    *count = hits.size();
+    for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];
+    return 0;
+}
+
 // ---- SWAR form (ham_swar_body.h): the per-lane function over every 16-byte-aligned lane position, as the kernel walks them
 #include "ham_swar_body.h"
 template <int NW>

@@ -283,6 +283,24 @@ def ham_search(needle, haystack, k, tile=512, words=0):
     return [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]
 
 
+def ham_search_bits(needle, haystack, k, tile=256):
+    """All-mode hits of the bit-sliced hamming_search form (ham_bits_body.h) over a tiled haystack; None where the form does not apply
+    (k >= n, or k needs more than five counter bits)."""
+    n = len(needle)
+    hay = np.zeros(len(haystack) + 16, dtype=np.uint8)
+    hay[:len(haystack)] = np.frombuffer(haystack, dtype=np.uint8)
+    cap = len(haystack) + 2
+    out = np.zeros((cap, 3), dtype=np.uint64)
+    cnt = C.c_uint64()
+    f = lib().emu_ham_search_bits
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    rc = f(needle, n, hay.ctypes.data, len(haystack), k, tile, out.ctypes.data, cap, C.byref(cnt))
+    if rc:
+        return None
+    return [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]
+
+
 def ham_search_swar(needle, haystack, k, delta=0):
     """All-mode hits [(start, end, k)] of the SWAR hamming_search form (ham_swar_body.h: 16 offsets per lane) with the haystack starting
     `delta` bytes behind a 16-byte boundary."""

@@ -55,3 +55,26 @@ def test_swar16_equals_oracle():
                 assert sorted(E.ham_search_swar(needle, hay, k, delta)) == want, (n, k, delta)
     assert E.ham_search_swar(b"abc", b"abc", 0) == [(0, 3, 0)]
     assert E.ham_search_swar(b"abc", b"xxabd", 1, 3) == [(2, 5, 1)]
+
+
+def test_bit_sliced_equals_oracle():
+    """Bit-sliced mismatch counters (ham_bits_body.h): needle lengths 1..32, every k below the needle length that fits five counter bits
+    (the bias 2^B - 1 - k turns "more than k" into a counter overflow), tiles that cut planted copies, haystacks with zeros."""
+    g = Dg.rng(0x4D)
+    for n in (1, 2, 5, 8, 9, 12, 16, 17, 24, 31, 32):
+        needle = bytes(g.integers(0, 256, size=n).astype(np.uint8))
+        hay = bytearray(g.integers(0, 256, size=1500).astype(np.uint8).tobytes())
+        for pos in range(3, 1450, 61):
+            m = bytearray(needle)
+            for _ in range(int(g.integers(0, 6))):
+                m[int(g.integers(0, n))] = int(g.integers(0, 256))
+            hay[pos:pos + n] = m
+        hay = bytes(hay)
+        for k in sorted({0, 1, 2, 3, 4, 7, 8, 14, 15, 16, 30, 31}):
+            if k >= n:
+                continue
+            want = O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+            for tile in (128, 256, 640):
+                got = E.ham_search_bits(needle, hay, k, tile)
+                assert got is not None and sorted(got) == want, (n, k, tile)
+    assert E.ham_search_bits(b"abcd", b"xxabcdxx", 4) is None and E.ham_search_bits(b"abcd" * 8, b"q" * 100, 31) == []

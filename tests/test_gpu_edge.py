@@ -157,3 +157,32 @@ def test_queue_of_single_pairs():
         a = [Dg.rand_str(g, int(g.integers(0, 60))) for _ in range(5000)]
         b = [Dg.mutate(g, x, 3) for x in a]
         assert np.array_equal(gpu_k(a, b, 4), oracle_k(a, b, 4))
+
+
+def test_many_helpers_and_failed_flush():
+    """levenshtein_simd_k_with_opts_many / levenshtein_many: what a loop over the single-call function returns, through the queue (several
+    flushes); and a flush that fails drops its pairs -- the queue works again afterwards (it used to fail the same way for ever)."""
+    import triple_accel_amd as T
+    g = Dg.rng(92)
+    pairs = []
+    for i in range(3000):
+        x = Dg.rand_str(g, int(g.integers(0, 120)))
+        pairs.append((x, Dg.mutate(g, x, int(g.integers(0, 9))) if i % 4 else Dg.rand_str(g, int(g.integers(0, 120)))))
+    want = O.levenshtein_k_batch(O.csr_from_list([p[0] for p in pairs]), O.csr_from_list([p[1] for p in pairs]), 6, (1, 1, 0, None))
+    got = T.levenshtein_simd_k_with_opts_many(iter(pairs), 6, flush_every=700)
+    assert got == [None if int(w) == 0xFFFFFFFF else int(w) for w in want]
+    assert T.levenshtein_many(pairs[:200]) == [O.levenshtein(x, y) for x, y in pairs[:200]]
+    # a band no kernel serves inside a queue pass (weighted costs, unbounded k, 40 000-byte strings): the flush fails and the queue empties
+    q = T.Queue(0xFFFFFFFF, T.EditCosts(2, 3, 1, None))
+    big = Dg.rand_str(g, 40_000)
+    q.push(big, big[::-1])
+    try:
+        q.flush()
+        failed = False
+    except Exception:
+        failed = True
+    if failed:
+        assert q.flush() == []
+        q.push(b"kitten", b"sitting")
+        assert q.flush() == [O.levenshtein_simd_k_with_opts(b"kitten", b"sitting", 0xFFFFFFFF, False, (2, 3, 1, None))[0]]
+    q.close()

@@ -5,6 +5,7 @@
 
 #include "ham_search_body.h"
 #include "ham_swar_body.h"
+#include "ham_bits_body.h"
 #include "lev_filter_body.h"
 #include "lev_search_body.h"
 #include "lev_search_wave_body.h"
@@ -593,6 +594,88 @@ __global__ __launch_bounds__(256) void hamming_search_swar16_kernel(SearchParams
     }
 }
 
+// needles of 9..32 bytes with a small k, bit-sliced counters (ham_bits_body.h): one lane per tile of P.tile bytes (a multiple of 128), the
+// 256-entry Mis table once per lane in LDS (64 KB, 512 threads: two workgroups per CU), a whole 128-byte line per lane per burst one line
+// ahead.  The NUL-byte scan rides along (the lane checks the bytes of its own tile).
+template <int B>
+__global__ __launch_bounds__(512) void hamming_search_bits_kernel(SearchParams P, uint32_t *nul_flag) {
+    __shared__ __attribute__((aligned(16))) uint32_t mis[256 * 64];
+    {
+        const uint32_t m = ham_bits_mis(P.needle, P.needle_len, threadIdx.x >> 1);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *row = (u32x4 *)(mis + (threadIdx.x >> 1) * 64 + (threadIdx.x & 1u) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) row[q] = u32x4{m, m, m, m};
+    }
+    __syncthreads();
+    const uint32_t lane_off = (threadIdx.x & 63u) * 4u;
+    auto lookup = [&](uint32_t v, int b) -> uint32_t {
+        const uint32_t a = __builtin_amdgcn_perm(v, lane_off, 0x0C0C0000u | ((4u + (uint32_t)b) << 8));   // lane*4 | byte b << 8
+        return *(const uint32_t *)((const uint8_t *)mis + a);
+    };
+    const uint32_t n = P.needle_len, k = P.k;
+    const uint64_t h = P.hay_len, last = h - n;
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b0 = tile * P.tile;                             // this lane reports the alignments that END at bytes [b0, b1)
+    if (b0 >= h) return;
+    const uint64_t b1 = b0 + P.tile < h ? b0 + P.tile : h;
+    const uint8_t *hay = P.hay;
+    HamBitsState<B> st;
+    ham_bits_reset<B>(st, n);
+    uint32_t bias[B];
+    ham_bits_bias<B>(k, n, bias);
+    for (uint64_t i = b0 > n - 1u ? b0 - (n - 1u) : 0; i < b0; i++) ham_bits_step<B>(st, lookup(hay[i], 0), bias);   // the n - 1 bytes in front
+    auto report = [&](uint64_t x) {                                // the alignment ending at byte x has at most k mismatches
+        if (x < n - 1u) return;                                    // (no alignment ends there: the verdict bits of a haystack's first bytes)
+        const uint64_t pos = x - (n - 1u);
+        if (pos > last) return;
+        uint32_t cnt = 0;
+        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != P.needle_dev[j];
+        const unsigned long long idx = atomicAdd(P.count, 1ull);
+        if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt, 0u};
+    };
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    uint64_t i = b0;
+    const uint64_t full_end = b0 + ((b1 - b0) & ~(uint64_t)127);
+    uint32_t nz = 0xFFFFFFFFu;                                     // AND of the byte tests: 0xFF per byte that is not NUL
+    u32x4u nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) nxt[q] = (i + 16u * q < b1) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                         // whole lines
+        u32x4u cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++)                                // blobs carry 16 bytes of slack
+            if (i + 128u + 16u * q < b1) nxt[q] = *(const u32x4u *)(hay + i + 128u + 16u * q);
+#pragma unroll 1
+        for (int part = 0; part < 4; part++) {                     // 32 bytes = 32 verdicts per register
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32x4u v = part == 0 ? cur[q] : part == 1 ? cur[2 + q] : part == 2 ? cur[4 + q] : cur[6 + q];
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const uint32_t ov = ham_bits_step<B>(st, lookup(v[b >> 2], b & 3), bias);
+                    acc = __builtin_amdgcn_alignbit(acc, ov, 31);   // (acc << 1) | (ov >> 31)
+                }
+                if (nul_flag) nz &= __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[0] ^ 0x0C0C0C0Cu) & __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[1] ^ 0x0C0C0C0Cu) &
+                                    __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[2] ^ 0x0C0C0C0Cu) & __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[3] ^ 0x0C0C0C0Cu);
+            }
+            if (acc != 0xFFFFFFFFu)                                // bit 31 - t = the verdict of byte i + 32 part + t
+                for (uint32_t t = 0; t < 32u; t++)
+                    if (!((acc >> (31u - t)) & 1u)) report(i + 32u * (uint32_t)part + t);
+        }
+        i += 128;
+    }
+    for (; i < b1; i++) {                                          // the tile's last, partial line
+        const uint32_t c = hay[i];
+        if (!(ham_bits_step<B>(st, lookup(c, 0), bias) >> 31)) report(i);
+        if (nul_flag && c == 0u) nz = 0;
+    }
+    if (nul_flag && nz != 0xFFFFFFFFu) atomicOr(nul_flag, 1u);
+}
+
 // needles of up to 32 bytes: shift-add scan (ham_search_body.h), one lane per tile of P.tile offsets, table in LDS,
 // haystack requested 64 bytes per lane one block ahead
 template <int NWS>
@@ -655,6 +738,28 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     SearchParams P = P0;
     if (nul_done) *nul_done = false;
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
+    // needles of 9..32 bytes whose k needs few counter bits: bit-sliced counters, 3 B + 3 instructions per byte against the SWAR form's
+    // 3 per needle dword + 3 (TA_HAMMING_SEARCH_NO_BITS=1 keeps the SWAR form)
+    const int planes = ham_bits_planes(P.k);
+    if (P.needle_len >= 9 && P.needle_len <= 32 && planes && P.k < P.needle_len && 3 * planes + 3 < 3 * (int)((P.needle_len + 3) / 4) + 1 &&
+        !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA") && !env_str("TA_HAMMING_SEARCH_NO_BITS")) {
+        uint64_t tile = (P.hay_len + 262143) / 262144;            // two sets of resident lanes
+        tile = (tile + 127) & ~(uint64_t)127;
+        if (tile < 256) tile = 256;
+        P.tile = (uint32_t)(tile > 0x7FFFFF80ull ? 0x7FFFFF80ull : tile);
+        const uint64_t lanes = (P.hay_len + P.tile - 1) / P.tile;
+        const dim3 grid((uint32_t)((lanes + 511) / 512)), block(512);
+        if (nul_done) *nul_done = nul_flag != nullptr;
+        set_last_kernel_name("hamming_search_bits_kernel<%d>", planes);
+        switch (planes) {
+            case 1: hipLaunchKernelGGL(hamming_search_bits_kernel<1>, grid, block, 0, s, P, nul_flag); break;
+            case 2: hipLaunchKernelGGL(hamming_search_bits_kernel<2>, grid, block, 0, s, P, nul_flag); break;
+            case 3: hipLaunchKernelGGL(hamming_search_bits_kernel<3>, grid, block, 0, s, P, nul_flag); break;
+            case 4: hipLaunchKernelGGL(hamming_search_bits_kernel<4>, grid, block, 0, s, P, nul_flag); break;
+            default: hipLaunchKernelGGL(hamming_search_bits_kernel<5>, grid, block, 0, s, P, nul_flag); break;
+        }
+        return hipGetLastError();
+    }
     if (P.needle_len <= 64 && !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA")) {
         const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 15u);
         const uint64_t lanes = (P.hay_len + delta + 15) / 16;
