@@ -390,3 +390,42 @@ def test_search_first_on_a_resident_shard():
         want = O.levenshtein_search_naive_with_opts(needle, hay, 5, O.ALL, (1, 1, 0, None), False)
         got = B.levenshtein_search_first_dev(needle, B.haystack_tensor(hay), 5, base=1000)
         assert got == ((want[0][0] + 1000, want[0][1] + 1000, want[0][2]) if want else None), where
+
+
+def test_hamming_search_forms_and_fused_nul_scan(monkeypatch):
+    """The three hamming_search kernels behind one entry -- SWAR with 16 offsets per lane (needles <= 64 bytes), bit-sliced counters
+    (9..32 bytes, small k), the round-1 forms behind their switches -- against the oracle on the same haystack; the kernel each
+    (n, k) takes; and the NUL-byte scan that rides inside the search kernels: a zero byte anywhere -- first byte, last byte, behind the
+    last offset, at a tile boundary -- is the SIMD contract's panic (src/hamming.rs:463), for both kernels."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(77)
+    hay_np = Dg.random_bytes(g, 700_000)
+    hay_np[hay_np == 0] = 1
+    for n, k, kern in [(4, 1, "swar16"), (8, 2, "swar16"), (12, 3, "bits"), (16, 7, "bits"), (16, 8, "swar16"), (24, 6, "bits"), (32, 8, "bits"),
+                       (32, 31, "bits"), (32, 32, "swar16"), (40, 9, "swar16"), (64, 20, "swar16"), (9, 1, "bits"), (70, 10, "hamming_search_kernel")]:
+        needle = bytes(int(c) or 1 for c in Dg.random_bytes(g, n))
+        hay = hay_np.copy()
+        nd = np.frombuffer(needle, dtype=np.uint8)
+        for pos in list(range(17, hay.size - 2 * n, 9973)) + [0, hay.size - n]:
+            hay[pos:pos + n] = nd
+            for q in g.integers(0, n, size=int(g.integers(0, k + 2))):
+                hay[pos + int(q)] = 7
+        dev = B.haystack_tensor(hay)
+        want = O.hamming_search_naive_with_opts(needle, hay.tobytes(), k, O.ALL)
+        assert len(want) >= 25
+        got = [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, dev, k)]
+        assert kern in T.last_kernel_name() or n > 64, (n, k, T.last_kernel_name())
+        assert got == want, (n, k)
+        for sw in ("TA_HAMMING_SEARCH_NO_BITS", "TA_HAMMING_SEARCH_SA", "TA_HAMMING_SEARCH_SWAR"):
+            if sw == "TA_HAMMING_SEARCH_SA" and n > 32:
+                continue
+            monkeypatch.setenv(sw, "1")
+            assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, dev, k)] == want, (n, k, sw)
+            monkeypatch.delenv(sw)
+        if n in (8, 24):
+            for zpos in (0, hay.size - 1, hay.size - n + 1, 128 * 5, 262143, 300_001):
+                hz = hay.copy()
+                hz[zpos] = 0
+                with pytest.raises(T.PanicError):
+                    B.hamming_search_dev(needle, B.haystack_tensor(hz), k)
