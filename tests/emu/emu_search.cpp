@@ -25,14 +25,17 @@ static int run_tiles_wave(const uint8_t *needle, uint32_t n, const uint8_t *hay,
     for (uint64_t eb = 0; eb < h; eb += tile) {
         uint64_t ee = eb + tile < h ? eb + tile : h;
         uint64_t cb = eb > halo ? eb - halo : 0;
-        auto flush = [&](uint32_t nh, const V32 &keys, const V32 &cols) {
-            for (uint32_t q = 0; q < nh; q++) {
+        auto flush = [&](const VB &hit, const V32 &keys, const V32 &cols) {      // lane t: emitted column t of the block
+            for (uint32_t q = 0; q < 64; q++) {
+                if (!hit.v[q]) continue;
                 const uint64_t end = cb + cols.v[q] + 1;
                 hits.push_back(Hit{end - (0xFFFFu - (keys.v[q] & 0xFFFFu)), end, keys.v[q] >> 16, 0});
             }
         };
-        if (trans) lev_search_block_wave<EmuWave, true>(hay, nd, n, C, cb, eb, ee, flush);
-        else lev_search_block_wave<EmuWave, false>(hay, nd, n, C, cb, eb, ee, flush);
+        uint8_t row_lds[64 * 4];
+        memset(row_lds, 0xA5, sizeof(row_lds));
+        if (trans) lev_search_block_wave<EmuWave, true>(hay, nd, n, C, cb, eb, ee, row_lds, flush);
+        else lev_search_block_wave<EmuWave, false>(hay, nd, n, C, cb, eb, ee, row_lds, flush);
     }
     return 0;
 }

@@ -56,10 +56,11 @@ TA_HD inline __attribute__((always_inline)) uint32_t lev_filter_step(FilterState
     return s.score;
 }
 
-// The same step without the score: the last row's horizontal +1 / -1 bits are shifted into two 32-column registers (one
-// v_alignbit_b32 each) and the score is settled once per 32 columns by lev_filter_fold32.
+// The same step without the score: the last row's horizontal -1 bits are shifted into a 32-column register (one v_alignbit_b32) and
+// the score is settled once per 32 columns by lev_filter_fold32 -- which reads it off the column itself (round 4: the +1 bits were
+// collected too, one more instruction per byte; the score of a column is the sum of its vertical steps, two popcounts per 32 bytes).
 template <bool TRANS>
-TA_HD inline __attribute__((always_inline)) void lev_filter_step_h(FilterState &s, uint32_t Eq, uint32_t &PH, uint32_t &MH) {
+TA_HD inline __attribute__((always_inline)) void lev_filter_step_h(FilterState &s, uint32_t Eq, uint32_t &MH) {
     uint32_t D0 = (((Eq & s.Pv) + s.Pv) ^ s.Pv) | Eq | s.Mv;
     if (TRANS) {
         D0 |= ((~s.D0p & Eq) << 1) & s.Eqp;
@@ -68,10 +69,8 @@ TA_HD inline __attribute__((always_inline)) void lev_filter_step_h(FilterState &
     const uint32_t Ph = s.Mv | ~(D0 | s.Pv);
     const uint32_t Mh = D0 & s.Pv;
 #if defined(__HIP_DEVICE_COMPILE__)
-    PH = __builtin_amdgcn_alignbit(PH, Ph, 31);                      // (PH << 1) | (Ph >> 31)
-    MH = __builtin_amdgcn_alignbit(MH, Mh, 31);
+    MH = __builtin_amdgcn_alignbit(MH, Mh, 31);                      // (MH << 1) | (Mh >> 31)
 #else
-    PH = (PH << 1) | (Ph >> 31);
     MH = (MH << 1) | (Mh >> 31);
 #endif
     const uint32_t Phs = Ph << 1, Mhs = Mh << 1;
@@ -83,10 +82,12 @@ TA_HD inline __attribute__((always_inline)) void lev_filter_step_h(FilterState &
 // never went below (score before) - (number of -1 steps): a LOWER BOUND -- the answer may be yes for a block without a hit
 // (the exact kernel then finds nothing there), never no for a block with one.  On text where matches are rare the -1 steps
 // are rare too and the bound is as good as the exact minimum; it saves 1.3 of the scan's 16 instructions per byte.
-TA_HD inline __attribute__((always_inline)) bool lev_filter_fold32(FilterState &s, uint32_t PH, uint32_t MH, uint32_t k) {
+// The score after those columns = the last row's value = the sum of the column's vertical steps over the needle's rows (row 0 is 0 and the
+// wildcard rows below the needle carry no steps): popcount(Pv) - popcount(Mv).
+TA_HD inline __attribute__((always_inline)) bool lev_filter_fold32(FilterState &s, uint32_t MH, uint32_t k) {
     const uint32_t down = (uint32_t)__builtin_popcount(MH);
     const bool any = s.score <= k + down;
-    s.score = s.score + (uint32_t)__builtin_popcount(PH) - down;
+    s.score = (uint32_t)__builtin_popcount(s.Pv) - (uint32_t)__builtin_popcount(s.Mv);
     return any;
 }
 
@@ -122,9 +123,9 @@ TA_HD inline void lev_filter_tile_lb(const uint8_t *hay, Peq peq, uint32_t n, ui
     while (i + FILTER_BLOCK <= col_end) {
         bool any = false;
         for (int half = 0; half < 2; half++) {
-            uint32_t PH = 0, MH = 0;
-            for (int b = 0; b < 32; b++) lev_filter_step_h<TRANS>(s, peq(hay[i + 32 * half + b]), PH, MH);
-            any |= lev_filter_fold32(s, PH, MH, k);
+            uint32_t MH = 0;
+            for (int b = 0; b < 32; b++) lev_filter_step_h<TRANS>(s, peq(hay[i + 32 * half + b]), MH);
+            any |= lev_filter_fold32(s, MH, k);
         }
         if (any) mark(i / FILTER_BLOCK);
         i += FILTER_BLOCK;

@@ -171,14 +171,14 @@ __global__ __launch_bounds__(REPL ? 512 : 256) void lev_filter_kernel(SearchPara
             } else {            // the score settled per 32 columns: a lower bound of the block's smallest cost (lev_filter_fold32)
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
-                    uint32_t PH = 0, MH = 0;
+                    uint32_t MH = 0;
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
                         const u32x4u v = blk == 0 ? cur[2 * half + q] : cur[4 + 2 * half + q];
 #pragma unroll
-                        for (int b = 0; b < 16; b++) lev_filter_step_h<TRANS>(st, lookup(v[b >> 2], b & 3), PH, MH);
+                        for (int b = 0; b < 16; b++) lev_filter_step_h<TRANS>(st, lookup(v[b >> 2], b & 3), MH);
                     }
-                    any |= lev_filter_fold32(st, PH, MH, k);
+                    any |= lev_filter_fold32(st, MH, k);
                 }
             }
             if (any) flag(i);
@@ -341,6 +341,7 @@ template <bool TRANS, bool BEST>
 __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, const uint32_t *list, uint32_t cap_list, SearchCtl *ctl,
                                                               SearchSlot *slots, uint8_t *report, uint32_t done_groups) {
     __shared__ uint32_t s_last, s_sel;
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[4][64];        // per wavefront: the last row's values of a block's emitted columns
     (void)store_match_agent;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;   // wave-uniform: scalar loop control
@@ -361,11 +362,11 @@ __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, co
             const uint64_t col_begin = emit_begin > P.halo ? emit_begin - P.halo : 0;
             if (BEST && t < SEARCH_SLOT_CAP && lane == 0)                  // "no hits" until the block says otherwise (no fill needed)
                 __hip_atomic_store((unsigned long long *)(slots + t), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lev_search_block_wave<DevWave, TRANS>(P.hay, needle, P.needle_len, C, col_begin, emit_begin, emit_end,
-                [=](uint32_t nh, uint32_t key, uint32_t col) {            // lane h < nh holds hit h
+            lev_search_block_wave<DevWave, TRANS>(P.hay, needle, P.needle_len, C, col_begin, emit_begin, emit_end, (uint8_t *)s_row[threadIdx.x >> 6],
+                [=](bool hit, uint32_t key, uint32_t col) {               // lane t: emitted column t of the block
                     const uint64_t gend = base + col_begin + col + 1;
                     const uint32_t cost = key >> 16, len = 0xFFFFu - (key & 0xFFFFu);
-                    const bool mine = lane < nh && gend > emit_from;
+                    const bool mine = hit && gend > emit_from;
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
                     if (m == 0) return;
                     const uint32_t cnt = (uint32_t)__builtin_popcountll(m), rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));

@@ -29,15 +29,16 @@ namespace ta {
 
 constexpr uint32_t SRCH_WAVE_MAX_COLS = 256;    // bytes a block may span (emitted columns + left context): 4 registers of 64
 
-// The block's hits are collected in two registers -- hit number h (in increasing end order) sits in LANE h: its packed key and
-// its column (a block emits at most SRCH_WAVE_MAX_HITS = 64 end positions) -- and handed over ONCE, after the
-// last step: flush(nh, keys, cols), hit h = (cost = keys[h] >> 16, length = 0xFFFF - (keys[h] & 0xFFFF), end = col_begin +
-// cols[h] + 1).  (One atomic cursor bump per block instead of one round trip to memory per hit inside the dependent chain.)
+// The last row's value of every emitted column goes to LDS as it is finished -- one ds_write under the lane mask of lane n - 1 per
+// step, nothing of it on the dependent chain (rounds 2-3 read it back to the scalar unit every step: v_readlane, s_cmp, a branch, 44 us
+// for cfg5's flagged blocks) -- and ONE vector pass after the last step tests them all: lane t holds emitted column t (a block emits at
+// most SRCH_WAVE_MAX_HITS = 64 end positions), flush(hit, keys, cols) with hit = "cost <= k" per lane, cost = keys >> 16, length =
+// 0xFFFF - (keys & 0xFFFF), end = col_begin + cols + 1.  (One atomic cursor bump per block.)  lds: 64 dwords of this wavefront's own.
 // `needle` must be readable per lane (global / kernarg memory on the device).
 constexpr uint32_t SRCH_WAVE_MAX_HITS = 64;
 template <class W, bool TRANS, class Flush>
 TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needle, uint32_t n, const SearchCosts &C,
-                                        uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, Flush flush) {
+                                        uint64_t col_begin, uint64_t emit_begin, uint64_t col_end, uint8_t *lds, Flush flush) {
     using U32 = typename W::U32;
     using Bool = typename W::Bool;
     if (col_begin >= col_end || n == 0) return;
@@ -63,8 +64,7 @@ TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needl
     U32 oldp = v;                              // this lane's value before its last update
     U32 dcur = W::splat(ROW0), dprev = W::splat(ROW0);   // the diag this lane used one / two steps ago
     U32 c = W::splat(0u);                     // the byte this lane used one step ago = hay[i-1]
-    U32 hit_key = W::splat(0u), hit_col = W::splat(0u);
-    uint32_t nh = 0;
+    const Bool last_row = lane == W::splat(n - 1u);
     const uint32_t steps = ncols + n - 1;
     const uint32_t first_emit = e0 + n - 1;    // lane n-1 reaches column e0 at this step
     uint32_t s = 0;
@@ -97,17 +97,17 @@ TA_HD inline void lev_search_block_wave(const uint8_t *hay, const uint8_t *needl
             v = W::sel(act, vv, v);
             ng = W::sel(act, a, ng);
             hg = h; oldp = old; c = cn;
-            if (s >= first_emit) {                                         // lane n-1 has just finished column s - (n-1)
-                const uint32_t key = W::readlane(v, n - 1);
-                if ((key >> 16) <= C.k && nh < SRCH_WAVE_MAX_HITS) {      // :1792-1806
-                    hit_key = W::writelane(hit_key, key, nh);
-                    hit_col = W::writelane(hit_col, s - (n - 1), nh);
-                    nh++;
-                }
-            }
+            if (s >= first_emit && s - first_emit < SRCH_WAVE_MAX_HITS)   // lane n-1 has just finished column s - (n-1)
+                W::lds_write32p(lds, W::splat(4u * (s - first_emit)), v, last_row);
         }
     }
-    if (nh) flush(nh, hit_key, hit_col);
+    W::lds_wave_sync();
+    const uint32_t n_emit = steps - first_emit < SRCH_WAVE_MAX_HITS ? steps - first_emit : SRCH_WAVE_MAX_HITS;      // = ncols - e0
+    const Bool mine = lane < W::splat(n_emit);
+    const U32 key = W::sel(mine, W::lds_read32(lds, lane << 2), W::splat(0xFFFFFFFFu));
+    const Bool hit = W::land(mine, (key >> 16) <= W::splat(C.k));                                   // :1792-1806
+    if (W::any(hit)) flush(hit, key, lane + W::splat(e0));
+    W::lds_wave_sync();                                                  // (the next block of this wavefront writes the same words)
 }
 
 }  // namespace ta
