@@ -394,11 +394,17 @@ __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, co
         __hip_atomic_store(&ctl->pad[0], t_enter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ctl->pad[1], (uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // last workgroup out writes the report.  Every store that another workgroup reads later was an agent-scope atomic store:
-    // waiting for this wavefront's own memory operations (s_waitcnt 0) is all the ordering the done counter needs.
+    // last workgroup out writes the report.  Every store that another workgroup reads later was an agent-scope atomic store and this
+    // wavefront's own memory operations are waited for (s_waitcnt 0); on top of that:
+    // Bit 31 of done_groups (the default; TA_SRCH_NO_FENCE=1 clears it): thread 0 of every workgroup issues ONE agent-scope release fence in
+    // front of its counter bump and the last workgroup an acquire fence behind it -- the release / acquire pair the language memory model
+    // asks for, per workgroup, not per wavefront (per wavefront it made the kernel 300 us long; per workgroup it costs 2-6 us per pass).
+    const bool fenced = (done_groups & 0x80000000u) != 0u;
+    done_groups &= 0x7FFFFFFFu;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) {       // two levels: the last workgroup of a group bumps the groups' counter
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const uint32_t g = blockIdx.x % done_groups, members = gridDim.x / done_groups + (g < gridDim.x % done_groups ? 1u : 0u);
         uint32_t last = 0;
         if (__hip_atomic_fetch_add(&ctl->done[g * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(256) void lev_search_wave_kernel(SearchParams P, co
     s_sel = 0;
     __syncthreads();
     if (!s_last) return;
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint32_t t_report = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const unsigned long long count = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SearchReport *rep = (SearchReport *)report;
@@ -474,6 +481,7 @@ hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, 
     if (const char *e = env_str("TA_SRCH_GRID")) { const int v = atoi(e); if (v >= 1 && v <= 4096) g = (uint32_t)v; }
     if (const char *e = env_str("TA_SRCH_DONE_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= (int)SEARCH_DONE_GROUPS) done_groups = (uint32_t)v; }
     if (done_groups > g) done_groups = g;
+    if (!env_str("TA_SRCH_NO_FENCE")) done_groups |= 0x80000000u;    // (2-6 us of a 0.49 ms pass: profiles/r04/raw/probe_search_fence.txt)
     const dim3 grid(g), block(256);
     if (trans) {
         if (best) hipLaunchKernelGGL((lev_search_wave_kernel<true, true>), grid, block, 0, s, P, list, cap_list, ctl, slots, report_dev, done_groups);
