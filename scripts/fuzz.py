@@ -1,6 +1,7 @@
 """Randomised parity run on a GPU box: random batches through every distance / search entry point against the CPU oracle.
 usage: python scripts/fuzz.py <minutes> [seed]   (not part of the test suite; prints the first mismatch and exits 1)"""
 import os, sys, time
+os.environ.setdefault("TA_TUNING", "1")      # lets a round switch the VLINE fetch form on (TA_BITS_VLINE is read per call under TA_TUNING)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +14,7 @@ minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 g = np.random.default_rng(seed)
 print("seed", seed, flush=True)
-COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 0, None), (1, 2, 0, None), (3, 2, 1, 2), (2, 3, 2, None), (1, 1, 1, None), (5, 3, 0, 4), (2, 2, 1, 3), (255, 255, 0, None)]
+COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 1, 0, None), (1, 2, 0, None), (3, 2, 1, 2), (2, 3, 2, None), (1, 1, 1, None), (5, 3, 0, 4), (2, 2, 1, 3), (255, 255, 0, None), (2, 2, 0, None), (3, 3, 0, 3)]
 
 
 def rand_pairs(n, lo, hi, alpha, sim, edits):
@@ -32,7 +33,10 @@ def rand_pairs(n, lo, hi, alpha, sim, edits):
 t_end, rounds, kinds = time.time() + 60 * minutes, 0, {}
 while time.time() < t_end:
     rounds += 1
-    kind = int(g.integers(0, 9))
+    kind = int(g.integers(0, 11))
+    os.environ.pop("TA_BITS_VLINE", None)
+    if g.random() < 0.3:
+        os.environ["TA_BITS_VLINE"] = "1"                # round 4: CSR batches through the VLINE fetch form
     early = bool(g.random() < 0.3)                 # the early-out option must never change an answer
     T.set_option(T.OPT_EARLY_OUT, early)
     alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
@@ -115,6 +119,39 @@ while time.time() < t_end:
                 want = O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), k, costs)
             ok = np.array_equal(got, want)
             what = ("big_batch", n, L, Lb, k, costs, small, early, T.last_launch_info()["kernel"], T.last_kernel_name())
+        elif kind == 9:         # round 4: batch tracebacks on the device
+            n = int(g.choice([1, 40, 700, 3000]))
+            hi = int(g.choice([12, 60, 200, 500]))
+            a, b = rand_pairs(n, int(g.integers(0, hi + 1)), hi, alpha, 0.8, int(g.choice([2, 10, 30])))
+            k = int(g.choice([0, 3, 10, 32, 64, 200]))
+            out, ed, ne = B.levenshtein_trace_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs)
+            gd = out.cpu().numpy().view(np.uint32); ge = B.edits_to_lists(ed, ne)
+            ok = True
+            for i in range(n):
+                wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+                if wd is None:
+                    ok = ok and gd[i] == 0xFFFFFFFF and ge[i] == []
+                else:
+                    ok = ok and gd[i] == wd and ge[i] == [tuple(e) for e in we]
+                if not ok:
+                    print("pair", i, a[i], b[i], gd[i], ge[i], wd, we)
+                    break
+            what = ("trace_batch", n, hi, k, costs, alpha)
+        elif kind == 10:        # round 4: hamming_search kernels by (needle length, k): SWAR16, bit-sliced, the long-needle form
+            n = int(g.choice([1, 3, 4, 8, 9, 12, 16, 17, 24, 31, 32, 33, 48, 64, 65]))
+            needle = g.integers(1, 256, n, dtype=np.uint8).tobytes()
+            hay = bytearray(g.integers(1, 256, int(g.choice([n, 700, 40000, 600000])), dtype=np.uint8).tobytes())
+            for pos in range(0, max(1, len(hay) - n), max(n + 3, 3000)):
+                m = bytearray(needle)
+                for _ in range(int(g.integers(0, 9))):
+                    m[int(g.integers(0, n))] = int(g.integers(1, 256))
+                hay[pos:pos + n] = m
+            hay = bytes(hay[: max(len(hay), n)])
+            k = int(g.choice([0, 1, 2, 3, 4, 7, 8, 15, 16, 31, 32, n]))
+            got = [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, B.haystack_tensor(hay), k)]
+            want = O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+            ok = got == want
+            what = ("hamming_kernels", n, k, len(hay), T.last_kernel_name())
         elif kind == 8:         # first hit of a long haystack (the lazy All-mode iterator's first element)
             if not O.costs_valid_search(costs):
                 continue
