@@ -567,7 +567,8 @@ def main():
               % (PROFILE_ROUND, pmc.get("_dominant"), kernel_name), file=sys.stderr)
         pmc = None
     # measured in THIS run where rocprofv3 is on the box: scripts/pmc_collect.py (separate --pmc passes around this same command, 3 steps)
-    if not args.no_pmc and world == 1 and not dist_on:
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "RPD_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not args.no_pmc and world == 1 and not dist_on and not under_profiler:       # (never a profiler inside a profiler)
         import shutil
         import tempfile
         if shutil.which("rocprofv3"):

@@ -30,15 +30,15 @@ steps() { case $1 in cfg3) echo "--steps 3 --warmup 1" ;; cfg5|hsearch*|cfg2t) e
 TAGS="cfg2 cfg2_mutated cfg4 cfg1 cfg5 cfg3 cfg2w cfg4w cfg2l cfg2s cfg2t cfg2_ragged cfg2_ragged_vline cfg2_dna hsearch8 hsearch32 hsearch64"
 envof() { case $1 in cfg2_ragged_vline) echo "TA_TUNING=1 TA_BITS_VLINE=1" ;; *) echo "TA_NOENV=1" ;; esac; }
 for tag in $TAGS; do
-  nocpu="--no-cpu"; [ $tag = cfg2 ] && nocpu=""
+  nocpu="--no-cpu --no-pmc"; [ $tag = cfg2 ] && nocpu=""       # (cfg2: the driver's command -- cpu_baseline leg and the live counter passes included)
   env $(envof $tag) timeout 900 python bench.py $(flags $tag) $(steps $tag) $nocpu > $O/bench_$tag.json 2> $O/bench_$tag.err
 done
-timeout 600 python bench.py --early-out --no-cpu > $O/bench_cfg2_early_out.json 2>/dev/null
-timeout 600 python bench.py --pairs 2000000 --no-cpu > $O/bench_cfg2_2m.json 2>/dev/null
+timeout 600 python bench.py --early-out --no-cpu --no-pmc > $O/bench_cfg2_early_out.json 2>/dev/null
+timeout 600 python bench.py --pairs 2000000 --no-cpu --no-pmc > $O/bench_cfg2_2m.json 2>/dev/null
 for tag in $TAGS; do
   [ $tag = cfg2_mutated ] && continue
   st=5; [ $tag = cfg3 ] && st=3
-  (cd /tmp; rm -rf /tmp/kt_$tag; env $(envof $tag) rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py $(flags $tag) --steps $st --warmup 1 --no-cpu 2>/dev/null | grep '^{' > $O/bench_${tag}_under_kernel_trace.json; cp $(find /tmp/kt_$tag -name "kt_kernel_stats.csv" | head -1) $O/bench_${tag}_kernel_stats.csv; rm -rf /tmp/kt_$tag)
+  (cd /tmp; rm -rf /tmp/kt_$tag; env $(envof $tag) rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o kt -f csv -- python $GRAFT_REPO_ROOT/bench.py $(flags $tag) --steps $st --warmup 1 --no-cpu --no-pmc 2>/dev/null | grep '^{' > $O/bench_${tag}_under_kernel_trace.json; cp $(find /tmp/kt_$tag -name "kt_kernel_stats.csv" | head -1) $O/bench_${tag}_kernel_stats.csv; rm -rf /tmp/kt_$tag)
   wl=$(flags $tag | cut -d' ' -f2); extra=$(flags $tag | cut -s -d' ' -f3-)
   env $(envof $tag) python scripts/pmc_collect.py --out $O/bench_${tag}_pmc.json --workload $wl --sets sq1,sq2,fetch,write,rd_b --steps $st --extra "$extra" 2>&1 | tail -1
 done

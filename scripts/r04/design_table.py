@@ -26,8 +26,13 @@ ROWS = [("cfg2", "cfg2 1M×256 B, k=32 (the headline)", "bit-parallel band, stri
         ("hsearch8", "hamming_search, 8 B needle over 1 GiB, k=2", "SWAR, 16 offsets per lane, NUL scan fused"),
         ("hsearch32", "hamming_search, 32 B needle over 1 GiB, k=8", "bit-sliced counters (4 planes), NUL scan fused"),
         ("hsearch64", "hamming_search, 64 B needle over 1 GiB, k=16", "SWAR, 16 offsets per lane")]
-print("| Config | Kernel(s) | ms / pass (wall, driver protocol) | TCUPS credited / evaluated | Algorithmic GB/s (% of 8 TB/s) | Fabric-side bytes / algorithmic | VALU instr / launch | Cycles / VALU instr (of the 2-cycle ceiling; of the mixed-stream rate) |")
-print("|---|---|---|---|---|---|---|---|")
+README = "--readme" in sys.argv
+if README:
+    print("| config | ms / pass | TCUPS credited / evaluated | % of 8 TB/s (algorithmic bytes) | fabric-side / algorithmic bytes | cycles per VALU instr |")
+    print("|---|---|---|---|---|---|")
+else:
+  print("| Config | Kernel(s) | ms / pass (wall, driver protocol) | TCUPS credited / evaluated | Algorithmic GB/s (% of 8 TB/s) | Fabric-side bytes / algorithmic | VALU instr / launch | Cycles / VALU instr (of the 2-cycle ceiling; of the mixed-stream rate) |")
+  print("|---|---|---|---|---|---|---|---|")
 for tag, name, kern in ROWS:
     b, p = J("bench_%s.json" % tag), J("bench_%s_pmc.json" % tag)
     if not b: continue
@@ -41,6 +46,10 @@ for tag, name, kern in ROWS:
         cyc = 1024.0 * busy / i_
         v = "%.2f (%.2f; %.2f)" % (cyc, 2.0 / cyc, MIXED / cyc)
         insts = "%.3g" % i_
+    if README:
+        print("| %s | %.4f | **%.1f**%s | %.1f %% | %s | %s |" % (name, b["ms_per_step"], b["value"] / 1e3, (" / %.1f" % (ev / 1e3)) if ev else "", 100 * r["frac"],
+              ("%.2f" % (tr / r["algorithmic_bytes_per_pass"])) if tr else "—", v.split(" ")[0] if v else "—"))
+        continue
     print("| %s | %s | **%.4f** | **%.1f**%s | %.0f (%.1f %%) | %s | %s | %s |" % (
         name, kern, b["ms_per_step"], b["value"] / 1e3, (" / %.1f" % (ev / 1e3)) if ev else "", r["achieved"], 100 * r["frac"],
         ("%.2f" % (tr / r["algorithmic_bytes_per_pass"])) if tr else "—", insts, v or "—"))

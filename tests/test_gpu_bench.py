@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def _bench(*flags):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--prewarm-ms", "20", *flags],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--prewarm-ms", "20", *(() if "--pmc-live" in flags else ("--no-pmc",)),
+                        *[f for f in flags if f != "--pmc-live"]],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -63,7 +64,7 @@ def test_one_rank_under_the_launcher_equals_plain_run():
     env = dict(os.environ)
     for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(v, None)
-    flags = ["--steps", "20", "--warmup", "3", "--no-cpu", "--pairs", "500000", "--prewarm-ms", "300"]
+    flags = ["--steps", "20", "--warmup", "3", "--no-cpu", "--no-pmc", "--pairs", "500000", "--prewarm-ms", "300"]
     plain = _bench(*flags)                            # (argparse keeps the last --steps / --warmup)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", *flags],
@@ -79,3 +80,15 @@ def test_line_carries_the_round3_fields():
     assert r["end_to_end_ms"] > r["ms_per_step"] and r["prewarm_passes"] >= 1
     assert r["roofline"]["kernel_name"].startswith("lev_bits") and "traffic_source" in r["roofline"]
     assert 2000 < r["config"]["credited_cells_per_unit"] < 15584
+
+
+def test_traffic_measured_in_the_run():
+    """Without --no-pmc (the driver's command) and with rocprofv3 on the box, roofline.traffic comes from counter passes of THIS run
+    (scripts/pmc_collect.py around the same workload), not from a committed file; the timed region is one hipGraph."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    r = _bench("--pairs", "200000", "--pmc-live")
+    assert r["timed_region"].startswith("one hipGraph")
+    assert r["roofline"]["traffic_source"].startswith("measured in this run"), r["roofline"]["traffic_source"]
+    assert 0.8 < r["roofline"]["traffic"] / r["roofline"]["algorithmic_bytes_per_pass"] < 1.5

@@ -57,10 +57,10 @@ hipError_t lev_band_launch(const LevParams &P, const LevPlan &pl, bool affine, i
 
 // Trace kernels (trace_on = true): D = 16 (bands up to 1024 diagonals), 34 (batches: a band of up to 34 diagonals in ONE lane, 64 pairs per
 // wavefront) or 66.
-template <int D, bool AFFINE, int TRANS>
+template <int D, bool AFFINE, int TRANS, bool L1 = false>
 __global__ __launch_bounds__(64) void lev_band_trace_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    LevBand<DevWave, D, AFFINE, TRANS, true>::run(P, blockIdx.x, lds);
+    LevBand<DevWave, D, AFFINE, TRANS, true, L1>::run(P, blockIdx.x, lds);
 }
 
 hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool affine, bool trans, hipStream_t s) {
@@ -73,6 +73,12 @@ hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool aff
     else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 2>), g, b, lds, s, P); \
            else hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 0>), g, b, lds, s, P); }
     if (pl.D == 16) { TA_T(16) }
+    else if (pl.D == 34 && pl.L == 1) {                      // the batch layout: the whole band in one lane -- no neighbour traffic (L1)
+        if (affine) { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<34, true, 2, true>), g, b, lds, s, P);
+                      else hipLaunchKernelGGL((lev_band_trace_kernel<34, true, 0, true>), g, b, lds, s, P); }
+        else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<34, false, 2, true>), g, b, lds, s, P);
+               else hipLaunchKernelGGL((lev_band_trace_kernel<34, false, 0, true>), g, b, lds, s, P); }
+    }
     else if (pl.D == 34) { TA_T(34) }
     else if (pl.D == 66) { TA_T(66) }
     else return hipErrorInvalidValue;
