@@ -15,10 +15,26 @@ int g_emu_score = -1;   // -1: as the launcher (score form wherever lev_score_fo
 extern "C" void emu_lev_set_score(int v) { g_emu_score = v; }
 extern "C" int emu_lev_score_applies(uint32_t mc, uint32_t gc, int trans, uint32_t tc) { return lev_score_form_applies(mc, gc, trans, tc) ? 1 : 0; }
 
+int g_emu_band_line = 0;   // 1: fixed-length batches in the one-lane-per-pair layout take the LINE form of the fetch (score form; as the launcher)
+extern "C" void emu_lev_set_line(int v) { g_emu_band_line = v; }
+
 template <int D, bool L1> static void run_dl(const LevParams &P, bool affine, int trans, uint32_t waves) {
     uint8_t *lds = (uint8_t *)calloc(P.lds_per_wave + 64, 1);
     const bool score = g_emu_score != 0 && lev_score_form_applies(P.mc, P.gc, trans, P.tc);
     for (uint32_t w = 0; w < waves; w++) {
+        if constexpr (L1) {
+            if (score && g_emu_band_line && !P.a.off && !P.b.off) {
+                memset(lds, 0xA5, P.lds_per_wave + 64);
+                if (affine) {
+                    if (trans == 1) LevBand<EmuWave, D, true, 1, false, true, true, true>::run(P, w, lds);
+                    else LevBand<EmuWave, D, true, 0, false, true, true, true>::run(P, w, lds);
+                } else {
+                    if (trans == 1) LevBand<EmuWave, D, false, 1, false, true, true, true>::run(P, w, lds);
+                    else LevBand<EmuWave, D, false, 0, false, true, true, true>::run(P, w, lds);
+                }
+                continue;
+            }
+        }
         if (score) {
             if (affine) {
                 if (trans == 1) LevBand<EmuWave, D, true, 1, false, L1, true>::run(P, w, lds);
@@ -63,6 +79,12 @@ extern "C" int emu_lev_band(const uint8_t *a_blob, const uint64_t *a_off, const 
     LevParams P;
     P.a = StrView{a_blob, a_off, 0, 0};
     P.b = StrView{b_blob, b_off, 0, 0};
+    if (g_emu_band_line && n) {                            // a batch whose strings all have one length per side: the strided view the launcher sees
+        bool uni = true;
+        const uint64_t la = a_off[1] - a_off[0], lb = b_off[1] - b_off[0];
+        for (uint32_t i = 0; i < n && uni; i++) uni = (a_off[i + 1] - a_off[i] == la) && (b_off[i + 1] - b_off[i] == lb);
+        if (uni && a_off[0] == 0 && b_off[0] == 0) { P.a = StrView{a_blob, nullptr, la, la}; P.b = StrView{b_blob, nullptr, lb, lb}; }
+    }
     P.subset = nullptr; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
     P.mc = mc; P.gc = gc; P.sg = sg; P.tc = tc;
     P.u = pl.u; P.o = pl.o; P.L = pl.L; P.PW = pl.PW; P.lds_per_wave = pl.lds_per_wave; P.Tw = pl.Tw; P.ch = pl.ch;

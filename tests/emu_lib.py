@@ -74,6 +74,12 @@ def lev_band_score_applies(costs, force_trans_select=False):
     return bool(lib().emu_lev_score_applies(mc, gc, trans, 0 if tc is None else tc))
 
 
+def band_line(on):
+    """Fixed-length batches in the one-lane-per-pair layout through the LINE form of the DP band kernel's fetch (whole 128-byte lines parked
+    in registers; score form), as the launcher does; LDS starts out as 0xA5 garbage."""
+    lib().emu_lev_set_line(1 if on else 0)
+
+
 def lev_band(a_list, b_list, k, costs=(1, 1, 0, None), force_D=0, force_L=0, force_affine=False, force_trans_select=False,
              chunk=0, score=True):
     """-> (list of dist|None, plan dict); chunk = bytes per streamed LDS chunk (0: the planner's choice);

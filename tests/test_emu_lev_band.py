@@ -219,3 +219,31 @@ def test_emu_score_form_rule():
     for costs in [(120, 100, 0, 100), (120, 100, 0, 145), (120, 100, 7, 199)]:
         assert O.costs_valid(costs)
         assert E.lev_band(a, b, 2000, costs)[0] == oracle(a, b, 2000, costs)
+
+
+@pytest.mark.parametrize("costs", [(2, 3, 1, None), (2, 2, 1, 3), (2, 3, 0, None), (1, 1, 0, None), (1, 1, 0, 1), (3, 2, 2, 2)])
+def test_emu_band_line_form(costs):
+    """The LINE form of the DP band kernel's fetch (one lane per pair, fixed-length batches: whole 128-byte lines parked in registers and
+    committed to the ring piece by piece) against the oracle and against the chunk form: string lengths below / at / above one and two
+    lines, different lengths of a and b (band offsets on both sides), k that keep the band in one lane (L = 1)."""
+    if not (O.costs_valid(costs) and E.lev_band_score_applies(costs)):
+        pytest.skip("costs outside the score form")
+    g = Dg.rng(0xB1 + costs[0] * 7 + costs[1])
+    for la, lb in [(256, 256), (128, 128), (100, 100), (260, 250), (250, 260), (129, 127), (16, 16), (15, 17), (300, 300), (48, 64), (1, 1)]:
+        n = 70
+        a, b = [], []
+        for i in range(n):
+            x = Dg.rand_str(g, la)
+            y = (Dg.mutate(g, x, 6, costs[3] is not None)[:lb]).ljust(lb, b"q") if i % 3 else Dg.rand_str(g, lb)
+            a.append(x); b.append(y)
+        for k in (8, 20, 32):
+            want = oracle(a, b, k, costs)
+            E.band_line(True)
+            try:
+                got, plan = E.lev_band(a, b, k, costs)
+            finally:
+                E.band_line(False)
+            chunk, plan2 = E.lev_band(a, b, k, costs)
+            assert plan == plan2
+            assert got == want, (la, lb, k, costs, plan)
+            assert chunk == want

@@ -358,3 +358,24 @@ def test_exp_batch_ragged_length_ordered(monkeypatch):
     monkeypatch.setenv("TA_NO_LENGTH_ORDER", "1")
     got = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), (1, 1, 0, None)).cpu().numpy().view(np.uint32)
     assert np.array_equal(got, O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), (1, 1, 0, None)))
+
+
+@pytest.mark.parametrize("costs,k,L", [((2, 3, 1, None), 32, 256), ((2, 2, 1, 3), 8, 128), ((2, 3, 0, None), 32, 256), ((3, 1, 0, None), 9, 100), ((1, 2, 2, 2), 20, 130)])
+def test_band_line_form_fixed_length(costs, k, L, monkeypatch):
+    """Fixed-length batches under general EditCosts in the one-lane-per-pair layout take the LINE form of the DP band kernel's fetch (every
+    128-byte line of a string requested once, parked in registers; lev_band_body.h): the launcher took it, the answers are the oracle's and
+    the chunk form's (TA_BAND_NO_LINE=1) -- string lengths at, below and between whole lines, different lengths of a and b."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    for la, lb in ((L, L), (L - 3, L), (L, L - 5)):
+        am, bm = Dg.pairs_mutated_fixed(0x7AB0 + L + la + lb, 30_000, max(la, lb), max(2, k // 4), swaps=costs[3] is not None)
+        a, b = np.ascontiguousarray(am[:, :la]), np.ascontiguousarray(bm[:, :lb])
+        b[::3] = Dg.pairs_random(la + lb, len(b[::3]), lb)[1]
+        want = O.levenshtein_k_batch(O.csr_from_fixed(a), O.csr_from_fixed(b), k, costs)
+        got = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), k, costs).cpu().numpy().view(np.uint32)
+        assert "line" in T.last_kernel_name(), T.last_kernel_name()
+        assert np.array_equal(got, want), (la, lb, np.flatnonzero(got != want)[:10])
+        monkeypatch.setenv("TA_BAND_NO_LINE", "1")
+        got2 = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), k, costs).cpu().numpy().view(np.uint32)
+        assert "line" not in T.last_kernel_name() and np.array_equal(got2, want)
+        monkeypatch.delenv("TA_BAND_NO_LINE")

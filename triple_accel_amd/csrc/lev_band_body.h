@@ -71,9 +71,13 @@ constexpr int lev_trace_words(int D) { return (D + 31) / 32; }   // 2 bits x D/2
 //   multiplier of 1), and an affine cell is dot4, max3, one subtraction of sg, two max: 5 instructions against 7 (linear gaps:
 //   2 against 2.5).  Needs 0 <= 2 gc - mc and 2 gc <= 255 (lev_score_form_applies, lev_plan.h); answers are identical -- the
 //   map is monotone and exact in 32-bit integers (|S| < 2^31: lengths as for LEV_INF).
-template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false, bool L1 = false, bool SCORE = false>
+// LINE (with L1, fixed-length batches): the LINE form of the fetch -- every 128-byte line of a string requested once, whole, parked in
+//   registers and handed to the LDS ring piece by piece (see run()); else the ring is filled chunk by chunk straight from memory.
+template <class W, int D, bool AFFINE, int TRANS, bool TRACE = false, bool L1 = false, bool SCORE = false, bool LINE = false>
 struct LevBand {
     static_assert(D % 2 == 0 && D >= 2, "D must be even");
+    static_assert(!LINE || L1, "the line form of the fetch is the one-lane-per-pair layout's");
+    using Q = typename W::Q;
     static_assert(!SCORE || (!TRACE && TRANS != 2), "the score form has no traceback and no select-form transposition");
     static constexpr int Dh = D / 2;                 // cells per lane per phase
     static constexpr int NW = (Dh + 2 + 3) / 4;      // packed window registers (Dh+2 bytes used)
@@ -391,13 +395,67 @@ struct LevBand {
         // iterations before min(ca, cb) would only shift zeros into zero windows: start there
         const uint32_t hfar = W::wave_max(W::sel(active, W::sel(h + h >= L * Dh, h, W::splat(L * Dh) - h), W::splat(0)));
         const uint32_t tp0 = Tw - hfar, kc0 = tp0 / CH;
-        load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
-        load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        // ---- LINE form (one lane per pair, fixed-length batch: one geometry for the wavefront).  The chunk form asks for every 128-byte line
+        // of a 256-byte string in four 32-byte chunks, 32 iterations apart -- by then the line has left the L2: 3.6-3.9 x the strings'
+        // bytes at the fabric side (profiles/r03).  Here a lane requests a whole line of its string in one burst (eight 16-byte loads),
+        // parks it in registers (2 x 8 x 16 bytes per lane) and commits the two pieces of the next chunk to the ring where the chunk form
+        // would load them; the commit of a line's last piece is followed by the burst for the next line.
+        Q SA[8], SB[8];
+        const Bool all_lanes = (lane == lane);
+        const uint32_t alen_u = (uint32_t)P.a.len, blen_u = (uint32_t)P.b.len;
+        uint32_t ea_u = 0, eb_u = 0;
+        if (LINE) {                                            // the wavefront's one geometry, on the scalar unit (as above, per lane)
+            const uint32_t diff_u = blen_u >= alen_u ? blen_u - alen_u : alen_u - blen_u;
+            const bool inband_u = diff_u <= P.u;
+            const uint32_t tb_u = inband_u ? (P.u - diff_u) >> 1 : 0u;
+            const uint32_t o_u = inband_u ? ((tb_u + (blen_u >= alen_u ? 0u : diff_u)) | 1u) : 1u;
+            const uint32_t h_u = (o_u + 1u) >> 1, ca_u = Tw - h_u, cb_u = Tw - L * Dh + h_u;
+            ea_u = ca_u + ((16u - (ca_u & 15u)) & 15u); eb_u = cb_u + ((16u - (cb_u & 15u)) & 15u);
+        }
+        auto fetch_line = [&](Q (&S)[8], const Ptr &p, uint32_t len_u, int32_t m) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int32_t off = 128 * m + 16 * c;
+                const Bool ok = (off >= 0 && (uint32_t)off < len_u) ? all_lanes : W::bfalse();
+                S[c] = W::gload16(W::ptr_add(p, W::splat(off >= 0 ? (uint32_t)off : 0u)), ok);
+            }
+        };
+        // ring position y0 (a multiple of 16) of one string: string piece sp = (y0 - e) / 16, zeros outside the string
+        auto commit_piece = [&](Q (&S)[8], const Ptr &p, uint32_t len_u, uint32_t e_u, U32 slot, uint32_t y0, uint32_t x) __attribute__((always_inline)) {
+            const int32_t sp = ((int32_t)y0 - (int32_t)e_u) >> 4;
+            const bool inside = sp >= 0 && (uint32_t)(16 * sp) < len_u;
+            const U32 dst = slot + (y0 & RMASK);
+            const bool first = (y0 & RMASK) == 0u;              // the ring's first four bytes again behind its end
+            switch (inside ? (sp & 7) : 8) {                     // wave-uniform: one of nine stores (case_tag LAST: see lev_bits_body.h, vput)
+#define TA_BPUT(c) case c: { const Q q = W::qxor(S[c], x); W::lds_store16(lds, dst, q, all_lanes); if (first) W::lds_write32(lds, slot + 2u * CH, W::qword(q, 0)); W::template case_tag<c>(); } break;
+                TA_BPUT(0) TA_BPUT(1) TA_BPUT(2) TA_BPUT(3) TA_BPUT(4) TA_BPUT(5) TA_BPUT(6) TA_BPUT(7)
+#undef TA_BPUT
+                default: { const Q q = W::qxor(W::qzero(), x); W::lds_store16(lds, dst, q, all_lanes); if (first) W::lds_write32(lds, slot + 2u * CH, W::qword(q, 0)); } break;
+            }
+            if (inside && (sp & 7) == 7) fetch_line(S, p, len_u, (sp >> 3) + 1);
+        };
+        auto commit_chunk = [&](uint32_t kc) __attribute__((always_inline)) {
+            for (uint32_t y0 = kc * CH; y0 < kc * CH + CH; y0 += 16u) {
+                commit_piece(SA, aptr, alen_u, ea_u, a_slot, y0, C12);
+                commit_piece(SB, bptr, blen_u, eb_u, b_slot, y0, 0u);
+            }
+        };
+        if (LINE) {
+            const int32_t spa0 = ((int32_t)(kc0 * CH) - (int32_t)ea_u) >> 4, spb0 = ((int32_t)(kc0 * CH) - (int32_t)eb_u) >> 4;
+            fetch_line(SA, aptr, alen_u, spa0 > 0 ? spa0 >> 3 : 0);
+            fetch_line(SB, bptr, blen_u, spb0 > 0 ? spb0 >> 3 : 0);
+            commit_chunk(kc0);
+            commit_chunk(kc0 + 1);
+        } else {
+            load_chunk(lds, P, kc0, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+            load_chunk(lds, P, kc0 + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+        }
         W::lds_wave_sync();
 
         for (uint32_t kc = kc0; kc * CH < iters; kc++) {
             if (kc > kc0) {
-                load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
+                if (LINE) commit_chunk(kc + 1);
+                else load_chunk(lds, P, kc + 1, grp, g, active, aptr, alen, bptr, blen, ea, eb);
                 W::lds_wave_sync();
             }
             const uint32_t t_lo = kc * CH;

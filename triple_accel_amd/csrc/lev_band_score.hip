@@ -18,10 +18,30 @@ __global__ __launch_bounds__(64 * LEV_SCORE_WAVES_PER_BLOCK) void lev_band_score
     LevBand<DevWave, D, AFFINE, TRANS, false, L1, true>::run(P, blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
 }
 
+// one lane per pair + a fixed-length batch: the LINE form of the fetch (every line of a string requested once, parked in registers)
+template <int D, bool AFFINE, int TRANS>
+__global__ __launch_bounds__(64 * LEV_SCORE_WAVES_PER_BLOCK) void lev_band_score_line_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6;
+    LevBand<DevWave, D, AFFINE, TRANS, false, true, true, true>::run(P, blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+}
+
 template <int D>
 static hipError_t launch_score_d(const LevParams &P, bool affine, int trans, uint32_t grid, size_t lds, hipStream_t s) {
     dim3 g(grid), b(64 * LEV_SCORE_WAVES_PER_BLOCK);
     const bool l1 = P.L == 1;
+    // (the parked lines are 64 VGPRs: the line form is taken where the kernel still fits 128 -- four wavefronts per SIMD: up to 12 diagonals
+    // per lane, without the affine + transposition combination at 12 (147 VGPRs))
+    if constexpr (D <= 12) {
+        if (l1 && !P.a.off && !P.b.off && P.ch == 32u && (D <= 10 || !(affine && trans == 1)) && !env_int("TA_BAND_NO_LINE")) {
+            if (affine) { if (trans == 1) hipLaunchKernelGGL((lev_band_score_line_kernel<D, true, 1>), g, b, lds, s, P);
+                          else hipLaunchKernelGGL((lev_band_score_line_kernel<D, true, 0>), g, b, lds, s, P); }
+            else { if (trans == 1) hipLaunchKernelGGL((lev_band_score_line_kernel<D, false, 1>), g, b, lds, s, P);
+                   else hipLaunchKernelGGL((lev_band_score_line_kernel<D, false, 0>), g, b, lds, s, P); }
+            set_last_kernel_name("lev_band_score_line_kernel<%d, %s, %d>", D, affine ? "true" : "false", trans);
+            return hipGetLastError();
+        }
+    }
 #define TA_L(A, T) do { if (l1) hipLaunchKernelGGL((lev_band_score_kernel<D, A, T, true>), g, b, lds, s, P); \
                         else hipLaunchKernelGGL((lev_band_score_kernel<D, A, T, false>), g, b, lds, s, P); } while (0)
     if (affine) { if (trans == 1) TA_L(true, 1); else TA_L(true, 0); }
