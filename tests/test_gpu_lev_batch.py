@@ -360,7 +360,7 @@ def test_exp_batch_ragged_length_ordered(monkeypatch):
     assert np.array_equal(got, O.levenshtein_exp_batch(O.csr_from_list(a), O.csr_from_list(b), (1, 1, 0, None)))
 
 
-@pytest.mark.parametrize("costs,k,L", [((2, 3, 1, None), 32, 256), ((2, 2, 1, 3), 8, 128), ((2, 3, 0, None), 32, 256), ((3, 1, 0, None), 9, 100), ((1, 2, 2, 2), 20, 130)])
+@pytest.mark.parametrize("costs,k,L", [((2, 3, 1, None), 32, 256), ((2, 2, 1, 3), 8, 128), ((2, 3, 0, None), 32, 256), ((3, 2, 0, None), 9, 100), ((2, 2, 2, 3), 12, 130)])
 def test_band_line_form_fixed_length(costs, k, L, monkeypatch):
     """Fixed-length batches under general EditCosts in the one-lane-per-pair layout take the LINE form of the DP band kernel's fetch (every
     128-byte line of a string requested once, parked in registers; lev_band_body.h): the launcher took it, the answers are the oracle's and
