@@ -470,7 +470,9 @@ struct LevBand {
             }
             // DP part: iteration tau = tp - Tw does steps s = 2 tau + 1 (even phase) and 2 tau + 2 (odd phase).  Four iterations per
             // pair of 4-byte ring reads while the chunk lasts (one address computation per four chars), single bytes for the rest.
+            const uint32_t s_ans_u = alen_u + blen_u, t_cap_u = s_ans_u == 0u ? 0xFFFFFFFFu : ((s_ans_u - 1u) >> 1) + Tw;
             auto capture = [&](uint32_t t_now) {
+                if (LINE && t_now != t_cap_u) return;        // (one geometry for the wavefront: a scalar compare, not a v_cmp + branch per iteration)
                 Bool cap = (t_cap == t_now);
                 if (__builtin_expect(W::any(cap), 0)) {      // the answer cell was written in this iteration (rare: keep it a branch)
                     U32 r = INF;
