@@ -245,8 +245,6 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
     }
 }
 
-bool lev_wide_fits(uint32_t) { return true; }
-
 // P.lds_per_wave carries max_len + 2 (elements per boundary line) for this kernel.
 hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
                            uint32_t *threads_out, uint32_t *dpt_out) {

@@ -297,10 +297,6 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
         li.kernel = 1; li.diags_per_lane = pl.D; li.lanes_per_pair = pl.L; li.pairs_per_wave = pl.PW;
         li.grid = grid; li.lds_bytes = lds;
     } else {
-        if (!lev_wide_fits(pl.need)) {
-            set_last_error_msg("band wider than the wide-band kernel supports (strings longer than 32767 bytes with an unbounded k)");
-            return TA_ERR_ARG;
-        }
         P.L = 0; P.PW = 1; P.Tw = 0;
         P.lds_per_wave = (uint32_t)((max_len + 2 > 0xFFFFFFF0ull) ? 0xFFFFFFF0ull : max_len + 2);   // boundary line length
         uint32_t grid = 0, lds = 0, threads = 0, dpt = 0;

@@ -96,7 +96,6 @@ hipError_t lev_wide_trace_launch(const LevParams &P, bool trans, hipStream_t s);
 hipError_t lev_widebits_trace_launch(const LevParams &P, bool trans, hipStream_t s);
 hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out,
                            uint32_t *threads_out, uint32_t *dpt_out);
-bool lev_wide_fits(uint32_t need_diagonals);
 hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t *out, hipStream_t s);
 hipError_t strings_maxlen_launch(const StrView &s, uint32_t n, uint32_t *out_max /*device, pre-zeroed*/, hipStream_t st);
 hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out,
