@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 PROFILE_ROUND = "r04"
+ALPHABETS = {"dna": b"ACGT", "protein": b"ACDEFGHIKLMNPQRSTVWY", "iupac": b"ACGTRYSWKMBDHVNU"}      # --dist values passed with alphabet=...
 
 
 def parse_args():
@@ -48,9 +49,10 @@ def parse_args():
                          "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
     ap.add_argument("--needle-len", type=int, default=32, help="hsearch: needle bytes (8 / 32: shift-add scan; > 32: SWAR kernel)")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
-    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna"],
+    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna", "protein", "iupac"],
                     help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair; "
-                         "dna: fixed-length strings over A C G T (half of the pairs mutated copies), passed with alphabet=b'ACGT' -- the small-alphabet kernel")
+                         "dna: fixed-length strings over A C G T (half of the pairs mutated copies), passed with alphabet=b'ACGT' -- the small-alphabet kernel; "
+                         "protein / iupac: the same over the 20 amino-acid letters / the 16 IUPAC nucleotide codes -- the kernel for alphabets of up to 32 symbols")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -218,15 +220,15 @@ def main():
                 return csr[0], csr[1], None
             if args.dist == "random" and wl != "cfg2t":
                 a, b = Dg.pairs_random(seed, n, L)
-            elif args.dist == "dna":
-                sym = np.frombuffer(b"ACGT", dtype=np.uint8)
-                a = sym[g.integers(0, 4, size=(n, L))]
-                b = sym[g.integers(0, 4, size=(n, L))]
+            elif args.dist in ALPHABETS:
+                sym = np.frombuffer(ALPHABETS[args.dist], dtype=np.uint8)
+                a = sym[g.integers(0, len(sym), size=(n, L))]
+                b = sym[g.integers(0, len(sym), size=(n, L))]
                 near = np.arange(n) % 2 == 1                      # every other pair: a copy with up to k / 2 substitutions
                 b[near] = a[near]
                 pos = g.integers(0, L, size=(n, max(1, (k or 64) // 2)))
                 rows = np.nonzero(near)[0]
-                b[rows[:, None], pos[rows]] = sym[g.integers(0, 4, size=(len(rows), pos.shape[1]))]
+                b[rows[:, None], pos[rows]] = sym[g.integers(0, len(sym), size=(len(rows), pos.shape[1]))]
             else:
                 a = g.integers(33, 127, size=(n, L), dtype=np.uint8)
                 b = a.copy()
@@ -282,7 +284,7 @@ def main():
                 run = lambda: B.levenshtein_exp_batch(sa, sb, costs, out=out)
                 oracle = lambda l, h, th: O.levenshtein_exp_batch(*csr(l, h), costs, threads=th)
             else:
-                alphabet = b"ACGT" if args.dist == "dna" else None
+                alphabet = ALPHABETS.get(args.dist)
                 run = lambda: B.levenshtein_k_batch(sa, sb, k, costs, out=out, alphabet=alphabet)
                 oracle = lambda l, h, th: O.levenshtein_k_batch(*csr(l, h), k, costs, threads=th)
             if n == 0:

@@ -220,10 +220,12 @@ typedef struct {
 /* N x levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) -> out[i] (u32 or TA_NONE). */
 int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k,
                            const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
-/* The same for strings written in a small alphabet the caller names (at most four distinct byte values -- DNA, RNA -- for which
- * a two-bit code (byte >> h) & 3 exists): the match vector of a column becomes a table lookup, about half the instructions of the
- * byte test.  The promise is verified on the device: pairs that hold any other byte are answered by the general kernel inside the
- * same call.  Batches the small-alphabet kernel does not cover run ta_levenshtein_k_batch unchanged. */
+/* The same for strings written in a small alphabet the caller names: at most four distinct byte values -- DNA, RNA -- for which
+ * a two-bit code (byte >> h) & 3 exists, or up to 32 -- IUPAC nucleotide codes, amino acids, digits, one case of the letters -- with a
+ * five-bit code (byte >> h) & 31 and the byte's other three bits the same in every symbol.  The match vector of a column becomes a
+ * table lookup: about half (four symbols) / two thirds (twenty) of the instructions of the byte test.  The promise is verified on
+ * the device: pairs that hold any other byte are answered by the general kernel inside the same call.  Batches the small-alphabet
+ * kernels do not cover run ta_levenshtein_k_batch unchanged. */
 int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                     const uint8_t *alphabet, size_t alphabet_len, uint32_t *out_dev, void *stream);
 /* N x levenshtein_exp_with_opts(a_i, b_i, false, costs): doubling k from 30 over the still-unresolved

@@ -157,6 +157,39 @@ extern "C" int emu_lev_bitsq(const uint8_t *a_blob, uint64_t a_len, const uint8_
     return 0;
 }
 
+// ---- alphabets of up to 32 symbols (lev_bitsqw_body.h)
+#include "lev_bitsqw_body.h"
+
+extern "C" int emu_lev_bitsqw(const uint8_t *a_blob, uint64_t a_len, const uint8_t *b_blob, uint64_t b_len, const uint32_t *subset,
+                              uint32_t n, uint32_t k, int has_t, const uint8_t *sym, uint32_t n_sym, uint32_t *out, uint32_t *bad_out) {
+    const uint64_t max_len = a_len > b_len ? a_len : b_len;
+    uint32_t u = 0;
+    if (!lev_bitsq_applies(k, 1, 1, 0, has_t != 0, 1, max_len, true, LEV_BITSQ_MIN_PAIRS, &u)) return 1;
+    LevParams P;
+    P.a = StrView{a_blob, nullptr, a_len, a_len};
+    P.b = StrView{b_blob, nullptr, b_len, b_len};
+    P.subset = subset; P.trace = nullptr; P.out = out; P.n = n; P.k = k;
+    P.mc = 1; P.gc = 1; P.sg = 0; P.tc = has_t ? 1 : 0;
+    P.u = u; P.o = 0; P.L = 1; P.PW = 64; P.Tw = 0; P.ch = 0;
+    if (!lev_bitsqw_hash(sym, n_sym, &P.q_shift, &P.q_memb, &P.q_hi)) return 3;
+    P.q_ns = n_sym;
+    P.lds_per_wave = LevBitsQW<EmuWave, false>::lds_per_wave(P.q_ns);
+    bad_out[0] = 0;
+    P.q_bad_count = bad_out; P.q_bad_list = bad_out + 1;
+    uint8_t tab[256];
+    for (uint32_t i = 0; i < 256; i++) tab[i] = (uint8_t)lev_bitsqw_entry(i, P.q_shift, P.q_memb, P.q_hi);
+    const size_t slack = 1100;                             // a byte outside the alphabet looks up "ring" 0xFF: read, never used
+    uint8_t *lds = (uint8_t *)malloc(P.lds_per_wave + slack);
+    const uint32_t waves = (n + 63) / 64;
+    for (uint32_t w = 0; w < waves; w++) {
+        memset(lds, 0xA5, P.lds_per_wave + slack);         // LDS starts out as garbage on the device
+        if (has_t) LevBitsQW<EmuWave, true>::run(P, w, lds, tab);
+        else LevBitsQW<EmuWave, false>::run(P, w, lds, tab);
+    }
+    free(lds);
+    return 0;
+}
+
 // ---- one pair, one wavefront (lev_one_body.h)
 #include "lev_one_body.h"
 

@@ -62,6 +62,7 @@ struct EmuWave {
         return r;
     }
     static U32 opaque(const U32 &x) { return x; }
+    static uint32_t opaque_s(uint32_t x) { return x; }
     static U32 dot4_byte(const U32 &x, int n, uint32_t m, const U32 &acc) {
         V32 r; for (int i = 0; i < 64; i++) r.v[i] = acc.v[i] + ((x.v[i] >> (8 * n)) & 0xffu) * (m & 0xffu); return r;
     }

@@ -179,7 +179,12 @@ def lev_bits2(a2d, b2d, k, trans=False, subset=None):
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]))
 
 
-def lev_bitsq(a2d, b2d, k, alphabet, trans=False, subset=None):
+def lev_bitsqw(a2d, b2d, k, alphabet, trans=False, subset=None):
+    """The form for alphabets of up to 32 symbols (lev_bitsqw_body.h); same contract as lev_bitsq."""
+    return lev_bitsq(a2d, b2d, k, alphabet, trans, subset, entry="emu_lev_bitsqw")
+
+
+def lev_bitsq(a2d, b2d, k, alphabet, trans=False, subset=None, entry="emu_lev_bitsq"):
     """Small-alphabet form (lev_bitsq_body.h) on a fixed-length batch -> (results with 'untouched' where a pair holds a byte outside
     the alphabet, sorted list of those pairs); (None, None) when the planner declines or the alphabet has no code hash."""
     a2d, b2d = np.ascontiguousarray(a2d, dtype=np.uint8), np.ascontiguousarray(b2d, dtype=np.uint8)
@@ -191,7 +196,7 @@ def lev_bitsq(a2d, b2d, k, alphabet, trans=False, subset=None):
     bad = np.zeros(n_all + 1, dtype=np.uint32)
     sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
     n = n_all if sub is None else len(sub)
-    f = lib().emu_lev_bitsq
+    f = getattr(lib(), entry)
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32,
                   C.c_void_p, C.c_void_p]
@@ -200,7 +205,7 @@ def lev_bitsq(a2d, b2d, k, alphabet, trans=False, subset=None):
     if rc in (1, 3):
         return None, None
     if rc:
-        raise RuntimeError("emu_lev_bitsq rc=%d" % rc)
+        raise RuntimeError("%s rc=%d" % (entry, rc))
     res = ["untouched" if int(x) == 0xDEADBEEF else None if int(x) == 0xFFFFFFFF else int(x) for x in out]
     return res, sorted(int(x) for x in bad[1:1 + int(bad[0])])
 

@@ -414,3 +414,50 @@ def test_emu_bitsq_foreign_bytes_and_subsets():
     assert bad == [i for i in sorted(foreign) if i % 3 == 0]
     for i in range(200):
         assert (got[i] == "untouched") == (i % 3 != 0 or i in foreign)
+
+
+# ---- alphabets of up to 32 symbols (lev_bitsqw_body.h): dense rings of 64 rows, `b` looked up by the byte itself
+PROTEIN = b"ACDEFGHIKLMNPQRSTVWY"
+IUPAC = b"ACGTRYSWKMBDHVNU"
+
+
+@pytest.mark.parametrize("la,lb,k,trans,alphabet", [
+    (256, 256, 32, False, PROTEIN), (256, 256, 30, True, PROTEIN), (128, 128, 8, True, IUPAC), (100, 97, 12, False, IUPAC),
+    (100, 110, 20, True, PROTEIN), (300, 300, 31, False, b"0123456789"), (513, 520, 25, False, PROTEIN), (64, 64, 0, False, b"AC"),
+    (40, 40, 5, True, bytes(range(32))), (17, 30, 14, False, b"abcdefghijklmnopqrstuvwxyz"), (1, 1, 1, False, b"A"),
+    (1000, 1000, 7, True, IUPAC), (255, 257, 32, False, PROTEIN), (129, 160, 32, False, IUPAC), (160, 129, 30, True, PROTEIN),
+    (290, 258, 32, False, PROTEIN), (200, 168, 32, False, b"ACGT"), (80, 50, 30, True, bytes(range(0x40, 0x60)))])
+def test_emu_bitsqw_alphabets_up_to_32(la, lb, k, trans, alphabet):
+    n = 64 * 2 + 9
+    a, b = _dna_batch(la * 7 + lb + k, n, la, lb, k, alphabet, swaps=trans)
+    costs = (1, 1, 0, 1 if trans else None)
+    want = [O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), k, False, costs)[0] for i in range(n)]
+    got, bad = E.lev_bitsqw(a, b, k, alphabet, trans)
+    assert got is not None, "declined"
+    assert bad == [] and got == want, (bad[:5], [(i, x, y) for i, (x, y) in enumerate(zip(got, want)) if x != y][:5])
+
+
+def test_emu_bitsqw_foreign_bytes_and_subsets():
+    """A byte outside the alphabet -- a code no symbol has ('B', 'X'), a symbol's code under other high bits ('a', 0xC1), in either string,
+    first / middle / last position -- sends the pair to the fallback list; the others are answered.  Alphabets without a 5-bit code whose
+    other bits agree are declined."""
+    a, b = _dna_batch(11, 200, 150, 150, 20, PROTEIN)
+    foreign = {3: (0, 0, ord("B")), 64: (1, 149, ord("X")), 65: (0, 77, ord("a")), 130: (1, 16, 0xC1), 199: (0, 149, ord("Z")), 100: (1, 0, 0),
+               7: (0, 15, ord("c")), 8: (0, 16, ord("J"))}
+    for i, (which, pos, byte) in foreign.items():
+        (a if which == 0 else b)[i, pos] = byte
+    got, bad = E.lev_bitsqw(a, b, 20, PROTEIN)
+    assert bad == sorted(foreign)
+    for i in range(200):
+        if i in foreign:
+            assert got[i] == "untouched"
+        else:
+            assert got[i] == O.levenshtein_naive_k_with_opts(a[i].tobytes(), b[i].tobytes(), 20, False, (1, 1, 0, None))[0], i
+    assert E.lev_bitsqw(a, b, 20, b"ACGTacgt")[0] is None          # two cases: the codes collide at every shift a byte's other bits allow
+    assert E.lev_bitsqw(a, b, 20, b"AB0")[0] is None               # distinct codes, other bits differ
+    assert E.lev_bitsqw(a, b, 33, PROTEIN)[0] is None and E.lev_bitsqw(a, b, 31, PROTEIN, trans=True)[0] is None
+    sub = np.arange(0, 200, 3, dtype=np.uint32)
+    got, bad = E.lev_bitsqw(a, b, 20, PROTEIN, subset=sub)
+    assert bad == [i for i in sorted(foreign) if i % 3 == 0]
+    for i in range(200):
+        assert (got[i] == "untouched") == (i % 3 != 0 or i in foreign)

@@ -527,7 +527,7 @@ def test_small_alphabet_kernel(L, Lb, k, costs, alphabet):
     sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
     got = B.levenshtein_k_batch(sa, sb, k, costs, alphabet=alphabet).cpu().numpy().view(np.uint32)
     info = T.last_launch_info()
-    assert info["kernel"] == 7 and T.last_kernel_name().startswith("lev_bitsq_kernel"), (info, T.last_kernel_name())
+    assert info["kernel"] == 7 and T.last_kernel_name().startswith("lev_bitsq_kernel<"), (info, T.last_kernel_name())
     base = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
     assert T.last_launch_info()["kernel"] == 3
     assert np.array_equal(got, base), np.flatnonzero(got != base)[:10]
@@ -536,8 +536,79 @@ def test_small_alphabet_kernel(L, Lb, k, costs, alphabet):
     fr = np.sort(foreign)[:200]
     assert np.array_equal(got[fr], O.levenshtein_k_batch(O.csr_from_fixed(a[fr]), O.csr_from_fixed(b[fr]), k, costs))
     assert (base != 0xFFFFFFFF).sum() > 1000 and (base == 0xFFFFFFFF).sum() > 1000
-    # what the kernel does not cover runs the general path: wide bands, general costs, alphabets without a two-bit code
-    for kk, cc, al in [(40, costs, alphabet), (k, (2, 3, 1, None), alphabet), (k, costs, b"ACGTN"), (k, costs, b"@AQP")]:
+    # what the kernels do not cover runs the general path: wide bands, general costs, alphabets without a code (two cases of the letters;
+    # more than 32 symbols)
+    for kk, cc, al in [(40, costs, alphabet), (k, (2, 3, 1, None), alphabet), (k, costs, b"ACGTacgt"), (k, costs, bytes(range(40)))]:
         out = B.levenshtein_k_batch(sa, sb, kk, cc, alphabet=al).cpu().numpy().view(np.uint32)
         assert T.last_launch_info()["kernel"] != 7
         assert np.array_equal(out[:2000], O.levenshtein_k_batch(O.csr_from_fixed(a[:2000]), O.csr_from_fixed(b[:2000]), kk, cc))
+
+
+PROTEIN = b"ACDEFGHIKLMNPQRSTVWY"
+IUPAC = b"ACGTRYSWKMBDHVNU"
+
+
+@pytest.mark.parametrize("L,Lb,k,costs,alphabet", [(256, 256, 32, LEV, PROTEIN), (128, 128, 8, RDAM, IUPAC), (200, 190, 30, RDAM, PROTEIN),
+                                                   (96, 100, 20, LEV, b"0123456789"), (256, 256, 32, LEV, b"ACGTN"), (300, 310, 25, RDAM, bytes(range(0x60, 0x80)))])
+def test_alphabets_of_up_to_32_symbols(L, Lb, k, costs, alphabet):
+    """levenshtein_k_batch(..., alphabet=...) with 5 .. 32 symbols: the kernel of lev_bitsqw_body.h (dense rings of 64 rows per symbol, `b`
+    looked up by the byte) against the oracle on a sample and pair by pair against the byte-test kernels; pairs that hold a byte outside the
+    alphabet -- a code no symbol has, or a symbol's code under other high bits; first / last / middle positions of either string -- are
+    answered by the general kernel inside the same call."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n = 200_000 + 21
+    g = Dg.rng(L + Lb + k + len(alphabet))
+    sym = np.frombuffer(alphabet, dtype=np.uint8)
+    a = sym[g.integers(0, len(sym), size=(n, L))]
+    b = sym[g.integers(0, len(sym), size=(n, Lb))]
+    m = min(L, Lb)
+    near = g.random(n) < 0.6
+    b[near, :m] = a[near, :m]
+    for row in np.nonzero(near)[0][:20000]:
+        s = Dg.mutate(g, bytes(b[row]), int(g.integers(0, k + 3)), swaps=costs[3] is not None)
+        s = bytes(int(sym[c % len(sym)]) if c not in sym else c for c in s)       # fold what mutate() writes into the alphabet
+        s = (s + sym[g.integers(0, len(sym), size=Lb)].tobytes())[:Lb]
+        b[row] = np.frombuffer(s, dtype=np.uint8)
+    outside = [x for x in range(256) if x not in alphabet]
+    alias = [x for x in outside if any((x & 31) == (y & 31) for y in alphabet)]  # a symbol's low five bits under other high bits
+    foreign = g.choice(n, size=300, replace=False)
+    for t, row in enumerate(foreign):
+        byte = (alias if t % 4 == 0 and alias else outside)[int(g.integers(0, 1 << 30)) % len(alias if t % 4 == 0 and alias else outside)]
+        (a if t % 2 else b)[row, [0, (Lb if t % 2 == 0 else L) - 1, m // 2][t % 3]] = byte
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    got = B.levenshtein_k_batch(sa, sb, k, costs, alphabet=alphabet).cpu().numpy().view(np.uint32)
+    info = T.last_launch_info()
+    assert info["kernel"] == 7 and T.last_kernel_name().startswith("lev_bitsqw_kernel<"), (info, T.last_kernel_name())
+    base = B.levenshtein_k_batch(sa, sb, k, costs).cpu().numpy().view(np.uint32)
+    assert T.last_launch_info()["kernel"] == 3
+    assert np.array_equal(got, base), np.flatnonzero(got != base)[:10]
+    ns = 20000
+    assert np.array_equal(got[:ns], O.levenshtein_k_batch(O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns]), k, costs))
+    fr = np.sort(foreign)[:200]
+    assert np.array_equal(got[fr], O.levenshtein_k_batch(O.csr_from_fixed(a[fr]), O.csr_from_fixed(b[fr]), k, costs))
+    assert (base != 0xFFFFFFFF).sum() > 1000 and (base == 0xFFFFFFFF).sum() > 1000
+    # a second call right away (the two fallback counters take turns), then the same alphabet through the 2-bit kernel's call path again
+    again = B.levenshtein_k_batch(sa, sb, k, costs, alphabet=alphabet).cpu().numpy().view(np.uint32)
+    assert np.array_equal(again, base)
+
+
+def test_four_symbols_through_the_wide_alphabet_kernel(monkeypatch):
+    """TA_BITSQ_WIDE=1 sends a four-letter alphabet through the 5-bit-code kernel: the same answers as the 2-bit-code kernel."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n, L, k = 100_000, 256, 32
+    g = Dg.rng(99)
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a = sym[g.integers(0, 4, size=(n, L))]
+    b = a.copy()
+    pos = g.integers(0, L, size=(n, 24))
+    b[np.arange(n)[:, None], pos] = sym[g.integers(0, 4, size=(n, 24))]
+    b[::3] = sym[g.integers(0, 4, size=(len(b[::3]), L))]
+    sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+    narrow = B.levenshtein_k_batch(sa, sb, k, LEV, alphabet=b"ACGT").cpu().numpy()
+    assert T.last_kernel_name().startswith("lev_bitsq_kernel<")
+    monkeypatch.setenv("TA_BITSQ_WIDE", "1")
+    wide = B.levenshtein_k_batch(sa, sb, k, LEV, alphabet=b"ACGT").cpu().numpy()
+    assert T.last_kernel_name().startswith("lev_bitsqw_kernel<")
+    assert np.array_equal(narrow, wide)

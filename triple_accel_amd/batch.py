@@ -81,8 +81,8 @@ def _out(n, device):
 
 def levenshtein_k_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, out=None, alphabet=None):
     """out[i] = levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) as int32 (-1 == None).
-    alphabet: the (at most four) byte values the strings are written in, e.g. b"ACGT": the small-alphabet kernel (same answers;
-    pairs with other bytes are still answered, by the general kernel)."""
+    alphabet: the byte values the strings are written in -- up to four (b"ACGT") or up to 32 (IUPAC codes, the amino acids'
+    letters): the small-alphabet kernels (same answers; pairs with other bytes are still answered, by the general kernel)."""
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out
     cc = _costs(costs)._c()

@@ -50,6 +50,8 @@ struct LevParams {
     uint32_t tune = 0;        // bit 2 (4): `subset` is ordered by exact column count (VLINE form); bit 0: chunk form of the bit-parallel band kernel's fetch also for fixed-length batches (set by the launcher)
                               // bit 1: early out of the bit-parallel band kernels (ta_set_option(TA_OPT_EARLY_OUT, 1))
     uint32_t q_table = 0, q_shift = 0;       // lev_bitsq: byte c of q_table = the symbol with code c, code = (byte >> q_shift) & 3
+    uint32_t q_memb = 0, q_hi = 0, q_ns = 0; // lev_bitsqw (<= 32 symbols): code = (byte >> q_shift) & 31; bit c of q_memb: code c is a symbol; q_hi = mask of the
+                                             // bits outside the code | their value in every symbol << 8; q_ns = number of symbols
     uint32_t *q_bad_count = nullptr, *q_bad_list = nullptr;   // lev_bitsq: the pairs that hold a byte outside the alphabet
     uint32_t *q_next_count = nullptr;        // lev_bitsq: the NEXT pass's counter, zeroed by this pass (two counters taken in turn)
     const uint32_t *n_dev = nullptr;         // bit-parallel band kernels: the number of pairs, read on the device (a list a kernel before wrote)

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "lev_bitsq_body.h"
+#include "lev_bitsqw_body.h"
 #include "lev_plan.h"
 #include "ta_internal.h"
 
@@ -33,6 +34,54 @@ hipError_t lev_bitsq_launch(const LevParams &P0, bool trans, hipStream_t s, uint
     set_last_kernel_name("lev_bitsq_kernel<%s>", trans ? "true" : "false");
     if (trans) hipLaunchKernelGGL(lev_bitsq_kernel<true>, dim3(grid), dim3(64 * wpb), lds, s, P);
     else hipLaunchKernelGGL(lev_bitsq_kernel<false>, dim3(grid), dim3(64 * wpb), lds, s, P);
+    return hipGetLastError();
+}
+
+// ---- alphabets of up to 32 symbols (lev_bitsqw_body.h): LDS = the byte -> ring table of the workgroup + the wavefronts' rings
+constexpr int BITSQW_MAX_WAVES_PER_BLOCK = 8;
+
+template <bool TRANS>
+__global__ __launch_bounds__(64 * BITSQW_MAX_WAVES_PER_BLOCK) void lev_bitsqw_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using K = LevBitsQW<DevWave, TRANS>;
+    for (uint32_t i = threadIdx.x; i < K::TABLE_BYTES; i += blockDim.x) lds[i] = (uint8_t)lev_bitsqw_entry(i, P.q_shift, P.q_memb, P.q_hi);
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.q_next_count) *P.q_next_count = 0;   // nobody reads it before the next pass
+    for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
+        K::run(P, w, lds + K::TABLE_BYTES + wave * P.lds_per_wave, lds);
+}
+
+// P as for lev_bitsq_launch with P.q_shift / q_memb / q_hi / q_ns from lev_bitsqw_hash
+hipError_t lev_bitsqw_launch(const LevParams &P0, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
+    using K = LevBitsQW<DevWave, false>;
+    LevParams P = P0;
+    P.lds_per_wave = K::lds_per_wave(P.q_ns);
+    // wavefronts per workgroup x workgroups per CU: the most wavefronts the CU's 160 KB of LDS hold (the larger workgroup on a tie)
+    uint32_t wpb = 1, best = 0;
+    for (uint32_t blocks = 1; blocks <= 4; blocks++) {
+        const uint32_t room = 160u * 1024u / blocks;
+        if (room < K::TABLE_BYTES + P.lds_per_wave) break;
+        uint32_t w = (room - K::TABLE_BYTES) / P.lds_per_wave;
+        if (w > (uint32_t)BITSQW_MAX_WAVES_PER_BLOCK) w = BITSQW_MAX_WAVES_PER_BLOCK;
+        if (w * blocks > best) { best = w * blocks; wpb = w; }
+    }
+    if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITSQW_MAX_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
+    const uint32_t waves = (P.n + 63u) / 64u, grid = (waves + wpb - 1) / wpb;
+    const size_t lds = K::TABLE_BYTES + (size_t)P.lds_per_wave * wpb;
+    if (grid_out) *grid_out = grid;
+    if (lds_out) *lds_out = (uint32_t)lds;
+    if (grid == 0) return hipSuccess;
+    static bool attr_set = false;                      // (idempotent: a race sets it twice)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)lev_bitsqw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)lev_bitsqw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    set_last_kernel_name("lev_bitsqw_kernel<%s>", trans ? "true" : "false");
+    if (trans) hipLaunchKernelGGL(lev_bitsqw_kernel<true>, dim3(grid), dim3(64 * wpb), lds, s, P);
+    else hipLaunchKernelGGL(lev_bitsqw_kernel<false>, dim3(grid), dim3(64 * wpb), lds, s, P);
     return hipGetLastError();
 }
 

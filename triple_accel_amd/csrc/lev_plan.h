@@ -207,6 +207,28 @@ static inline bool lev_bitsq_hash(const uint8_t *sym, size_t n, uint32_t *shift_
     return false;
 }
 
+// The same for alphabets of 5 .. 32 symbols (lev_bitsqw_body.h): h in 0..3 with ((s >> h) & 31) distinct over the symbols AND the other
+// three bits of the byte the same in every symbol (the kernel verifies `a` by comparing them).  memb: bit c = code c is a symbol;
+// hi = (mask of the other bits) | (their common value << 8).
+static inline bool lev_bitsqw_hash(const uint8_t *sym, size_t n, uint32_t *shift_out, uint32_t *memb_out, uint32_t *hi_out) {
+    if (!sym || n == 0 || n > 32) return false;
+    for (uint32_t h = 0; h <= 3; h++) {
+        const uint32_t other = ~(31u << h) & 0xFFu;
+        uint32_t memb = 0;
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) {
+            const uint32_t c = (sym[i] >> h) & 31u;
+            if ((memb >> c) & 1u) ok = false;
+            memb |= 1u << c;
+            if ((sym[i] & other) != (sym[0] & other)) ok = false;
+        }
+        if (!ok) continue;
+        *shift_out = h; *memb_out = memb; *hi_out = other | ((sym[0] & other) << 8);
+        return true;
+    }
+    return false;
+}
+
 // ---- ONE pair, band of at most 64 diagonals (lev_one_body.h: match vectors 64 columns at a time, the recurrence on the scalar unit)
 static inline bool lev_one_applies(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc, uint64_t max_len, uint32_t *u_out) {
     const uint32_t u = lev_batch_unit_k(k, mc, gc, sg, max_len);

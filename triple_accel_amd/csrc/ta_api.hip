@@ -480,12 +480,14 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st, exact_columns);
 }
 
-/* ta_levenshtein_k_batch for strings written in a SMALL ALPHABET the caller names (at most four distinct byte values: DNA, RNA):
- * the column's match vector is then a table lookup (lev_bitsq_body.h) instead of a byte test -- the same answers, bit for bit.
+/* ta_levenshtein_k_batch for strings written in a SMALL ALPHABET the caller names (up to four byte values -- DNA, RNA: lev_bitsq_body.h;
+ * up to 32 -- IUPAC codes, amino acids: lev_bitsqw_body.h): the column's match vector is then a table lookup instead of a byte test --
+ * the same answers, bit for bit.
  * The promise is verified on the device, byte by byte: a pair that holds any other byte is answered by the general kernel in the
  * same call (a second, usually empty, launch over the list of such pairs; no host round trip).  Batches the small-alphabet kernel
- * does not cover (CSR batches, general EditCosts, bands beyond 33 diagonals, fewer than 16384 pairs, alphabets of more than four
- * symbols or without a two-bit code) run ta_levenshtein_k_batch as they are. */
+ * does not cover (CSR batches, general EditCosts, bands beyond 33 diagonals, fewer than 16384 pairs, alphabets of more than 32
+ * symbols or without a code: two bits for up to four symbols, else five bits with the byte's other three bits the same in every
+ * symbol -- one case of the letters, the digits) run ta_levenshtein_k_batch as they are. */
 int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                     const uint8_t *alphabet, size_t alphabet_len, uint32_t *out_dev, void *stream) {
     int rc = check_batch_args(a, b, n, out_dev);
@@ -496,11 +498,15 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     const bool fixed = !a->off && !b->off;
     const bool trans = costs->has_transpose != 0;
     const uint64_t max_len = fixed ? (a->len > b->len ? a->len : b->len) : 0;
-    uint32_t u = 0, q_shift = 0, q_table = 0;
+    uint32_t u = 0, q_shift = 0, q_table = 0, q_memb = 0, q_hi = 0;
     const bool pinned = env_int("TA_NO_BITS") || env_int("TA_FORCE_NA") || env_int("TA_BITS_STATIC") || env_int("TA_FORCE_D") || env_int("TA_NO_BITSQ");
     if (!fixed || pinned || !alphabet ||
         !lev_bitsq_applies(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, trans ? costs->transpose_cost : 0, max_len, true, n, &u) ||
-        !lev_bitsq_hash(alphabet, alphabet_len, &q_shift, &q_table))
+        alphabet_len == 0)
+        return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
+    // at most four symbols with a two-bit code: lev_bitsq_body.h; up to 32 with a five-bit code: lev_bitsqw_body.h
+    const bool narrow = !env_int("TA_BITSQ_WIDE") && lev_bitsq_hash(alphabet, alphabet_len, &q_shift, &q_table);
+    if (!narrow && (env_int("TA_NO_BITSQW") || !lev_bitsqw_hash(alphabet, alphabet_len, &q_shift, &q_memb, &q_hi)))
         return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
     hipStream_t st = (hipStream_t)stream;
     StreamGuard guard(st);
@@ -523,7 +529,7 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     P.subset = nullptr; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
     P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
     P.u = u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = 0; P.Tw = 0; P.ch = 0;
-    P.q_table = q_table; P.q_shift = q_shift; P.q_bad_count = counters + 8u * mine; P.q_bad_list = (uint32_t *)bad.dev;
+    P.q_table = q_table; P.q_shift = q_shift; P.q_memb = q_memb; P.q_hi = q_hi; P.q_ns = (uint32_t)alphabet_len; P.q_bad_count = counters + 8u * mine; P.q_bad_list = (uint32_t *)bad.dev;
     P.q_next_count = counters + 8u * (mine ^ 1u);
     ta_launch_info li = {};
     li.transpose = trans;
@@ -531,7 +537,8 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
     li.cell_bits = sel.cell_bits;
     uint32_t grid = 0, lds = 0;
-    TA_HIP(lev_bitsq_launch(P, trans, st, &grid, &lds));
+    if (narrow) TA_HIP(lev_bitsq_launch(P, trans, st, &grid, &lds));
+    else TA_HIP(lev_bitsqw_launch(P, trans, st, &grid, &lds));
     li.kernel = 7; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
     // the pairs that hold a byte outside the alphabet: the byte-test kernel over the list the first kernel wrote (its length is read
     // on the device; a small grid strides over it)
@@ -544,7 +551,7 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
     snprintf(name, sizeof(name), "%s", ta_last_kernel_name());
     TA_HIP(lev_bits_launch(F, bp, trans, max_len, st, nullptr, nullptr));
     set_last_kernel_name("%s", name);                   // the pass's dominant kernel is the first one
-    if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=%zu k=%u u=%u kernel=7 (small alphabet, shift %u table %08x) grid=%u lds=%u\n", n, k, u, q_shift, q_table, grid, lds);
+    if (env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] lev pass: n=%zu k=%u u=%u kernel=7 (small alphabet, %s, shift %u table %08x) grid=%u lds=%u\n", n, k, u, narrow ? "2-bit codes" : "5-bit codes", q_shift, narrow ? q_table : q_memb, grid, lds);
     g_last_launch = li;
     g_answer_single_store = false;
     clean = true;

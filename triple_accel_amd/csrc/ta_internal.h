@@ -83,6 +83,7 @@ hipError_t lev_bits_launch(const LevParams &P, const LevBitsPlan &pl, bool trans
 // the VLINE fetch form (lev_bits_vline.hip): CSR batches through the stride-8 window
 hipError_t lev_bits_vline_launch(const LevParams &P, const LevBitsPlan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bitsq_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
+hipError_t lev_bitsqw_launch(const LevParams &P, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_bits2_launch(const LevParams &P, const LevBits2Plan &pl, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out);
 hipError_t lev_one_launch(const LevParams &P, bool trans, uint64_t max_len, hipStream_t s, uint32_t *lds_out);
 bool lev_sliced_applies(const StrView &a, const StrView &b, uint32_t unit_k, uint32_t *strips_out);

@@ -54,6 +54,9 @@ struct DevWave {
     }
     // value barrier: stops instcombine from re-associating across it
     static __device__ __forceinline__ U32 opaque(U32 x) { asm volatile("" : "+v"(x)); return x; }
+    // a wave-uniform value the optimiser must take as new at this point (e.g. so that tests of a kernel argument's bits inside a loop stay
+    // scalar compares there instead of 64-bit condition masks hoisted out of it, two SGPRs apiece)
+    static __device__ __forceinline__ uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
     // acc + byte n of x * m  (m <= 255)  -> v_dot4_u32_u8 with a one-hot multiplier
     static __device__ __forceinline__ U32 dot4_byte(U32 x, int n, uint32_t m, U32 acc) {
         return __builtin_amdgcn_udot4(x, m << (8 * n), acc, false);
