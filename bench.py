@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 PROFILE_ROUND = "r04"
-ALPHABETS = {"dna": b"ACGT", "protein": b"ACDEFGHIKLMNPQRSTVWY", "iupac": b"ACGTRYSWKMBDHVNU"}      # --dist values passed with alphabet=...
+ALPHABETS = {"dna": b"ACGT", "dna5": b"ACGTN", "protein": b"ACDEFGHIKLMNPQRSTVWY", "iupac": b"ACGTRYSWKMBDHVNU"}      # --dist values passed with alphabet=...
 
 
 def parse_args():
@@ -49,10 +49,10 @@ def parse_args():
                          "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
     ap.add_argument("--needle-len", type=int, default=32, help="hsearch: needle bytes (8 / 32: shift-add scan; > 32: SWAR kernel)")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
-    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna", "protein", "iupac"],
+    ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna", "dna5", "protein", "iupac"],
                     help="ragged: CSR batch, lengths uniform on 32..L per pair (b within +-4 of a), random bytes; cells credited pair by pair; "
                          "dna: fixed-length strings over A C G T (half of the pairs mutated copies), passed with alphabet=b'ACGT' -- the small-alphabet kernel; "
-                         "protein / iupac: the same over the 20 amino-acid letters / the 16 IUPAC nucleotide codes -- the kernel for alphabets of up to 32 symbols")
+                         "dna5 / protein / iupac: the same over A C G T N / the 20 amino-acid letters / the 16 IUPAC nucleotide codes -- the kernel for alphabets of up to 32 symbols")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own batch; strong: the same batch partitioned over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -95,7 +95,8 @@ while time.time() < t_end:
             L = int(g.choice([24, 64, 128, 200, 256, 300]))
             Lb = max(1, L + int(g.integers(-6, 7)))
             k = int(g.choice([0, 3, 8, 12, 14, 15, 20, 30, 32, 33]))
-            sym = np.frombuffer(b"ACGT", dtype=np.uint8) if small else np.arange(alpha[0], alpha[1], dtype=np.uint8)
+            small_alphabet = [b"ACGT", b"ACGT", b"ACGTN", b"ACGTRYSWKMBDHVNU", b"ACDEFGHIKLMNPQRSTVWY", b"0123456789", b"acgu"][int(g.integers(0, 7))]
+            sym = np.frombuffer(small_alphabet, dtype=np.uint8) if small else np.arange(alpha[0], alpha[1], dtype=np.uint8)
             fa = sym[g.integers(0, len(sym), size=(n, L))]
             fb = sym[g.integers(0, len(sym), size=(n, Lb))]
             near = g.random(n) < 0.5
@@ -106,9 +107,11 @@ while time.time() < t_end:
             fb[rows[:, None], pos[rows]] = sym[g.integers(0, len(sym), size=(len(rows), 4))]
             alphabet = None
             if small:
-                alphabet = b"ACGT"
+                alphabet = small_alphabet
+                os.environ["TA_BITSQ_WIDE"] = "1" if g.random() < 0.6 else "0"      # the 5-bit-code kernel wherever it can run / where it pays
                 bad = g.choice(n, size=int(g.integers(0, 50)), replace=False)
-                fa[bad, g.integers(0, L, size=len(bad))] = ord("N")
+                outside = np.array([x for x in range(256) if x not in small_alphabet], dtype=np.uint8)
+                (fa if g.random() < 0.5 else fb)[bad, g.integers(0, m, size=len(bad))] = outside[g.integers(0, len(outside), size=len(bad))]
             if g.random() < 0.5 and not small:              # the same pairs as a CSR batch with ragged tails: taken in length order
                 la = g.integers(max(1, L - 40), L + 1, size=n); lb = np.minimum(Lb, np.maximum(1, la + g.integers(-5, 6, size=n)))
                 a = [fa[i, :la[i]].tobytes() for i in range(n)]; b = [fb[i, :lb[i]].tobytes() for i in range(n)]

@@ -550,13 +550,14 @@ IUPAC = b"ACGTRYSWKMBDHVNU"
 
 @pytest.mark.parametrize("L,Lb,k,costs,alphabet", [(256, 256, 32, LEV, PROTEIN), (128, 128, 8, RDAM, IUPAC), (200, 190, 30, RDAM, PROTEIN),
                                                    (96, 100, 20, LEV, b"0123456789"), (256, 256, 32, LEV, b"ACGTN"), (300, 310, 25, RDAM, bytes(range(0x60, 0x80)))])
-def test_alphabets_of_up_to_32_symbols(L, Lb, k, costs, alphabet):
+def test_alphabets_of_up_to_32_symbols(L, Lb, k, costs, alphabet, monkeypatch):
     """levenshtein_k_batch(..., alphabet=...) with 5 .. 32 symbols: the kernel of lev_bitsqw_body.h (dense rings of 64 rows per symbol, `b`
     looked up by the byte) against the oracle on a sample and pair by pair against the byte-test kernels; pairs that hold a byte outside the
     alphabet -- a code no symbol has, or a symbol's code under other high bits; first / last / middle positions of either string -- are
-    answered by the general kernel inside the same call."""
+    answered by the general kernel inside the same call.  (TA_BITSQ_WIDE=1: the kernel runs wherever it can, not only where it pays.)"""
     import triple_accel_amd as T
     from triple_accel_amd import batch as B
+    monkeypatch.setenv("TA_BITSQ_WIDE", "1")
     n = 200_000 + 21
     g = Dg.rng(L + Lb + k + len(alphabet))
     sym = np.frombuffer(alphabet, dtype=np.uint8)
@@ -612,3 +613,22 @@ def test_four_symbols_through_the_wide_alphabet_kernel(monkeypatch):
     wide = B.levenshtein_k_batch(sa, sb, k, LEV, alphabet=b"ACGT").cpu().numpy()
     assert T.last_kernel_name().startswith("lev_bitsqw_kernel<")
     assert np.array_equal(narrow, wide)
+
+
+def test_wide_alphabet_kernel_runs_where_it_pays():
+    """The default routing of alphabets of more than four symbols (ta_levenshtein_k_batch_alphabet; profiles/r04/ab_alphabet.md): the 5-bit-code
+    kernel for at most four groups of four codes at bands of 16 diagonals and more, the byte-test kernels otherwise -- the same answers."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    n, L = 60_000, 200
+    g = Dg.rng(5)
+    for alphabet, k, wide in ((b"ACGTN", 32, True), (b"ACGTN", 8, False), (PROTEIN, 32, False), (IUPAC, 20, False), (b"0123456789", 24, True)):
+        sym = np.frombuffer(alphabet, dtype=np.uint8)
+        a = sym[g.integers(0, len(sym), size=(n, L))]
+        b = a.copy()
+        pos = g.integers(0, L, size=(n, 12))
+        b[np.arange(n)[:, None], pos] = sym[g.integers(0, len(sym), size=(n, 12))]
+        sa, sb = B.Strings.from_fixed(a), B.Strings.from_fixed(b)
+        got = B.levenshtein_k_batch(sa, sb, k, LEV, alphabet=alphabet).cpu().numpy().view(np.uint32)
+        assert T.last_kernel_name().startswith("lev_bitsqw_kernel<") == wide, (alphabet, k, T.last_kernel_name())
+        assert np.array_equal(got[:3000], O.levenshtein_k_batch(O.csr_from_fixed(a[:3000]), O.csr_from_fixed(b[:3000]), k, LEV))

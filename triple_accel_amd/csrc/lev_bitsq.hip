@@ -41,7 +41,7 @@ hipError_t lev_bitsq_launch(const LevParams &P0, bool trans, hipStream_t s, uint
 constexpr int BITSQW_MAX_WAVES_PER_BLOCK = 8;
 
 template <bool TRANS>
-__global__ __launch_bounds__(64 * BITSQW_MAX_WAVES_PER_BLOCK) void lev_bitsqw_kernel(LevParams P) {
+__global__ __launch_bounds__(64 * BITSQW_MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void lev_bitsqw_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using K = LevBitsQW<DevWave, TRANS>;
     for (uint32_t i = threadIdx.x; i < K::TABLE_BYTES; i += blockDim.x) lds[i] = (uint8_t)lev_bitsqw_entry(i, P.q_shift, P.q_memb, P.q_hi);
@@ -57,14 +57,15 @@ hipError_t lev_bitsqw_launch(const LevParams &P0, bool trans, hipStream_t s, uin
     using K = LevBitsQW<DevWave, false>;
     LevParams P = P0;
     P.lds_per_wave = K::lds_per_wave(P.q_ns);
-    // wavefronts per workgroup x workgroups per CU: the most wavefronts the CU's 160 KB of LDS hold (the larger workgroup on a tie)
+    // wavefronts per workgroup x workgroups per CU: the most wavefronts (up to 16) the CU's 160 KB of LDS hold (the larger workgroup on a tie)
     uint32_t wpb = 1, best = 0;
     for (uint32_t blocks = 1; blocks <= 4; blocks++) {
-        const uint32_t room = 160u * 1024u / blocks;
+        const uint32_t room = 156u * 1024u / blocks;    // (4 KB of the 160 left to the allocation granule)
         if (room < K::TABLE_BYTES + P.lds_per_wave) break;
         uint32_t w = (room - K::TABLE_BYTES) / P.lds_per_wave;
         if (w > (uint32_t)BITSQW_MAX_WAVES_PER_BLOCK) w = BITSQW_MAX_WAVES_PER_BLOCK;
-        if (w * blocks > best) { best = w * blocks; wpb = w; }
+        const uint32_t total = w * blocks > 16u ? 16u : w * blocks;
+        if (total > best) { best = total; wpb = w; }
     }
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITSQW_MAX_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t waves = (P.n + 63u) / 64u, grid = (waves + wpb - 1) / wpb;

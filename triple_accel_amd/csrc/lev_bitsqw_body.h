@@ -4,21 +4,27 @@
 // Same recurrence, same 33-diagonal window, same band geometry and result contract as lev_bitsq_body.h (whose `column` this file calls):
 // the match vector of a column is the 33-bit window of the column character's row mask Peq[c], read from LDS.  What changes with the
 // alphabet's size:
-//   * Rings.  Peq[s] is a ring of 64 rows per symbol -- 2 dwords + a wrap copy of the first, 12 bytes -- and a pair holds one ring per
-//     symbol OF THE ALPHABET (dense, in code order): 20 symbols = 244 bytes per pair, 15.6 KB per wavefront (10 wavefronts per CU).  The
-//     rows a span of 16 columns reads and the rows committed ahead of it are at most 63 (run(): the piece a commit overwrites died a span
-//     ago), so 64 rows do.  A column is one ds_read_b64 at dword (row & 63) >> 5 of its symbol's ring and one v_alignbit by row & 31.
+//   * Rings.  Peq[s] is a ring of 64 rows per symbol -- 2 dwords, 8 bytes -- and a pair holds one ring per symbol OF THE ALPHABET (dense,
+//     in code order) plus one spare slot: 20 symbols = 172 bytes per pair, 11 KB per wavefront (14 wavefronts per CU; 16 up to 18
+//     symbols).  The rows a span of 16 columns reads and the rows committed ahead of it are at most 63 (run(): the piece a commit
+//     overwrites died a span ago), so 64 rows do.  A column is one ds_read_b64 of its symbol's ring; the 33 window bits start at bit
+//     g = row & 63 and run on from the second dword into the first when g >= 32 -- the two dwords trade places, a wave-uniform choice (two
+//     v_cndmask on a scalar condition) -- then one v_alignbit by g & 31.  The rings of eight columns are requested before the first runs.
 //   * `a`: symbols -> codes by a shift and a mask, code = (byte >> h) & 31, where the host found h with distinct codes over the alphabet
 //     whose OTHER three bits are the same in every symbol (lev_bitsqw_hash; one case of the letters, the digits: h = 0).  Every 16 rows the
-//     five code bit-planes of a 16-byte piece are packed by v_dot4_u32_u8 (as in lev_bitsq_body.h), the four / eight products of planes
-//     {0,1} / {2,3,4} are formed once, and each symbol of the alphabet is ONE v_and of two of them, written to its ring (the symbols are
-//     walked in code order under wave-uniform tests of the membership word).  The promise about the alphabet is verified: the three other
-//     bits of every byte are compared, and a row that no symbol's mask covers holds a code outside the alphabet.
+//     five code bit-planes of a 16-byte piece are packed by v_dot4_u32_u8 (as in lev_bitsq_body.h), and the mask of a code is ONE
+//     three-input operation on the product of planes {0,1} and the planes {2,3,4}.  The codes are walked in order, four (one product of
+//     planes 2..4) under ONE wave-uniform test of the membership word, nothing branching inside a group: a code that is no symbol writes
+//     its mask where the next symbol writes its own right after.  The promise about the alphabet is verified: the three other bits of
+//     every byte are compared, and a row that no symbol's mask covers holds a code outside the alphabet.
 //   * `b`: a column's ring is looked up BY THE BYTE ITSELF in a 256-entry table in LDS (one per workgroup, built by the kernel from h, the
-//     membership word and the other bits: entry = 3 * rank of the symbol, 0xFF for a byte outside the alphabet): one ds_read_u8 per
+//     membership word and the other bits: entry = 2 * rank of the symbol, 0xFF for a byte outside the alphabet): one ds_read_u8 per
 //     column, no hash, and the verification for free.
 //   * A pair that holds any byte outside the alphabet is not answered here (P.q_bad_list; the launcher's byte-test pass answers it).
-// Per column: the 15 (20 with transposition) instructions of the recurrence, 4 of lookups, ~ 9 of conversions for a 20-letter alphabet.
+// Measured (profiles/r04/ab_alphabet.md): 37 VALU + 19 scalar instructions per column of 64 pairs on the 20 amino acids (17 the recurrence
+// and the swap, 4 the lookups of `b`, 16 the conversion of `a`) against 41.9 + ~0 for the byte test of lev_bits_body.h at 16 wavefronts
+// per CU: 0.322 against 0.290 ms on cfg2's geometry.  It pays for few symbols in few groups of codes at wide bands (ACGTN: 0.272 against
+// 0.290) -- which is where ta_levenshtein_k_batch_alphabet sends batches here; the rest runs the byte-test kernels.
 #pragma once
 #include "lev_bitsq_body.h"
 
@@ -28,7 +34,7 @@ namespace ta {
 TA_HD inline uint32_t lev_bitsqw_entry(uint32_t byte, uint32_t shift, uint32_t memb, uint32_t hi) {
     const uint32_t code = (byte >> shift) & 31u;
     const bool ok = ((memb >> code) & 1u) != 0u && (byte & (hi & 0xFFu)) == ((hi >> 8) & 0xFFu);
-    return ok ? 3u * (uint32_t)__builtin_popcount(memb & ((1u << code) - 1u)) : 0xFFu;
+    return ok ? 2u * (uint32_t)__builtin_popcount(memb & ((1u << code) - 1u)) : 0xFFu;
 }
 
 template <class W, bool TRANS>
@@ -39,9 +45,9 @@ struct LevBitsQW {
     using Q = typename W::Q;
     using Base = LevBitsQ<W, TRANS>;
     using State = typename Base::State;
-    static constexpr uint32_t SYM_STRIDE = 12;                 // bytes per symbol: 2 ring dwords + the wrap copy
+    static constexpr uint32_t SYM_STRIDE = 8;                  // bytes per symbol: the ring's 2 dwords
     static constexpr uint32_t TABLE_BYTES = 256;
-    static TA_HD inline uint32_t pair_stride(uint32_t ns) { return 4u * ((3u * ns + 1u) | 1u); }     // an odd number of dwords
+    static TA_HD inline uint32_t pair_stride(uint32_t ns) { return 4u * ((2u * (ns + 1u) + 1u) | 1u); }   // + a spare slot; an odd number of dwords
     static TA_HD inline uint32_t lds_per_wave(uint32_t ns) { return 64u * pair_stride(ns); }
 
     // (the launcher guarantees: fixed-length batch, unit costs, band + transposition rows <= 33, P.q_shift / q_memb / q_hi / q_ns from
@@ -127,19 +133,25 @@ struct LevBitsQW {
             for (int j = 0; j < 4; j++) A[j] = ((j & 1) ? Pl[0] : ~Pl[0]) & ((j & 2) ? Pl[1] : ~Pl[1]);
 #pragma unroll
             for (int j = 0; j < 8; j++) B[j] = ((j & 1) ? Pl[2] : ~Pl[2]) & ((j & 2) ? Pl[3] : ~Pl[3]) & ((j & 4) ? Pl[4] : ~Pl[4]);
-            const uint32_t hw = 2u * (piece & 3u);             // the halfword's byte offset in the 8-byte ring
+            const uint32_t hw = 2u * (piece & 3u);             // the halfword's byte offset in the ring
             const U32 ring_hw = ring + hw;
             U32 seen = W::splat(0);
-            const uint32_t memb_now = W::opaque_s(memb);     // (tested here, bit by bit, on the scalar unit)
-            U32 at = ring_hw;                                  // (a register walks the rings: offsets in scalars would be 32 loop invariants)
+            // The symbols are walked in code order, four codes (one product of planes 2..4) under ONE wave-uniform test; inside a group
+            // nothing branches: a code that is no symbol writes its mask where the next symbol will write its own right after (the
+            // address does not move on), and the slot behind the last ring takes what follows the last symbol.
+            const uint32_t memb_now = W::opaque_s(memb);
+            U32 at = ring_hw;
 #pragma unroll
-            for (int code = 0; code < 32; code++) {
-                if ((memb_now >> code) & 1u) {                 // wave-uniform: the symbols of the alphabet, in code order
-                    const U32 M = A[code & 3] & B[code >> 2];
-                    seen = seen | M;
-                    W::lds_write16(lds, at, M);
-                    if (hw < 4u) W::lds_write16(lds, at + 8u, M);                   // the wrap copy of the ring's first dword
-                    at = at + SYM_STRIDE;
+            for (int grp = 0; grp < 8; grp++) {
+                if ((memb_now >> (4 * grp)) & 15u) {           // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t is_sym = (memb_now >> (4 * grp + j)) & 1u;
+                        const U32 M = A[j] & B[grp];
+                        seen = seen | (M & (0u - is_sym));
+                        W::lds_write16(lds, at, M);
+                        at = at + SYM_STRIDE * is_sym;
+                    }
                 }
             }
             // a row of the string that no symbol's mask covers holds a code outside the alphabet
@@ -163,12 +175,18 @@ struct LevBitsQW {
             }
             if ((piece & 7u) == 7u) fetch(SB, bptr, blen_u, (int32_t)(piece >> 3) + 1);
         };
-        // column t + 1: the window's top row is a[t - d_hi]
-        auto col = [&](uint32_t t, U32 ring_of_symbol) {
-            const uint32_t g = (t - dhi) & 63u, w4 = (g >> 5) << 2, s = g & 31u;
-            U32 lo, hi;
-            W::lds_read64(lds, ring_of_symbol + w4, lo, hi);
+        // column t + 1: the window's top row is a[t - d_hi], bit g = (t - d_hi) & 63 of the ring; the 33 window bits run on from the ring's
+        // second dword into its first (rows 64 on) when g >= 32: the two dwords trade places (a wave-uniform choice)
+        auto window = [&](uint32_t t, U32 x0, U32 x1) {
+            const uint32_t g = (t - dhi) & 63u, s = g & 31u;
+            const bool up = g >= 32u;
+            const U32 lo = up ? x1 : x0, hi = up ? x0 : x1;
             Base::column(st, W::alignbit_rt(hi, lo, s), W::shr_u(hi, s));
+        };
+        auto col = [&](uint32_t t, U32 ring_of_symbol) {
+            U32 x0, x1;
+            W::lds_read64(lds, ring_of_symbol, x0, x1);
+            window(t, x0, x1);
         };
 
         fetch(SA, aptr, alen_u, 0);
@@ -187,8 +205,15 @@ struct LevBitsQW {
             if (nacc == 32u) { cnt = W::bcnt(st.acc, cnt); nacc = 0; }
             const uint32_t left = blen_u - t;
             if (left >= 16u) {
+                // the rings of eight columns are requested before the first of them runs: one LDS latency per eight columns
 #pragma unroll
-                for (int c = 0; c < 16; c++) col(t + (uint32_t)c, ba[c]);
+                for (int h = 0; h < 2; h++) {
+                    U32 x0[8], x1[8];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) W::lds_read64(lds, ba[8 * h + c], x0[c], x1[c]);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) window(t + (uint32_t)(8 * h + c), x0[c], x1[c]);
+                }
                 nacc += 16u;
             } else {                                           // the batch's last columns
 #pragma unroll

@@ -505,9 +505,19 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
         alphabet_len == 0)
         return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
     // at most four symbols with a two-bit code: lev_bitsq_body.h; up to 32 with a five-bit code: lev_bitsqw_body.h
-    const bool narrow = !env_int("TA_BITSQ_WIDE") && lev_bitsq_hash(alphabet, alphabet_len, &q_shift, &q_table);
-    if (!narrow && (env_int("TA_NO_BITSQW") || !lev_bitsqw_hash(alphabet, alphabet_len, &q_shift, &q_memb, &q_hi)))
-        return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
+    const bool force_wide = env_int("TA_BITSQ_WIDE") != 0;
+    const bool narrow = !force_wide && lev_bitsq_hash(alphabet, alphabet_len, &q_shift, &q_table);
+    if (!narrow) {
+        if (env_int("TA_NO_BITSQW") || !lev_bitsqw_hash(alphabet, alphabet_len, &q_shift, &q_memb, &q_hi))
+            return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
+        // Where the 5-bit-code kernel pays (measured, profiles/r04/ab_alphabet.md): its per-16-rows conversion grows with the groups of
+        // four codes that hold a symbol, and narrow bands have the two-pairs-per-lane byte test.  Beyond 4 groups (IUPAC's 16 letters
+        // and the 20 amino acids: 7) or at 15 diagonals and fewer the byte-test kernels are as fast or faster: the general path runs.
+        uint32_t groups = 0;
+        for (uint32_t g4 = 0; g4 < 8; g4++) groups += ((q_memb >> (4u * g4)) & 15u) ? 1u : 0u;
+        if (!force_wide && (groups > 4 || (uint64_t)u + 1u + (trans ? 2u : 0u) <= 15u))
+            return ta_levenshtein_k_batch(a, b, n, k, costs, out_dev, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     StreamGuard guard(st);
     Scratch &bad = tls_scratch(15), &cnt = tls_scratch(16);
