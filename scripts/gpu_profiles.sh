@@ -18,6 +18,8 @@ flags() {   # tag -> bench.py flags
     cfg2_mutated) echo "--workload cfg2 --dist mutated" ;;
     cfg2_ragged) echo "--workload cfg2 --dist ragged" ;;
     cfg2_dna) echo "--workload cfg2 --dist dna" ;;
+    cfg2_dna5) echo "--workload cfg2 --dist dna5" ;;
+    cfg2_protein_table) echo "--workload cfg2 --dist protein" ;;
     cfg2_ragged_vline) echo "--workload cfg2 --dist ragged" ;;
     hsearch8) echo "--workload hsearch --needle-len 8" ;;
     hsearch32) echo "--workload hsearch --needle-len 32" ;;
@@ -26,9 +28,11 @@ flags() {   # tag -> bench.py flags
   esac
 }
 steps() { case $1 in cfg3) echo "--steps 3 --warmup 1" ;; cfg5|hsearch*|cfg2t) echo "--steps 10 --warmup 2" ;; cfg2) echo "" ;; *) echo "--steps 50" ;; esac; }
-# (cfg2_ragged_vline: the ragged batch through the VLINE fetch form, TA_TUNING=1 TA_BITS_VLINE=1 -- an A/B row, not a default path)
-TAGS="cfg2 cfg2_mutated cfg4 cfg1 cfg5 cfg3 cfg2w cfg4w cfg2l cfg2s cfg2t cfg2_ragged cfg2_ragged_vline cfg2_dna hsearch8 hsearch32 hsearch64"
-envof() { case $1 in cfg2_ragged_vline) echo "TA_TUNING=1 TA_BITS_VLINE=1" ;; *) echo "TA_NOENV=1" ;; esac; }
+# (cfg2_ragged_vline: the ragged batch through the VLINE fetch form, TA_TUNING=1 TA_BITS_VLINE=1 -- an A/B row, not a default path;
+#  cfg2_protein_table: the 20 amino acids through the 5-bit-code small-alphabet kernel, TA_BITSQ_WIDE=1 -- an A/B row too: the default runs the byte test;
+#  cfg2_dna5: A C G T N, where the default IS that kernel)
+TAGS="cfg2 cfg2_mutated cfg4 cfg1 cfg5 cfg3 cfg2w cfg4w cfg2l cfg2s cfg2t cfg2_ragged cfg2_ragged_vline cfg2_dna cfg2_dna5 cfg2_protein_table hsearch8 hsearch32 hsearch64"
+envof() { case $1 in cfg2_ragged_vline) echo "TA_TUNING=1 TA_BITS_VLINE=1" ;; cfg2_protein_table) echo "TA_TUNING=1 TA_BITSQ_WIDE=1" ;; *) echo "TA_NOENV=1" ;; esac; }
 for tag in $TAGS; do
   nocpu="--no-cpu --no-pmc"; [ $tag = cfg2 ] && nocpu=""       # (cfg2: the driver's command -- cpu_baseline leg and the live counter passes included)
   env $(envof $tag) timeout 900 python bench.py $(flags $tag) $(steps $tag) $nocpu > $O/bench_$tag.json 2> $O/bench_$tag.err

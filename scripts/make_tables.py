@@ -52,7 +52,7 @@ def main():
     out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
             "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
     for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg3", "cfg5", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "cfg2_ragged", "cfg2_ragged_vline", "cfg2_dna",
-               "hsearch8", "hsearch32", "hsearch64", "cfg2_early_out", "cfg2_2m"):
+               "cfg2_dna5", "cfg2_protein_table", "hsearch8", "hsearch32", "hsearch64", "cfg2_early_out", "cfg2_2m"):
         b = J("bench_%s.json" % wl)
         if not b:
             continue
@@ -77,7 +77,7 @@ def main():
             "over A C G T through the small-alphabet kernel; cfg2_early_out: `ta_set_option(TA_OPT_EARLY_OUT)` on the random batch -- same answers, "
             "data-dependent work, NOT a headline figure; cfg2_2m: 2M pairs per pass; cfg2l / cfg2s: cfg2's geometry under EditCosts(2,3,0,None) -- DP band kernel, linear "
             "gaps -- and (2,2,0,None) = unit costs x 2 on the bit-parallel kernel; cfg2t: every pair traced, ta_levenshtein_trace_batch (bytes: strings + records are "
-            "NOT counted, only strings, distances and the scripts written); cfg2_ragged_vline: the ragged batch through the VLINE fetch form, an A/B row; "
+            "NOT counted, only strings, distances and the scripts written); cfg2_ragged_vline: the ragged batch through the VLINE fetch form, an A/B row; cfg2_dna5: strings over A C G T N -- the 5-bit-code small-alphabet kernel, the default there; cfg2_protein_table: the 20 amino acids FORCED through that kernel (TA_BITSQ_WIDE=1), an A/B row -- the default runs the byte test at cfg2's rate, ab_alphabet.md; "
             "hsearchN: hamming_search of an N-byte needle over 1 GiB, k = N / 4, cells = N byte compares per offset.)", ""]
     e2e = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg5", "cfg1", "cfg2_ragged")]
     out += ["## Host buffers in, answers out (`end_to_end_ms`: pinned H2D of the batch + the pass + D2H; never the headline)", "",
@@ -99,7 +99,7 @@ def main():
     for wl, needle in (("cfg2", "lev_bits_"), ("cfg4", "lev_bits"), ("cfg3", "lev_widebits_kernel"), ("cfg3", "bag_bound"), ("cfg5", "lev_filter_kernel"),
                        ("cfg5", "lev_search_wave_kernel"), ("cfg1", "hamming"), ("cfg2w", "lev_band_kernel"), ("cfg4w", "lev_band_kernel"),
                        ("cfg2_ragged", "lev_bits_"), ("cfg2_ragged", "len_hist"), ("cfg2_ragged", "len_scan"), ("cfg2_ragged", "len_scatter"),
-                       ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8"), ("cfg2_ragged_vline", "lev_bits_s8v"), ("cfg2_ragged_vline", "len_scatter"),
+                       ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8"), ("cfg2_dna5", "lev_bitsqw_kernel"), ("cfg2_protein_table", "lev_bitsqw_kernel"), ("cfg2_ragged_vline", "lev_bits_s8v"), ("cfg2_ragged_vline", "len_scatter"),
                        ("cfg2l", "lev_band_score"), ("cfg2s", "lev_bits_line"), ("cfg2s", "scale_results"), ("cfg2t", "lev_band_trace_kernel"), ("cfg2t", "lev_trace_walk"),
                        ("hsearch8", "hamming_search"), ("hsearch32", "hamming_search"), ("hsearch64", "hamming_search")):
         k = kernel_us(wl, needle)

@@ -23,6 +23,8 @@ ROWS = [("cfg2", "cfg2 1M×256 B, k=32 (the headline)", "bit-parallel band, stri
         ("cfg2_ragged", "cfg2 ragged: 1M pairs, lengths uniform on 32..256, k=32 (CSR)", "counting sort, longest first + stride-8 window, chunk-form fetch"),
         ("cfg2_ragged_vline", "the same through the VLINE fetch form (`TA_BITS_VLINE=1`, an A/B row)", "counting sort on exact lengths + stride-8 window, VLINE fetch"),
         ("cfg2_dna", "cfg2 on DNA: 1M×256 B over A C G T, k=32", "small-alphabet kernel (§3.2d)"),
+        ("cfg2_dna5", "cfg2 over A C G T N (5 symbols), k=32", "5-bit-code small-alphabet kernel (§3.2d; the default for ≤ 4 groups of codes at ≥ 16 diagonals)"),
+        ("cfg2_protein_table", "cfg2 over the 20 amino acids, k=32, FORCED through the 5-bit-code kernel (`TA_BITSQ_WIDE=1`, an A/B row: the default is the byte test, 0.290)", "5-bit-code small-alphabet kernel"),
         ("hsearch8", "hamming_search, 8 B needle over 1 GiB, k=2", "SWAR, 16 offsets per lane, NUL scan fused"),
         ("hsearch32", "hamming_search, 32 B needle over 1 GiB, k=8", "bit-sliced counters (4 planes), NUL scan fused"),
         ("hsearch64", "hamming_search, 64 B needle over 1 GiB, k=16", "SWAR, 16 offsets per lane")]

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "lev_bitsq_body.h"
 #include "lev_bitsqw_body.h"
 #include "lev_plan.h"
@@ -73,12 +75,17 @@ hipError_t lev_bitsqw_launch(const LevParams &P0, bool trans, hipStream_t s, uin
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
-    static bool attr_set = false;                      // (idempotent: a race sets it twice)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)lev_bitsqw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // workgroups of more than 64 KB of dynamic LDS need the attribute, once per device (idempotent: a race sets it twice)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+        e = hipFuncSetAttribute((const void *)lev_bitsqw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)lev_bitsqw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     set_last_kernel_name("lev_bitsqw_kernel<%s>", trans ? "true" : "false");
     if (trans) hipLaunchKernelGGL(lev_bitsqw_kernel<true>, dim3(grid), dim3(64 * wpb), lds, s, P);
