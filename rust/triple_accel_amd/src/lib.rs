@@ -29,6 +29,10 @@ mod ffi {
     pub struct TaEditCosts { pub mismatch_cost: u8, pub gap_cost: u8, pub start_gap_cost: u8, pub has_transpose: u8, pub transpose_cost: u8 }
     #[repr(C)] pub struct TaMatch { pub start: u64, pub end: u64, pub k: u32, pub pad_: u32 }
     #[repr(C)] pub struct TaEdit { pub edit: u32, pub pad_: u32, pub count: u64 }
+    /// `ta_strings` (include/triple_accel_amd.h): string i of a batch is `blob[off[i] .. off[i+1])` (CSR, n + 1 device offsets) or,
+    /// with `off` null, `blob[i * stride .. i * stride + len)`.  All pointers are DEVICE memory.
+    #[repr(C)] #[derive(Copy, Clone)]
+    pub struct TaStrings { pub blob: *const u8, pub off: *const u64, pub stride: u64, pub len: u64, pub max_len: u64 }
     pub const TA_NONE: u32 = 0xFFFF_FFFF;
     #[link(name = "triple_accel_amd")]
     extern "C" {
@@ -53,8 +57,13 @@ mod ffi {
         pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                  search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_free(p: *mut c_void);
+        pub fn ta_levenshtein_k_batch(a: *const TaStrings, b: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
+                                      out_dev: *mut u32, stream: *mut c_void) -> c_int;
+        pub fn ta_levenshtein_exp_batch(a: *const TaStrings, b: *const TaStrings, n: usize, costs: *const TaEditCosts,
+                                        out_dev: *mut u32, stream: *mut c_void) -> c_int;
+        pub fn ta_hamming_batch(a: *const TaStrings, b: *const TaStrings, n: usize, out_dev: *mut u32, stream: *mut c_void) -> c_int;
         pub fn ta_levenshtein_trace_batch(a: *const TaStrings, b: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
-                                          out_dev: *mut u32, edits_dev: *mut c_void, n_edits_dev: *mut u32, cap: usize, stream: *mut c_void) -> c_int;
+                                          out_dev: *mut u32, edits_dev: *mut TaEdit, n_edits_dev: *mut u32, cap: usize, stream: *mut c_void) -> c_int;
         pub fn ta_thread_release();
         pub fn ta_device_count() -> c_int;
         pub fn ta_queue_create(k: u32, costs: *const TaEditCosts, out: *mut *mut c_void) -> c_int;
@@ -363,6 +372,34 @@ pub mod levenshtein {
     /// src/levenshtein.rs:1549
     pub fn levenshtein_search_naive<'a>(needle: &'a [u8], haystack: &'a [u8]) -> Box<dyn Iterator<Item = Match> + 'a> {
         levenshtein_search_simd(needle, haystack)
+    }
+}
+
+/// Batches of pairs RESIDENT IN HBM (no reference analogue: the reference answers one pair per call).  The caller owns the device
+/// buffers (any HIP allocation: `hipMalloc`, a torch tensor's `data_ptr()`); `stream` is a `hipStream_t` (null = the default
+/// stream); the calls enqueue kernels and return, results are device memory too (`u32` per pair, `0xFFFF_FFFF` = `None`).
+pub mod device {
+    use super::ffi::*;
+    use super::levenshtein::EditCosts;
+    use super::*;
+    pub use super::ffi::{TaEdit, TaStrings};
+
+    /// N x `levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs)`
+    pub unsafe fn levenshtein_k_batch(a: &TaStrings, b: &TaStrings, n: usize, k: u32, costs: EditCosts, out_dev: *mut u32, stream: *mut c_void) {
+        check(ta_levenshtein_k_batch(a, b, n, k, &costs.raw(), out_dev, stream));
+    }
+    /// N x `levenshtein_exp_with_opts(a_i, b_i, false, costs)`
+    pub unsafe fn levenshtein_exp_batch(a: &TaStrings, b: &TaStrings, n: usize, costs: EditCosts, out_dev: *mut u32, stream: *mut c_void) {
+        check(ta_levenshtein_exp_batch(a, b, n, &costs.raw(), out_dev, stream));
+    }
+    /// N x `hamming(a_i, b_i)` (`0xFFFF_FFFF` where the lengths differ)
+    pub unsafe fn hamming_batch(a: &TaStrings, b: &TaStrings, n: usize, out_dev: *mut u32, stream: *mut c_void) {
+        check(ta_hamming_batch(a, b, n, out_dev, stream));
+    }
+    /// N x `levenshtein_simd_k_with_opts(a_i, b_i, k, true, costs)`: distances, run counts and `cap` `TaEdit` records per pair
+    pub unsafe fn levenshtein_trace_batch(a: &TaStrings, b: &TaStrings, n: usize, k: u32, costs: EditCosts, out_dev: *mut u32,
+                                          edits_dev: *mut TaEdit, n_edits_dev: *mut u32, cap: usize, stream: *mut c_void) {
+        check(ta_levenshtein_trace_batch(a, b, n, k, &costs.raw(), out_dev, edits_dev, n_edits_dev, cap, stream));
     }
 }
 

@@ -70,26 +70,134 @@ def test_product_never_touches_the_oracle():
                 assert "ta_oracle" not in text and "oracle_lib" not in text and "libta_emu" not in text, f
 
 
-def _c_arity(header, name):
-    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)            # declarations only: comments name functions too
-    m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, code, re.S)
-    assert m, name
-    args = m.group(1).strip()
-    return 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+def _shim_texts():
+    header = open(os.path.join(ROOT, "include", "triple_accel_amd.h")).read()
+    rs = open(os.path.join(ROOT, "rust", "triple_accel_amd", "src", "lib.rs")).read()
+    return header, rs
+
+
+def _shim_problems(header, rs):
+    """What rustc's name resolution + an FFI lint would say about the shim's `extern "C"` boundary (there is no rustc here):
+    undefined type names, #[repr(C)] structs that differ from the header's, parameter / return TYPES that differ."""
+    import rust_shim_check as R
+    problems = []
+    known = R.defined_types(rs) | R.PRIMITIVES
+    fns, hfns = R.extern_fns(rs), R.header_fns(header)
+    assert len(fns) >= 10
+    for name, (params, ret) in fns.items():
+        for pname, ty in params + ([("return", ret)] if ret else []):
+            for ident in R.type_idents(ty):
+                if ident not in known:
+                    problems.append("%s: type `%s` of `%s` is not defined in the crate" % (name, ident, pname))
+        if name not in hfns:
+            problems.append("%s: not declared in the header" % name)
+            continue
+        hparams, hret = hfns[name]
+        if len(hparams) != len(params):
+            problems.append("%s: %d parameters, the header has %d" % (name, len(params), len(hparams)))
+            continue
+        for (pname, ty), (hname, hty) in zip(params, hparams):
+            want = R.c_to_rust(hty)
+            if ty != want:
+                problems.append("%s: parameter `%s` is `%s`, the header's `%s %s` needs `%s`" % (name, pname, ty, hty, hname, want))
+        want_ret = None if hret == "void" else R.c_to_rust(hret)
+        if ret != want_ret:
+            problems.append("%s: returns `%s`, the header says `%s`" % (name, ret, hret))
+    structs, hstructs = R.repr_c_structs(rs), R.header_structs(header)
+    for hname, rname in R.C_STRUCTS.items():
+        if rname == "c_void" or rname not in structs:
+            continue                                       # opaque handles; structs the shim does not bind
+        want = [(n, R.c_to_rust(t)) for n, t in hstructs[hname]]
+        if structs[rname] != want:
+            problems.append("struct %s: fields %r, the header's %s has %r" % (rname, structs[rname], hname, want))
+    for rname in structs:
+        if rname not in R.C_STRUCTS.values():
+            problems.append("struct %s: #[repr(C)] without a header counterpart" % rname)
+    return problems
 
 
 def test_rust_shim_extern_block_matches_the_header():
-    """Every `extern "C"` item of rust/triple_accel_amd/src/lib.rs is declared in include/triple_accel_amd.h with the same
-    number of parameters (there is no rustc here to do the check)."""
-    header = open(os.path.join(ROOT, "include", "triple_accel_amd.h")).read()
-    rs = open(os.path.join(ROOT, "rust", "triple_accel_amd", "src", "lib.rs")).read()
-    block = rs[rs.index('extern "C" {'):]
-    block = block[:block.index("\n    }")]
-    fns = re.findall(r"pub fn (ta_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->\s*[A-Za-z_0-9:]+)?\s*;", block, re.S)
-    assert len(fns) >= 10
-    for name, args in fns:
-        n_rs = len([a for a in args.split(",") if a.strip()])
-        assert n_rs == _c_arity(header, name), (name, n_rs, _c_arity(header, name))
+    """Every `extern "C"` item of rust/triple_accel_amd/src/lib.rs against include/triple_accel_amd.h: every type name it uses is
+    defined in the crate, parameter and return TYPES are the header's (pointer depth and constness included), and every
+    #[repr(C)] struct has the header struct's fields in the header's order and widths."""
+    header, rs = _shim_texts()
+    assert _shim_problems(header, rs) == []
+
+
+def test_rust_shim_checker_catches_the_round_4_defects():
+    """The checker must fail on what slipped through rounds 1-4: a type used in the extern block that the crate never defines
+    (`TaStrings`), a wrong pointer type, a struct whose fields drift from the header."""
+    header, rs = _shim_texts()
+    import re as _re
+    no_struct = _re.sub(r"#\[repr\(C\)\] #\[derive\(Copy, Clone\)\]\s*pub struct TaStrings \{[^}]*\}", "", rs)
+    assert no_struct != rs
+    assert any("`TaStrings`" in p and "not defined" in p for p in _shim_problems(header, no_struct))
+    wrong_ptr = rs.replace("edits_dev: *mut TaEdit, n_edits_dev", "edits_dev: *mut c_void, n_edits_dev")
+    assert wrong_ptr != rs and any("edits_dev" in p for p in _shim_problems(header, wrong_ptr))
+    drift = rs.replace("pub struct TaMatch { pub start: u64, pub end: u64, pub k: u32, pub pad_: u32 }",
+                       "pub struct TaMatch { pub start: u64, pub end: u64, pub k: u64 }")
+    assert drift != rs and any(p.startswith("struct TaMatch") for p in _shim_problems(header, drift))
+    arity = rs.replace("pub fn ta_free(p: *mut c_void);", "pub fn ta_free(p: *mut c_void, q: usize);")
+    assert arity != rs and any(p.startswith("ta_free") for p in _shim_problems(header, arity))
+
+
+def test_rust_shim_signatures_only_name_known_types():
+    """Name resolution over the WHOLE file, not only the extern block: every type identifier in any `fn` signature or struct
+    field is defined in the crate, imported, a generic parameter of that item, or in the std prelude."""
+    import rust_shim_check as R
+    _, rs = _shim_texts()
+    code = R.strip_rust_comments(rs)
+    prelude = {"Option", "Some", "None", "Vec", "Box", "Iterator", "IntoIterator", "PartialEq", "Self", "String", "Result",
+               "Item", "Copy", "Clone", "Drop", "std", "vec", "IntoIter", "self"}
+    known = R.defined_types(rs) | R.PRIMITIVES | prelude
+    sigs = re.findall(r"\bfn\s+\w+\s*(<[^>]*>)?\s*\(([^{;]*?)\)\s*(->\s*[^{;]+?)?\s*(?:where\s+([^{;]+?))?\s*[{;]", code, re.S)
+    assert len(sigs) > 60
+    for generics, params, ret, where in sigs:
+        local = set(re.findall(r"[A-Za-z_]\w*", generics or ""))
+        for p in R._split_top(params):
+            if ":" not in p:
+                continue                                   # `self`, `&self`, `&mut self`
+            ty = p.split(":", 1)[1]
+            for ident in R.type_idents(re.sub(r"'\w+", "", ty)):
+                assert ident in known or ident in local, (ident, p)
+        for ident in R.type_idents(re.sub(r"'\w+", "", (ret or "").lstrip("->"))):
+            assert ident in known or ident in local, (ident, ret)
+    for body in re.findall(r"\bstruct\s+\w+\s*(?:<[^>]*>)?\s*\{([^}]*)\}", code, re.S):
+        for f in R._split_top(body):
+            for ident in R.type_idents(re.sub(r"'\w+", "", f.split(":", 1)[1])):
+                assert ident in known, (ident, f)
+
+
+def test_rust_shim_cargo_check():
+    """Opt-in: where a Rust toolchain exists (not in the build image), `cargo check` must pass on the shim crate."""
+    import shutil
+    import subprocess
+    cargo = shutil.which("cargo")
+    if not cargo:
+        pytest.skip("no cargo on this box")
+    crate = os.path.join(ROOT, "rust", "triple_accel_amd")
+    env = dict(os.environ, TRIPLE_ACCEL_AMD_LIB_DIR=os.path.join(ROOT, "triple_accel_amd"), CARGO_TARGET_DIR="/tmp/ta_cargo_target")
+    r = subprocess.run([cargo, "check", "--offline", "--lib"], cwd=crate, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_integration_md_shim_excerpt_is_the_crate():
+    """INTEGRATION.md section 2 quotes the shim: every code line of the excerpt must be a line of the shipped crate
+    (round 4's excerpt had drifted: an `rc == 6` branch that would have recursed into the same GPU call)."""
+    _, rs = _shim_texts()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```rust\n(.*?)```", md, re.S)
+    assert blocks
+    have = {" ".join(l.split()) for l in rs.splitlines()}
+    n = 0
+    for b in blocks:
+        for line in b.splitlines():
+            line = " ".join(line.split())
+            if not line or line.startswith("// ...") or line == "...":
+                continue
+            assert line in have, "INTEGRATION.md quotes a line that is not in the crate: %r" % line
+            n += 1
+    assert n > 40
 
 
 def test_every_reference_pub_fn_has_a_mirror():
