@@ -43,10 +43,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "hsearch"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5w", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "hsearch"],
                     help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
                          "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel; hsearch = hamming_search of a --needle-len byte needle "
                          "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
+    ap.add_argument("--costs", default="2,3,1,-",
+                    help="cfg5w: cfg5's geometry (32 B needle, 1 GiB shard, k = 16, Best) under these EditCosts, as mismatch,gap,start_gap,transpose "
+                         "('-' = None): the unit-cost scan as a SUPERSET filter with k' = srch_filter_k + the exact kernel on the flagged blocks")
     ap.add_argument("--needle-len", type=int, default=32, help="hsearch: needle bytes (8 / 32: shift-add scan; > 32: SWAR kernel)")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
     ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna", "dna5", "protein", "iupac"],
@@ -64,6 +67,9 @@ def parse_args():
                     help="enqueue the K timed passes one by one; default: captured once into ONE hipGraph (where the pass is a pure kernel "
                          "launch: the fixed-length pair batches) and replayed inside the barrier-to-barrier region -- the same K passes, "
                          "without K trips through Python / ctypes / the runtime's launch path while the clock runs")
+    ap.add_argument("--no-side-batch", action="store_true",
+                    help="parity gate without its side batch of 2,048 mutated pairs (the counter passes use this: one more launch of the same "
+                         "kernel would enter their per-pass averages)")
     ap.add_argument("--early-out", action="store_true",
                     help="ta_set_option(TA_OPT_EARLY_OUT): wavefronts stop once none of their pairs can end at or below k -- same answers, "
                          "data-dependent work; NOT the headline (the reference evaluates its whole band): the line says so in config.early_out")
@@ -291,10 +297,32 @@ def main():
                 run = lambda: None
 
             def parity():
+                some = side_n = 0
+                if k is not None and wl != "cfg3" and fixed is not None and not args.no_side_batch:
+                    # Random pairs are all None at these k: the gate below then compares sentinels.  A SIDE batch of mutated pairs of the
+                    # same geometry (real distances; swaps for the transposition family) goes through the same entry point, costs, k
+                    # and alphabet -- the same kernel selection rule -- and is compared answer by answer.  (It runs BEFORE the timed
+                    # batch's pass so that last_launch_info / last_kernel_name describe the timed batch.)
+                    side_n = 2048
+                    am, bm = Dg.pairs_mutated_fixed(seed0 + 0x5EED, side_n, L, (k // max(costs[0], costs[1], 1)) or 1, swaps=costs[3] is not None)
+                    if args.dist in ALPHABETS:                       # keep the side batch inside the alphabet the kernel was promised
+                        sym = np.frombuffer(ALPHABETS[args.dist], dtype=np.uint8)
+                        am, bm = sym[am % len(sym)], sym[bm % len(sym)]
+                    side = torch.empty(side_n, dtype=torch.int32, device="cuda")
+                    if wl == "cfg2t":
+                        B.levenshtein_trace_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), k, costs, out=side)
+                    else:
+                        B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), k, costs, out=side, alphabet=ALPHABETS.get(args.dist))
+                    want2 = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), k, costs, threads=cores)
+                    assert np.array_equal(side.cpu().numpy().view(np.uint32), want2), "parity gate failed on the mutated side batch: HIP path != oracle"
+                    some += int((want2 != 0xFFFFFFFF).sum())
                 run(); torch.cuda.synchronize()
                 ns = min(n, 4000 if wl != "cfg3" else 48)
                 got = out[:ns].cpu().numpy().view(np.uint32)
-                assert np.array_equal(got, oracle(0, ns, cores)), "parity gate failed: HIP path != oracle"
+                want = oracle(0, ns, cores)
+                assert np.array_equal(got, want), "parity gate failed: HIP path != oracle"
+                extra_t["parity_some"] = some + int((want != 0xFFFFFFFF).sum())
+                extra_t["parity_side"] = side_n
                 if wl == "cfg2t":                           # the scripts, edit for edit, against the scalar traceback; their bytes
                     scripts = B.edits_to_lists(ed[:600], ne[:600])
                     for i in range(min(n, 600)):
@@ -373,8 +401,13 @@ def main():
         mib = args.pairs or 1024
         needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()     # same needle on every rank
         k, costs = 16, LEV
+        if wl == "cfg5w":
+            cs = args.costs.split(",")
+            costs = (int(cs[0]), int(cs[1]), int(cs[2]), None if cs[3] in ("-", "None", "") else int(cs[3]))
         cells_unit, bytes_unit = 32, 1                              # per haystack byte: 32 cells, 1 byte read
         desc = "levenshtein_search 32B needle over a %d MiB random haystack shard per GPU, k=16, Best" % mib
+        if wl == "cfg5w":
+            desc += ", EditCosts(%d,%d,%d,%s)" % (costs[0], costs[1], costs[2], "None" if costs[3] is None else "Some(%d)" % costs[3])
         unit_name, dtype = "haystack bytes", "u16+u16 (cost|length packed in a u32 lane)"
 
         def make(share_of_common_batch):
@@ -385,7 +418,7 @@ def main():
             g = Dg.rng(0x7A05 + 1000 * rank)
             hay_np = Dg.random_bytes(g, size)
             for pos in range(1 << 16, hay_np.size - 100, 1 << 20):     # ~1 planted mutated copy per MiB
-                mm = np.frombuffer(Dg.mutate(g, needle, 10), dtype=np.uint8)
+                mm = np.frombuffer(Dg.mutate(g, needle, 10 if wl == "cfg5" else 5, wl == "cfg5w" and costs[3] is not None), dtype=np.uint8)
                 hay_np[pos:pos + mm.size] = mm
             hay = B.haystack_tensor(hay_np)                         # resident in HBM from here on
             holder = {}
@@ -520,6 +553,7 @@ def main():
     launch_mode = {}
     run, units, parity, extra = make(strong and world > 1)
     parity_n = parity()
+    parity_some, parity_side = extra.get("parity_some"), extra.get("parity_side", 0)
     if wl == "cfg2t":      # algorithmic bytes of a traceback pass: the strings, the distance and run count per pair, the runs written (16 B each)
         extra["bytes_total"] += 4 * units + 16 * extra["runs_total"]
     info = T.last_launch_info()
@@ -540,6 +574,17 @@ def main():
         if rank == 0:
             strong_fig = {"value": cells_s * args.steps / el_s / 1e9, "unit": "GCUPS", "ms_per_step": el_s / args.steps * 1e3,
                           "units_total": tot_s, "units_this_rank": units_s, "device_ms_per_pass": dev_s_ms}
+            ppw = (T.last_launch_info() or {}).get("pairs_per_wave") or 0
+            if ppw and wl not in ("cfg5", "cfg5w", "hsearch"):
+                # why strong scaling of a sub-millisecond pass flattens: a pass costs WHOLE wavefronts per SIMD, and a
+                # rank's share below one resident set (256 CUs x 16 wavefronts) still costs one wavefront lifetime + the pass's fixed part
+                wf = -(-units_s // ppw)
+                strong_fig["resident_set_arithmetic"] = {
+                    "pairs_per_wavefront": ppw, "wavefronts_this_rank": wf, "resident_set_wavefronts": 4096,
+                    "resident_sets_this_rank": round(wf / 4096.0, 3),
+                    "note": "below ~1 resident set per rank a pass costs one wavefront lifetime + its fixed part, not 1/N of the 1-GPU pass: "
+                            "weak scaling (the line's value) is the curve that stays flat; this figure is expected to flatten beyond N ~ %d"
+                            % max(1, (units // ppw) // 4096)}
         extra = {"bytes_total": extra_bytes}
     if rank != 0:
         if dist_on:
@@ -560,7 +605,33 @@ def main():
     traffic = None
     traffic_source = None
     valu_issue = None
-    tag = wl + ("" if args.dist in ("random", "mutated") else "_" + args.dist) + ("%d" % args.needle_len if wl == "hsearch" else "")       # the profile files of this workload / distribution
+
+    def issue_roofline(c, source):
+        """The bound that matters on this integer path: cycles per wave64 VALU instruction per SIMD over the dominant kernel's launch
+        (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs), against the guide's 2-cycle ceiling and against what a MIXED stream of
+        full-rate and half-rate opcodes issues at on gfx950 (scripts/ubench_mix.hip, measured; committed under profiles/)."""
+        insts, busy = c["SQ_INSTS_VALU"]["mean_per_launch"], c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+        cyc_per_inst = 1024.0 * busy / insts
+        v = {"kernel": c.get("_dominant"), "valu_insts_per_launch": insts, "busy_cycles_per_xcd": busy, "simds": 1024,
+             "cycles_per_valu_inst_per_simd": cyc_per_inst,
+             # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 -> the hard ceiling
+             "frac_of_2cycle_ceiling": 2.0 / cyc_per_inst, "source": source}
+        try:
+            mix = load_json(PROFILE_ROUND, "isa_mix.json")
+            if mix and tag in mix:          # opcode histogram of the inner loop x per-class issue cost measured opcode by opcode
+                m = mix[tag]
+                v["isa_model_cycles_per_valu_inst"] = m["modelled_cycles_per_valu_inst"]
+                v["frac_of_isa_model"] = m["modelled_cycles_per_valu_inst"] / cyc_per_inst
+            ub = open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "ubench_mix.txt")).read()
+            sect = ub[ub.index("4 wave(s) per SIMD"):]
+            mixed = float(sect[sect.index("xor/perm strictly alternating"):].split("ms")[1].split("cycles")[0])
+            v["measured_mixed_stream_cycles_per_valu_inst"] = mixed
+            v["frac_of_mixed_stream_rate"] = mixed / cyc_per_inst
+        except Exception:
+            pass
+        return v
+    tag = wl + ("" if args.dist in ("random", "mutated") else "_" + args.dist) + ("%d" % args.needle_len if wl == "hsearch" else "") + \
+          ("_" + args.costs.replace(",", "") if wl == "cfg5w" else "")       # the profile files of this workload / distribution
     pmc = load_json(PROFILE_ROUND, "bench_%s_pmc.json" % tag)
     # a committed counter pass is only spliced into the line when it was recorded for the kernel this run launched
     # (T.last_kernel_name(): the dominant kernel of the pass, as rocprofv3 prints it) -- never for another build's kernel
@@ -577,17 +648,20 @@ def main():
             try:
                 tmp_json = os.path.join(tempfile.mkdtemp(prefix="ta_pmc_"), "pmc.json")
                 flags = ["--dist", args.dist] + (["--pairs", str(args.pairs)] if args.pairs else []) + \
-                        (["--needle-len", str(args.needle_len)] if wl == "hsearch" else []) + (["--early-out"] if args.early_out else []) + \
+                        (["--needle-len", str(args.needle_len)] if wl == "hsearch" else []) + (["--costs", args.costs] if wl == "cfg5w" else []) + (["--early-out"] if args.early_out else []) + \
                         ["--prewarm-ms", "0"]
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_collect.py"), "--out", tmp_json, "--workload", wl,
-                                    "--sets", "rd_b,write", "--steps", "3", "--extra", " ".join(flags)],
-                                   capture_output=True, text=True, timeout=240)
+                                    "--sets", "rd_b,write,issue", "--steps", "3", "--extra", " ".join(flags)],
+                                   capture_output=True, text=True, timeout=360)
                 live = json.load(open(tmp_json))
                 if kernel_name and kernel_name in str(live.get("_dominant", "")):
                     traffic = int(live["_traffic"]["bytes_per_pass"])
                     traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_64B/128B, WRITE_SIZE (separate passes, "
                                       "3 steps each, same workload) after the timed region; 128 x RDREQ_128B + 64 x RDREQ_64B + WRITE_SIZE, "
                                       "all kernels of one pass")
+                    if "SQ_INSTS_VALU" in live and "GRBM_GUI_ACTIVE" in live:
+                        valu_issue = issue_roofline(live, "measured in this run: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE "
+                                                          "(its own pass, 3 steps, same workload) after the timed region")
             except Exception as e:
                 print("bench.py: live counter pass failed (%s: %s): replaying the committed one" % (type(e).__name__, e), file=sys.stderr)
     if pmc and traffic is None:
@@ -597,26 +671,9 @@ def main():
                               "same command, kernel %s); not measured in this run" % (PROFILE_ROUND, tag, pmc.get("_dominant")))
         except Exception:
             traffic = None
+    if pmc and valu_issue is None:
         try:
-            insts, busy = pmc["SQ_INSTS_VALU"]["mean_per_launch"], pmc["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
-            cyc_per_inst = 1024.0 * busy / insts
-            valu_issue = {"kernel": pmc.get("_dominant"), "valu_insts_per_launch": insts, "busy_cycles_per_xcd": busy, "simds": 1024,
-                          "cycles_per_valu_inst_per_simd": cyc_per_inst,
-                          # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 -> the hard ceiling
-                          "frac_of_2cycle_ceiling": 2.0 / cyc_per_inst,
-                          "source": "profiles/%s/bench_%s_pmc.json" % (PROFILE_ROUND, tag)}
-            mix = load_json(PROFILE_ROUND, "isa_mix.json")
-            if mix and tag in mix:          # opcode histogram of the inner loop x per-class issue cost measured opcode by opcode
-                m = mix[tag]
-                valu_issue["isa_model_cycles_per_valu_inst"] = m["modelled_cycles_per_valu_inst"]
-                valu_issue["frac_of_isa_model"] = m["modelled_cycles_per_valu_inst"] / cyc_per_inst
-            # what a MIXED stream really costs on this chip (profiles/<round>/ubench_mix.txt: a full-rate op next to half-rate ones
-            # takes a whole 4-cycle slot; the column code itself, compute only, runs at this rate)
-            ub = open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "ubench_mix.txt")).read()
-            sect = ub[ub.index("4 wave(s) per SIMD"):]
-            mixed = float(sect[sect.index("xor/perm strictly alternating"):].split("ms")[1].split("cycles")[0])
-            valu_issue["measured_mixed_stream_cycles_per_valu_inst"] = mixed
-            valu_issue["frac_of_mixed_stream_rate"] = mixed / cyc_per_inst
+            valu_issue = issue_roofline(pmc, "replayed from profiles/%s/bench_%s_pmc.json; not measured in this run" % (PROFILE_ROUND, tag))
         except Exception:
             pass
 
@@ -642,7 +699,7 @@ def main():
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread, oracle/ta_oracle.c (restated scalar hamming_search_naive), %.1f s"
                              % (cpu_sample >> 20, dt), "host": facts}
-        elif wl == "cfg5":
+        elif wl in ("cfg5", "cfg5w"):
             hay_np = extra["hay_np"]
             cpu_sample = min(8 << 20, hay_np.size)
             t1 = time.perf_counter()
@@ -739,7 +796,7 @@ def main():
         "config": {"workload": "%s: %s (%s bytes)" % (wl, desc, args.dist), "units_per_gpu": units, "units_total": all_units,
                    "unit": unit_name, "credited_cells_per_unit": all_cells / max(all_units, 1), "evaluated_band_cells_per_unit": evaluated_unit,
                    "parallelism": "independent units sharded x%d (%s), %s" % (
-                       world, args.scaling, "no collective" if wl != "cfg5" or not dist_on else
+                       world, args.scaling, "no collective" if wl not in ("cfg5", "cfg5w") or not dist_on else
                        "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
                    "backend": backend if dist_on else None,
                    "early_out": bool(args.early_out)},
@@ -754,7 +811,10 @@ def main():
                      "note": "integer VALU-issue-bound path (DESIGN.md section 5); the HBM fraction is reported because north_star asks for it"},
         "cpu_baseline": cpu,
         "timed_region": launch_mode.get("mode"),
-        "kernel": info, "parity_checked_units": parity_n,
+        "kernel": info, "parity_checked_units": parity_n + parity_side,
+        # how many of the answers compared with the oracle before the timed region were Some(d) -- random pairs at these k are all None,
+        # so the gate also runs a side batch of mutated pairs of the same geometry through the same entry point (parity_side_batch)
+        "parity_checked_some": parity_some, "parity_side_batch": parity_side,
     }
     print(json.dumps(line))
     if dist_on:

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETS = {
     "sq1": "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
     "sq2": "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS_SMEM",
+    "issue": "SQ_INSTS_VALU GRBM_GUI_ACTIVE",          # the VALU-issue roofline in ONE pass (bench.py's live counter leg)
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
     "rd_a": "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum",
@@ -49,7 +50,7 @@ def main():
     for nm in names:
         shutil.rmtree(tmp, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + SETS[nm].split() + ["-d", tmp, "-o", "p", "-f", "csv", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu", "--no-pmc"] + args.extra.split()
+               os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu", "--no-pmc", "--no-side-batch"] + args.extra.split()
         r = subprocess.run(cmd, cwd="/tmp", capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"))
         files = glob.glob(tmp + "/**/p_counter_collection.csv", recursive=True)
         if r.returncode != 0 or not files:

@@ -75,6 +75,10 @@ extern "C" int emu_search_anchored_packed_ok(uint64_t h, uint32_t n, uint32_t mc
     return srch_anchored_packed_ok(h, n, mc, gc, sg) ? 1 : 0;
 }
 
+extern "C" uint32_t emu_search_filter_k(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, int has_t, uint32_t tc) {
+    return srch_filter_k(k, mc, gc, sg, has_t != 0, tc);
+}
+
 extern "C" int emu_lev_search(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k,
                               uint32_t mc, uint32_t gc, uint32_t sg, int has_t, uint32_t tc, int anchored,
                               uint64_t tile, uint64_t halo, Hit *out, uint64_t cap, uint64_t *count) {

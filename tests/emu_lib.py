@@ -49,6 +49,8 @@ def lib():
         L.emu_lev_search.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
                                      C.c_uint64, C.POINTER(C.c_uint64)]
+        L.emu_search_filter_k.restype = C.c_uint32
+        L.emu_search_filter_k.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
         L.emu_search_anchored_packed_ok.restype = C.c_int
         L.emu_search_anchored_packed_ok.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emu_sliced_plan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
@@ -261,6 +263,12 @@ def lev_search_tiled(needle, haystack, k, costs=(1, 1, 0, None), anchored=False,
     for i in range(cnt.value):
         res.append((int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))))
     return res
+
+
+def search_filter_k(k, costs):
+    """k' of the superset filter under general EditCosts (srch_filter_k, lev_search_body.h)"""
+    mc, gc, sg, tc = costs
+    return int(lib().emu_search_filter_k(k, mc, gc, sg, 0 if tc is None else 1, 0 if tc is None else tc))
 
 
 def lev_filter_blocks(needle, haystack, k, trans=False, tile=256, halo=None, words=0):

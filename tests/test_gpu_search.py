@@ -429,3 +429,80 @@ def test_hamming_search_forms_and_fused_nul_scan(monkeypatch):
                 hz[zpos] = 0
                 with pytest.raises(T.PanicError):
                     B.hamming_search_dev(needle, B.haystack_tensor(hz), k)
+
+
+WEIGHTED = [(2, 2, 0, None), (2, 3, 1, None), (2, 2, 1, 3), (3, 1, 0, None), (1, 2, 0, None), (4, 3, 3, 5), (2, 2, 0, 2), (3, 2, 0, 1)]
+
+
+@pytest.mark.parametrize("costs", WEIGHTED)
+def test_weighted_costs_through_the_superset_filter(costs, monkeypatch):
+    """General EditCosts: the unit-cost scan with k' = srch_filter_k flags a superset of the blocks that hold a weighted hit and the
+    exact kernels (one wavefront per flagged block up to 64-byte needles, the memory-backed column beyond) price them with the real
+    costs.  All and Best against the oracle (planted copies with gap runs and swaps); on the resident shard the hits equal the
+    exact kernel's over everything (TA_SEARCH_NOWFILTER=1: round 4's rule), with a shifted base and emit_from."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0x5F17 + costs[0] * 7 + costs[1])
+    for n in (6, 17, 32, 48, 64, 100):
+        needle = Dg.rand_str(g, n)
+        hay = bytearray(Dg.planted_haystack(int(g.integers(1 << 30)), needle, 120_000, 6000 + n, max(1, n // 5)))
+        for pos in range(3000, len(hay) - 2 * n, 11_000):
+            m = Dg.mutate(g, needle, max(1, n // 8), swaps=True)
+            hay[pos:pos + len(m)] = m
+        hay = bytes(hay)
+        ht = B.haystack_tensor(hay)
+        for k in sorted({costs[0], n // 2, n, n + n // 2}):
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (n, k, st, costs)
+            monkeypatch.delenv("TA_SEARCH_NOWFILTER", raising=False)
+            got = B.levenshtein_search_dev(needle, ht, k, costs, base=500, emit_from=500 + 33)
+            monkeypatch.setenv("TA_SEARCH_NOWFILTER", "1")
+            ref = B.levenshtein_search_dev(needle, ht, k, costs, base=500, emit_from=500 + 33)
+            monkeypatch.delenv("TA_SEARCH_NOWFILTER")
+            assert np.array_equal(got, ref), (n, k, costs, len(got), len(ref))
+        assert len(O.levenshtein_search_naive_with_opts(needle, hay, n, O.ALL, costs, False)) > 0
+
+
+def test_weighted_filter_ties_small_alphabet_and_best_selection():
+    """Binary / ternary alphabets under weighted costs: hits in nearly every block (the dense fall-back), quirk Q2's ties in the match
+    starts, the device-side Best selection == the Best fold over all hits == the oracle's Best."""
+    from triple_accel_amd import batch as B, dist as TD
+    g = Dg.rng(0x71E5)
+    for costs in WEIGHTED:
+        for trial in range(4):
+            n = int(g.integers(5, 30))
+            needle = g.integers(97, 100, size=n, dtype=np.uint8).tobytes()
+            hay = g.integers(97, 100, size=30_000, dtype=np.uint8).tobytes()
+            k = int(g.integers(1, n + 1))
+            for st in (O.ALL, O.BEST):
+                want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, costs, False)
+                assert prod_search(needle, hay, k, st, costs) == want, (needle, k, st, costs)
+        needle = Dg.rand_str(g, 24)
+        k = 10
+        hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 300_000, 4000, 4)
+        t = B.haystack_tensor(hay)
+        allhits = B.levenshtein_search_dev(needle, t, k, costs)
+        best_rows = B.levenshtein_search_best_dev(needle, t, k, costs)
+        assert len(allhits) > 0
+        kmin = allhits[:, 2].min()
+        assert (best_rows[:, 2] == kmin).all() and len(best_rows) == int((allhits[:, 2] == kmin).sum())
+        got = TD.fold_best([tuple(int(v) for v in r) for r in best_rows], k, True)
+        assert got == O.levenshtein_search_naive_with_opts(needle, hay, k, O.BEST, costs, False), costs
+
+
+def test_cfg5w_geometry_shard():
+    """cfg5's geometry under the three weighted cost sets of bench.py --workload cfg5w (32-byte needle, k = 16, a 4 MiB random
+    shard with planted copies): All and Best against the oracle."""
+    import triple_accel_amd as T
+    g = Dg.rng(0x7A55)
+    needle = Dg.random_bytes(g, 32).tobytes()
+    hay = bytearray(Dg.random_bytes(g, 4 << 20).tobytes())
+    for pos in range(10000, len(hay) - 100, 200_000):
+        m = Dg.mutate(g, needle, 6, swaps=True)
+        hay[pos:pos + len(m)] = m
+    hay = bytes(hay)
+    for costs in [(2, 2, 0, None), (2, 3, 1, None), (2, 2, 1, 3)]:
+        for st in (O.ALL, O.BEST):
+            want = O.levenshtein_search_naive_with_opts(needle, hay, 16, st, costs, False)
+            got = [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, 16, st, T.EditCosts(*costs), False)]
+            assert got == want and len(want) > 0, (costs, st)

@@ -132,6 +132,28 @@ def test_trace_batch_fixed_length_cfg2_shape_and_cap():
         assert (got[i] == we) if wd is not None else (got[i] == []), i
     out2, edits2, ne2 = B.levenshtein_trace_batch(B.Strings.from_fixed(am[:500]), B.Strings.from_fixed(bm[:500]), 32, cap=3)
     assert np.array_equal(ne2.cpu().numpy(), ne[:500].cpu().numpy())
-    got2 = B.edits_to_lists(edits2, ne2)
+    got2 = B.edits_to_lists(edits2, ne2, allow_cut=True)
     for i in range(500):
         assert got2[i] == got[i][:3], i
+    with pytest.raises(ValueError):
+        B.edits_to_lists(edits2, ne2)                       # a cut script is an error unless asked for
+
+
+def test_trace_batch_csr_side_without_max_len():
+    """A CSR side built as Strings(blob, off) carries max_len = 0 ("let the library measure it", triple_accel_amd.h): the default
+    cap must come from the offsets, not from a length of 0 (it was min(2k+1, 3) = 3 and every longer script was cut
+    without an error)."""
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0xC5A)
+    a = [Dg.rand_str(g, int(g.integers(20, 120))) for _ in range(400)]
+    b = [Dg.mutate(g, x, 7, False) for x in a]
+    sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+    ra, rb = B.Strings(sa.blob, sa.off), B.Strings(sb.blob, sb.off)        # no max_len
+    assert ra.max_len == 0
+    out, edits, ne = B.levenshtein_trace_batch(ra, rb, 16)
+    assert edits.shape[1] == 33
+    got = B.edits_to_lists(edits, ne)
+    d = out.cpu().numpy().view(np.uint32)
+    for i in range(len(a)):
+        wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], 16, True)
+        assert (d[i] == wd and got[i] == we) if wd is not None else (d[i] == 0xFFFFFFFF and got[i] == []), i

@@ -51,6 +51,15 @@ class Strings:
         blob[: n * length] = t.reshape(-1).to(device)
         return cls(blob, None, stride=length, length=length, n=n)
 
+    def longest(self):
+        """an upper bound on the length of any string of the side: `length` (strided), `max_len` when the caller gave it, else
+        measured from the offsets (a CSR side built as Strings(blob, off) has max_len = 0 = "let the library measure it")"""
+        if self.off is None:
+            return int(self.length)
+        if not self.max_len and self.n > 0:
+            self.max_len = int((self.off[1:] - self.off[:-1]).max().item())
+        return int(self.max_len)
+
     def _c(self):
         """the C view (built once: the tensors of a batch side do not change)"""
         c = self.__dict__.get("_cview")
@@ -116,7 +125,7 @@ def levenshtein_trace_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, 
     assert a.n == b.n
     n, dev = a.n, a.blob.device
     if cap is None:
-        cap = min(2 * int(k) + 1, 2 * max(a.max_len or a.length, b.max_len or b.length, 1) + 1)
+        cap = min(2 * int(k) + 1, 2 * max(a.longest(), b.longest(), 1) + 1)
     out = _out(n, dev) if out is None else out
     edits = torch.empty((n, cap, 2), dtype=torch.int64, device=dev) if edits is None else edits
     n_edits = torch.empty(n, dtype=torch.int32, device=dev) if n_edits is None else n_edits
@@ -128,9 +137,15 @@ def levenshtein_trace_batch(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, 
     return out, edits, n_edits
 
 
-def edits_to_lists(edits, n_edits):
-    """the device result of levenshtein_trace_batch as Python lists [(name, count), ...] per pair (host copy)"""
+def edits_to_lists(edits, n_edits, allow_cut=False):
+    """the device result of levenshtein_trace_batch as Python lists [(name, count), ...] per pair (host copy).  A script that did
+    not fit the `cap` records of its pair was cut on the device (n_edits says how long it is): that is an error here, not a
+    silently shorter script, unless the caller asks for the cut scripts (allow_cut)."""
     e, ne = edits.cpu().numpy(), n_edits.cpu().numpy()
+    cut = [i for i in range(len(ne)) if int(ne[i]) > e.shape[1]]
+    if cut and not allow_cut:
+        raise ValueError("levenshtein_trace_batch: %d script(s) longer than cap = %d runs (first: pair %d with %d runs); pass a larger cap"
+                         % (len(cut), e.shape[1], cut[0], int(ne[cut[0]])))
     return [[(_EDIT_NAMES[int(e[i, t, 0]) & 0xFFFFFFFF], int(e[i, t, 1])) for t in range(min(int(ne[i]), e.shape[1]))] for i in range(len(ne))]
 
 

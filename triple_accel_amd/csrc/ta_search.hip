@@ -151,8 +151,12 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
     const bool unit = costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 &&
                       (!costs->has_transpose || costs->transpose_cost == 1);
     const bool trans = costs->has_transpose != 0;
-    // With k >= needle_len every position matches: no filter.
-    const bool filter_ok = unit && !anchored && needle_len <= 256 && k < needle_len && h >= 4096 && !env_str("TA_SEARCH_NOFILTER");
+    // The filter scans with unit costs; under any other EditCosts it runs with k' = srch_filter_k (lev_search_body.h): a superset
+    // filter -- every alignment of weighted cost <= k has at most k' unit edits -- in front of the exact kernel, which knows the
+    // real costs.  With k' >= needle_len every position matches: no filter.  (TA_SEARCH_NOWFILTER=1: unit costs only, round 4's rule.)
+    const uint32_t kf = unit ? k : srch_filter_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, costs->transpose_cost);
+    const bool filter_ok = (unit || !env_str("TA_SEARCH_NOWFILTER")) && !anchored && needle_len <= 256 && kf < needle_len && h >= 4096 &&
+                           !env_str("TA_SEARCH_NOFILTER");
     bool searched = false;
     unsigned long long c = 0;
     if (filter_ok) {
@@ -164,9 +168,11 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
         TA_HIP(hipMemsetAsync(ctl, 0, sizeof(SearchCtl), st));           // the pass's one fill
         P.count = &ctl->count;
         SearchParams F = P;
+        F.k = kf;
+        if (F.halo < (uint32_t)needle_len + kf + 2) F.halo = (uint32_t)needle_len + kf + 2;       // left context of a unit-cost match of k' edits
         uint64_t ft = (h + 524287) / 524288;                          // two sets of resident lanes (256 CUs x 16 waves x 64): 0.557 against 0.601 ms
                                                                       // per GiB with one set of 8 waves per CU (profiles/r03/ab_search.md)
-        if (ft < 4 * (uint64_t)P.halo) ft = 4 * (uint64_t)P.halo;    // keep the left-context overhead under 25 %
+        if (ft < 4 * (uint64_t)F.halo) ft = 4 * (uint64_t)F.halo;    // keep the left-context overhead under 25 %
         ft = (ft + 2 * FILTER_BLOCK - 1) / (2 * FILTER_BLOCK) * (2 * FILTER_BLOCK);      // whole 128-byte lines per lane
         if (const char *e = env_str("TA_FILTER_TILE")) { long v = atol(e); if (v >= 64) ft = (uint64_t)v / FILTER_BLOCK * FILTER_BLOCK; }
         F.tile = (uint32_t)(ft > 0x7FFFFFC0ull ? 0x7FFFFFC0ull : ft);
