@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--early-out", action="store_true",
                     help="ta_set_option(TA_OPT_EARLY_OUT): wavefronts stop once none of their pairs can end at or below k -- same answers, "
                          "data-dependent work; NOT the headline (the reference evaluates its whole band): the line says so in config.early_out")
+    ap.add_argument("--unit-prefilter", action="store_true",
+                    help="ta_set_option(TA_OPT_UNIT_PREFILTER): weighted batches (cfg2w / cfg4w / cfg2l) run the unit-cost pass with k' first and "
+                         "price only its survivors -- same answers, data-dependent work; NOT a headline figure: config.unit_prefilter says so")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed passes for this long BEFORE the W warm-up steps: the input set-up on the host leaves the GPU idle for "
                          "seconds and its clocks take longer than a handful of 0.4 ms passes to come back (0 = off)")
@@ -135,6 +138,8 @@ def main():
 
     if args.early_out:
         T.set_option(T.OPT_EARLY_OUT, True)
+    if args.unit_prefilter:
+        T.set_option(T.OPT_UNIT_PREFILTER, True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -485,6 +490,7 @@ def main():
         graph = None
         if graphable and not args.no_graph:
             try:
+                run()                                         # (one pass outside the capture: the library sizes its scratch lists here, not inside it)
                 torch.cuda.synchronize()
                 side = torch.cuda.Stream()
                 graph = torch.cuda.CUDAGraph()
@@ -648,7 +654,7 @@ def main():
             try:
                 tmp_json = os.path.join(tempfile.mkdtemp(prefix="ta_pmc_"), "pmc.json")
                 flags = ["--dist", args.dist] + (["--pairs", str(args.pairs)] if args.pairs else []) + \
-                        (["--needle-len", str(args.needle_len)] if wl == "hsearch" else []) + (["--costs", args.costs] if wl == "cfg5w" else []) + (["--early-out"] if args.early_out else []) + \
+                        (["--needle-len", str(args.needle_len)] if wl == "hsearch" else []) + (["--costs", args.costs] if wl == "cfg5w" else []) + (["--early-out"] if args.early_out else []) + (["--unit-prefilter"] if args.unit_prefilter else []) + \
                         ["--prewarm-ms", "0"]
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_collect.py"), "--out", tmp_json, "--workload", wl,
                                     "--sets", "rd_b,write,issue", "--steps", "3", "--extra", " ".join(flags)],
@@ -799,7 +805,7 @@ def main():
                        world, args.scaling, "no collective" if wl not in ("cfg5", "cfg5w") or not dist_on else
                        "halo tails + match lists all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)),
                    "backend": backend if dist_on else None,
-                   "early_out": bool(args.early_out)},
+                   "early_out": bool(args.early_out), "unit_prefilter": bool(args.unit_prefilter)},
         "value_evaluated_cells": evaluated_value,
         "end_to_end_ms": e2e_ms,          # host buffers in, answers out (pinned H2D + pass + D2H); never the headline
         "strong_scaling": strong_fig,

@@ -90,8 +90,12 @@ const char *ta_status_str(int status);
  *   wavefront as soon as none of its pairs can still end at or below k (the top cell of the current band column minus the
  *   downward steps below it -- a lower bound of every cell of the column -- exceeds k; checked every 24-32 columns).  The answers are the same -- those pairs are None either way
  *   (src/levenshtein.rs:539-541) -- but the work then depends on the data: batches of dissimilar strings finish after a few
- *   dozen columns.  Off by default: the reference evaluates its whole band, and so does every benchmark figure of this library. */
-enum { TA_OPT_EARLY_OUT = 1 };
+ *   dozen columns.  Off by default: the reference evaluates its whole band, and so does every benchmark figure of this library.
+ *   TA_OPT_UNIT_PREFILTER: batches under weighted EditCosts (ta_levenshtein_k_batch, >= 1024 pairs) first run the unit-cost bit-parallel
+ *   pass with k' = max(k / min(mc, tc), (k - sg) / min(mc, gc, tc)): a pair whose UNIT distance exceeds k' has a weighted distance above k --
+ *   None (src/levenshtein.rs:539-541) -- and only the others are priced by the DP band kernel with the real costs.  Same answers; the work
+ *   depends on the data (dissimilar batches: the unit pass alone, 0.3 of the weighted pass; near pairs: both).  Off by default. */
+enum { TA_OPT_EARLY_OUT = 1, TA_OPT_UNIT_PREFILTER = 2 };
 int ta_set_option(int option, int value);
 /* number of visible HIP devices (0 => every compute call returns TA_ERR_HIP) */
 int ta_device_count(void);
@@ -114,7 +118,7 @@ int ta_levenshtein_select(size_t a_len, size_t b_len, uint32_t k, const ta_edit_
 /* What the last distance batch launched on this thread used (for tests / debug logging;
  * the analogue of the reference's `debug` feature println, src/levenshtein.rs:840-847). */
 typedef struct {
-    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup, 3 = bit-parallel band (unit costs), 4 = bit-parallel full columns (unit costs, long pairs), 5 = pair-sliced systolic band (EXPERIMENTAL builds), 6 = single pair, band <= 64 diagonals (unit costs), 7 = small-alphabet bit-parallel band (ta_levenshtein_k_batch_alphabet); pairs_per_wave 128 with kernel 3 = two pairs per lane */
+    uint32_t kernel;          /* 1 = band-wavefront (registers+DPP), 2 = wide-band workgroup, 3 = bit-parallel band (unit costs), 4 = bit-parallel full columns (unit costs, long pairs), 5 = pair-sliced systolic band (EXPERIMENTAL builds), 6 = single pair, band <= 64 diagonals (unit costs), 7 = small-alphabet bit-parallel band (ta_levenshtein_k_batch_alphabet), 8 = checkpoint-and-recompute traceback of the unit-cost families (ta_levenshtein_trace_batch, bands of up to 33 diagonals); pairs_per_wave 128 with kernel 3 = two pairs per lane */
     uint32_t diags_per_lane;  /* D */
     uint32_t lanes_per_pair;  /* L */
     uint32_t pairs_per_wave;

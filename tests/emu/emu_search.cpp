@@ -215,6 +215,69 @@ extern "C" int emu_ham_search_bits(const uint8_t *needle, uint32_t n, const uint
     return 0;
 }
 
+// ---- bit-sliced counters over a subset of the needle's positions, Q phases per dword (ham_phase_body.h): the kernel's tile walk --
+// span bytes in front of the tile in steps of Q, a verdict word per step, candidates recounted over the whole needle
+#include "ham_phase_body.h"
+template <int B>
+static void ham_phase_all(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, const HamPhaseGeom &G,
+                          std::vector<Hit> &hits, uint64_t *candidates) {
+    uint32_t mis[256], bias[B];
+    for (uint32_t c = 0; c < 256; c++) mis[c] = ham_phase_mis(needle, G, c);
+    ham_phase_bias<B>(k, G, bias);
+    const uint64_t last = h - n;
+    const uint32_t Q = G.Q, W = G.W;
+    for (uint64_t b0 = 0; b0 < h; b0 += tile) {
+        const uint64_t b1 = b0 + tile < h ? b0 + tile : h;
+        HamBitsState<B> st;
+        ham_phase_reset<B>(st, G);
+        auto step = [&](uint64_t i) -> uint32_t {
+            uint32_t m = 0;
+            for (int r = (int)Q - 1; r >= 0; r--) {
+                const uint32_t t = mis[i + (uint32_t)r < h ? hay[i + (uint32_t)r] : 0u];
+                m = Q == 1 ? t : ((m << (W & 31u)) | t);
+            }
+            return Q > 1 ? ham_phase_step<B, true>(st, m, bias, G.keep) : ham_phase_step<B, false>(st, m, bias, G.keep);
+        };
+        for (uint64_t i = b0 > G.span ? b0 - G.span : 0; i < b0; i += Q) step(i);
+        for (uint64_t i = b0; i < b1; i += Q) {
+            const uint32_t ov = step(i);
+            for (uint32_t r = 0; r < Q; r++) {
+                if ((ov >> (r * W + W - 1u)) & 1u) continue;
+                const uint64_t x = i + r;
+                if (x < G.span) continue;
+                const uint64_t pos = x - G.span;
+                if (pos > last) continue;
+                (*candidates)++;
+                uint32_t cnt = 0;
+                for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != needle[j];
+                if (cnt <= k) hits.push_back(Hit{pos, pos + n, cnt, 0u});
+            }
+        }
+    }
+}
+// q_force: 0 = the plan's Q, else 1 / 2 / 4 where the plan allows at least that many phases; rc 1 = the form does not apply
+extern "C" int emu_ham_search_phase(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, uint64_t tile, uint32_t q_force,
+                                    Hit *out, uint64_t cap, uint64_t *count, uint32_t *plan /* Q, L, B */, uint64_t *candidates) {
+    uint32_t Q = 0, L = 0; int B = 0;
+    if (n == 0 || n > h || tile == 0 || (tile % 4u) || !ham_phase_plan(n, k, Q, L, B)) return 1;
+    if (q_force && q_force < Q) {
+        Q = q_force; L = (n + Q - 1u) / Q;
+        if (L > 32u / Q) L = 32u / Q;
+    }
+    const HamPhaseGeom G = ham_phase_geom(Q, L);
+    plan[0] = Q; plan[1] = L; plan[2] = (uint32_t)B;
+    *candidates = 0;
+    std::vector<Hit> hits;
+    switch (B) {
+        case 1: ham_phase_all<1>(needle, n, hay, h, k, tile, G, hits, candidates); break; case 2: ham_phase_all<2>(needle, n, hay, h, k, tile, G, hits, candidates); break;
+        case 3: ham_phase_all<3>(needle, n, hay, h, k, tile, G, hits, candidates); break; case 4: ham_phase_all<4>(needle, n, hay, h, k, tile, G, hits, candidates); break;
+        default: ham_phase_all<5>(needle, n, hay, h, k, tile, G, hits, candidates); break;
+    }
+    *count = hits.size();
+    for (uint64_t i = 0; i < hits.size() && i < cap; i++) out[i] = hits[i];
+    return 0;
+}
+
 // ---- SWAR form (ham_swar_body.h): the per-lane function over every 16-byte-aligned lane position, as the kernel walks them
 #include "ham_swar_body.h"
 template <int NW>

@@ -123,6 +123,59 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
+def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False):
+    """Batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): the walk's codes turned into the run-length script the
+    reference returns -- [(edit name, count)] per pair, None for a pair whose distance is None.  dists: the pass's answers (None = no
+    script); u: the pass's unit_k.  fixed: the strided (fixed-length) view of the batch instead of CSR."""
+    n = len(a_list)
+    ab, ao = pack(a_list)
+    bb, bo = pack(b_list)
+    max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
+    pw = 2 * max_len // 16 + 2
+    path = np.full(n * pw, 0xDEADBEEF, dtype=np.uint32)
+    steps = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    dist = np.array([0xFFFFFFFF if d is None else d for d in dists], dtype=np.uint32)
+    f = lib().emu_lev_bits_trace
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p,
+                  C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    if fixed:
+        la, lb = len(a_list[0]), len(b_list[0])
+        assert all(len(x) == la for x in a_list) and all(len(x) == lb for x in b_list)
+        rc = f(ab.ctypes.data, None, la, bb.ctypes.data, None, lb, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, path.ctypes.data, pw, steps.ctypes.data)
+    else:
+        rc = f(ab.ctypes.data, ao.ctypes.data, 0, bb.ctypes.data, bo.ctypes.data, 0, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, path.ctypes.data, pw, steps.ctypes.data)
+    if rc:
+        raise RuntimeError("emu_lev_bits_trace rc=%d" % rc)
+    out = []
+    for p in range(n):
+        if dists[p] is None:
+            assert steps[p] == 0
+            out.append(None)
+            continue
+        a, b = a_list[p], b_list[p]
+        swap = len(a) > len(b)
+        x, y = (b, a) if swap else (a, b)
+        runs, fi, fj = [], 0, 0
+        for t in range(int(steps[p]) - 1, -1, -1):                          # the walk's last step is the script's first edit
+            code = (int(path[p * pw + (t >> 4)]) >> (2 * (t & 15))) & 3
+            if code == 0:
+                e = "Match" if x[fi] == y[fj] else "Mismatch"; fi += 1; fj += 1
+            elif code == 1:
+                e = "BGap" if swap else "AGap"; fj += 1
+            elif code == 2:
+                e = "AGap" if swap else "BGap"; fi += 1
+            else:
+                e = "Transpose"; fi += 2; fj += 2
+            if runs and runs[-1][0] == e:
+                runs[-1] = (e, runs[-1][1] + 1)
+            else:
+                runs.append((e, 1))
+        assert fi == len(x) and fj == len(y), (p, fi, fj, len(x), len(y))
+        out.append(runs)
+    return out
+
+
 def bits_fixed_chunk(on):
     """Fixed-length batches through the CHUNK form of the fetch (what the launcher picks up to one 128-byte line per string)."""
     lib().emu_bits_set_fixed_chunk(1 if on else 0)
@@ -318,6 +371,27 @@ def ham_search_bits(needle, haystack, k, tile=256):
     if rc:
         return None
     return [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]
+
+
+def ham_search_phase(needle, haystack, k, tile=256, q_force=0):
+    """All-mode hits of the phased bit-sliced hamming_search form (ham_phase_body.h) over a tiled haystack, with its plan and the number of
+    candidates its filter passed: (hits, (Q, L, B), candidates); None where the form does not apply."""
+    n = len(needle)
+    hay = np.zeros(len(haystack) + 16, dtype=np.uint8)
+    hay[:len(haystack)] = np.frombuffer(haystack, dtype=np.uint8)
+    cap = len(haystack) + 2
+    out = np.zeros((cap, 3), dtype=np.uint64)
+    cnt, cand = C.c_uint64(), C.c_uint64()
+    plan = (C.c_uint32 * 3)()
+    f = lib().emu_ham_search_phase
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                  C.c_void_p, C.c_void_p]
+    rc = f(needle, n, hay.ctypes.data, len(haystack), k, tile, q_force, out.ctypes.data, cap, C.byref(cnt), plan, C.byref(cand))
+    if rc:
+        return None
+    hits = [(int(out[i, 0]), int(out[i, 1]), int(out[i, 2] & np.uint64(0xFFFFFFFF))) for i in range(cnt.value)]
+    return hits, (int(plan[0]), int(plan[1]), int(plan[2])), int(cand.value)
 
 
 def ham_search_swar(needle, haystack, k, delta=0):

@@ -78,3 +78,60 @@ def test_bit_sliced_equals_oracle():
                 got = E.ham_search_bits(needle, hay, k, tile)
                 assert got is not None and sorted(got) == want, (n, k, tile)
     assert E.ham_search_bits(b"abcd", b"xxabcdxx", 4) is None and E.ham_search_bits(b"abcd" * 8, b"q" * 100, 31) == []
+
+
+def test_phase_plan_rules():
+    """(needle length, k) -> (phases per dword, positions counted, counter bits): the subset stays selective (L >= 2k, L - k >= 6) unless it
+    is the whole needle; the BASELINE-style rows land where DESIGN says."""
+    pl = lambda n, k: (E.ham_search_phase(bytes(range(1, n + 1)), bytes(300), k) or (None, None))[1]
+    assert pl(32, 8) == (2, 16, 4) and pl(64, 16) == (1, 32, 5) and pl(32, 2) == (4, 8, 2) and pl(16, 2) == (2, 8, 2)
+    assert pl(64, 17) is None and pl(32, 20) == (1, 32, 5) and pl(32, 32) is None and pl(200, 3) == (2, 16, 2) and pl(200, 2) == (4, 8, 2) and pl(8, 2) == (1, 8, 2)
+    for n in range(1, 80):
+        for k in range(0, 32):
+            p = pl(n, k)
+            if p is None:
+                continue
+            q, l, b = p
+            assert k < n and (1 << b) - 1 >= k and q * l <= 32 and q * (l - 1) <= n - 1
+            assert (q == 1 and l == n) or (l >= 2 * k and l - k >= 6), (n, k, p)
+
+
+def test_phase_form_equals_oracle():
+    """The phased bit-sliced filter (ham_phase_body.h): every needle length 1..72 and some longer, every k the plan takes up to n/2, tiles
+    that cut planted copies, every forced phase count, haystack lengths that are no multiple of the phase count, zeros in the haystack."""
+    g = Dg.rng(0x4E)
+    for n in list(range(1, 73)) + [100, 127, 128, 200]:
+        needle = bytes(g.integers(0, 256, size=n).astype(np.uint8))
+        hl = 1400 + int(g.integers(0, 4))
+        hay = bytearray(g.integers(0, 256, size=hl).astype(np.uint8).tobytes())
+        for pos in range(3, hl - n - 1, 97):
+            m = bytearray(needle)
+            for _ in range(int(g.integers(0, max(2, n // 2 + 2)))):
+                m[int(g.integers(0, n))] = int(g.integers(0, 256))
+            hay[pos:pos + n] = m
+        hay[hl - n:] = needle                                                  # a hit that ends with the haystack
+        hay = bytes(hay)
+        for k in sorted({0, 1, 2, 3, 5, 8, n // 4, n // 3, n // 2, min(31, n - 1)}):
+            if k >= n:
+                continue
+            want = O.hamming_search_naive_with_opts(needle, hay, k, O.ALL)
+            for tile, qf in ((128, 0), (256, 1), (640, 2), (384, 0)):
+                r = E.ham_search_phase(needle, hay, k, tile, qf)
+                if r is None:
+                    continue
+                got, plan, cand = r
+                assert sorted(got) == want, (n, k, tile, qf, plan)
+                assert cand >= len(want)
+
+
+def test_phase_form_low_entropy_and_dense_hits():
+    """Four-letter and one-letter texts: the subset filter passes many candidates, the recount decides; dense hits (every offset)."""
+    g = Dg.rng(0x4F)
+    for n, k in ((32, 8), (64, 16), (33, 2), (16, 2), (40, 10), (12, 0)):
+        needle = bytes(g.integers(97, 101, size=n).astype(np.uint8))
+        hay = bytes(g.integers(97, 101, size=900).astype(np.uint8))
+        for tile in (128, 512):
+            got, plan, cand = E.ham_search_phase(needle, hay, k, tile)
+            assert sorted(got) == O.hamming_search_naive_with_opts(needle, hay, k, O.ALL), (n, k, plan)
+    got, plan, cand = E.ham_search_phase(b"a" * 40, b"a" * 500, 3, 128)
+    assert sorted(got) == [(p, p + 40, 0) for p in range(461)] and cand == 461

@@ -1,0 +1,77 @@
+"""not-gpu: batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h) in the 64-lane host emulation against the oracle's
+scripts (src/levenshtein.rs:493-532 argmin order, :561-606 walk), edit for edit."""
+import numpy as np
+import pytest
+
+import datagen as Dg
+import emu_lib as E
+import oracle_lib as O
+
+
+def _check(a, b, k, trans, tile, fixed=False):
+    costs = (1, 1, 0, 1) if trans else (1, 1, 0, None)
+    want = [O.levenshtein_naive_k_with_opts(x, y, k, True, costs) for x, y in zip(a, b)]
+    dists = [w[0] for w in want]
+    max_len = max([len(x) for x in a] + [len(y) for y in b] + [1])
+    u = min(k, max_len)
+    got = E.lev_bits_trace(a, b, u, dists, trans, tile, fixed)
+    for p, (g, w) in enumerate(zip(got, want)):
+        assert g == w[1], (p, a[p], b[p], k, trans, tile, g, w)
+    return sum(1 for d in dists if d is not None)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("tile", [16, 32])
+def test_trace_mutated_ragged(trans, tile):
+    g = Dg.rng(0x7B1 + tile + int(trans))
+    for k in (3, 8, 17, 30, 32):
+        if trans and k > 30:
+            continue
+        a, b = [], []
+        for i in range(150):
+            n = int(g.integers(0, 140))
+            x = Dg.rand_str(g, n)
+            y = Dg.mutate(g, x, int(g.integers(0, k + 3)), trans) if i % 5 else Dg.rand_str(g, int(g.integers(0, 140)))
+            if i % 2:
+                x, y = y, x                                              # both orientations: the kernel swaps the shorter onto the rows
+            a.append(x); b.append(y)
+        assert _check(a, b, k, trans, tile) > 60
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_trace_small_alphabet_ties(trans):
+    """Binary strings: many equal-cost paths -- the tie order decides the script."""
+    g = Dg.rng(0x7B9 + int(trans))
+    for k in (2, 6, 12, 30):
+        a, b = [], []
+        for i in range(130):
+            n = int(g.integers(1, 90))
+            x = bytes(g.integers(97, 99, size=n).astype(np.uint8))
+            y = bytearray(x)
+            for _ in range(int(g.integers(0, k + 1))):
+                t = int(g.integers(0, 3))
+                pos = int(g.integers(0, len(y) + 1))
+                if t == 0 and pos < len(y):
+                    y[pos] = 97 + int(g.integers(0, 2))
+                elif t == 1:
+                    y.insert(pos, 97 + int(g.integers(0, 2)))
+                elif pos < len(y):
+                    del y[pos]
+            a.append(x); b.append(bytes(y))
+        assert _check(a, b, k, trans, 16) > 40
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_trace_fixed_length_and_long(trans):
+    """Fixed-length (strided) batches, strings over several tiles and lines, empty strings, identical pairs, None pairs in the wavefront."""
+    g = Dg.rng(0x7C3 + int(trans))
+    am, bm = Dg.pairs_mutated_fixed(0x7C4, 100, 256, 12, swaps=trans)
+    a = [bytes(r) for r in am]; b = [bytes(r) for r in bm]
+    b[7] = a[7]
+    b[9] = bytes(g.integers(1, 255, size=256).astype(np.uint8))
+    assert _check(a, b, 30 if trans else 32, trans, 16, fixed=True) > 90
+    assert _check(a, b, 30 if trans else 32, trans, 32, fixed=True) > 90
+    a2 = [b"", b"abc", b"", b"kitten", b"ab", b"ba", b"abcdefgh" * 40, b"x" * 300]
+    b2 = [b"", b"", b"xyz", b"sitting", b"ba", b"ab", (b"abcdefgh" * 40)[3:] + b"zz", b"x" * 290 + b"y" * 5]
+    _check(a2, b2, 20, trans, 16)
+    _check(a2, b2, 20, trans, 32)

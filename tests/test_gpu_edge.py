@@ -1,4 +1,6 @@
 """-m gpu: edge cases -- empty and tiny inputs, maximum costs, very long strings with a narrow band, big batches."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,17 +174,24 @@ def test_many_helpers_and_failed_flush():
     got = T.levenshtein_simd_k_with_opts_many(iter(pairs), 6, flush_every=700)
     assert got == [None if int(w) == 0xFFFFFFFF else int(w) for w in want]
     assert T.levenshtein_many(pairs[:200]) == [O.levenshtein(x, y) for x, y in pairs[:200]]
-    # a band no kernel serves inside a queue pass (weighted costs, unbounded k, 40 000-byte strings): the flush fails and the queue empties
-    q = T.Queue(0xFFFFFFFF, T.EditCosts(2, 3, 1, None))
-    big = Dg.rand_str(g, 40_000)
-    q.push(big, big[::-1])
+    # a flush whose pass fails (TA_FAIL_PASS: a tuning switch that makes the distance pass return TA_ERR_UNSUPPORTED): the flush raises, the
+    # queue drops the pairs and works again afterwards
+    q = T.Queue(12, T.EditCosts(2, 3, 1, None))
+    q.push(b"kitten", b"sitting")
+    q.push(b"flaw", b"lawn")
+    os.environ["TA_FAIL_PASS"] = "1"
     try:
-        q.flush()
-        failed = False
-    except Exception:
-        failed = True
-    if failed:
-        assert q.flush() == []
-        q.push(b"kitten", b"sitting")
-        assert q.flush() == [O.levenshtein_simd_k_with_opts(b"kitten", b"sitting", 0xFFFFFFFF, False, (2, 3, 1, None))[0]]
+        with pytest.raises(Exception):
+            q.flush()
+    finally:
+        del os.environ["TA_FAIL_PASS"]
+    assert q.flush() == []
+    q.push(b"kitten", b"sitting")
+    assert q.flush() == [O.levenshtein_simd_k_with_opts(b"kitten", b"sitting", 12, False, (2, 3, 1, None))[0]]
+    # 40,000-byte strings under weighted costs in a queue pass: served like any other pair
+    big = Dg.rand_str(g, 40_000)
+    near = Dg.mutate(g, big, 4)
+    q.push(big, big[::-1])
+    q.push(big, near)
+    assert q.flush() == [O.levenshtein_simd_k_with_opts(big, y, 12, False, (2, 3, 1, None))[0] for y in (big[::-1], near)]
     q.close()

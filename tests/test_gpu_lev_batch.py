@@ -379,3 +379,93 @@ def test_band_line_form_fixed_length(costs, k, L, monkeypatch):
         got2 = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), k, costs).cpu().numpy().view(np.uint32)
         assert "line" not in T.last_kernel_name() and np.array_equal(got2, want)
         monkeypatch.delenv("TA_BAND_NO_LINE")
+
+
+def test_exp_batch_device_driven_rounds(monkeypatch):
+    """ta_levenshtein_exp_batch on batches of >= 1024 pairs enqueues its whole k schedule with the lists' lengths kept on the device (no host
+    round trip between rounds): same distances as the oracle and as the host-driven loop (TA_EXP_HOST_ROUNDS=1), for every kernel family a
+    round can take -- bit-parallel band (both fetch forms, two pairs per lane), row-blocked bit-parallel, DP band (cost and score form), DP
+    wide -- on fixed-length and ragged batches with pairs that resolve in different rounds; and the call can be captured in a graph."""
+    import torch
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0xE4B)
+    cases = []
+    # fixed length 600: mutated with 0 / 5 / 40 / 130 edits, and unrelated pairs -> rounds k = 30, 60, 120, ... and the unbounded one
+    n = 3000
+    x, _ = Dg.pairs_random(11, n, 600)
+    y = x.copy()
+    for i in range(n):
+        e = (0, 5, 40, 130, -1)[i % 5]
+        y[i] = np.frombuffer(Dg.mutate(g, bytes(x[i]), e, True)[:600].ljust(600, b"q"), dtype=np.uint8) if e >= 0 else Dg.pairs_random(1000 + i, 1, 600)[1][0]
+    cases.append(("fixed600", B.Strings.from_fixed(x), B.Strings.from_fixed(y), O.csr_from_fixed(x), O.csr_from_fixed(y)))
+    # fixed length 96 (narrow bands, two pairs per lane needs >= 262,144 pairs: one pair per lane here), similar pairs
+    am, bm = Dg.pairs_mutated_fixed(0xE4C, 5000, 96, 6, swaps=True)
+    cases.append(("fixed96", B.Strings.from_fixed(am), B.Strings.from_fixed(bm), O.csr_from_fixed(am), O.csr_from_fixed(bm)))
+    # ragged
+    a, b = [], []
+    for i in range(2500):
+        s = Dg.rand_str(g, int(g.integers(1, 700)))
+        t = Dg.mutate(g, s, int(g.integers(0, 150)), True) if i % 3 else Dg.rand_str(g, int(g.integers(1, 700)))
+        a.append(s); b.append(t)
+    cases.append(("ragged", B.Strings.from_list(a), B.Strings.from_list(b), O.csr_from_list(a), O.csr_from_list(b)))
+    for name, sa, sb, ca, cb in cases:
+        for costs in [(1, 1, 0, None), (1, 1, 0, 1), (2, 2, 0, None), (2, 3, 1, None), (3, 2, 0, 2), (1, 2, 0, None)]:
+            want = O.levenshtein_exp_batch(ca, cb, costs)
+            got = B.levenshtein_exp_batch(sa, sb, costs).cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want), (name, costs, np.flatnonzero(got != want)[:8])
+            monkeypatch.setenv("TA_EXP_HOST_ROUNDS", "1")
+            got = B.levenshtein_exp_batch(sa, sb, costs).cpu().numpy().view(np.uint32)
+            monkeypatch.delenv("TA_EXP_HOST_ROUNDS")
+            assert np.array_equal(got, want), (name, costs, "host rounds")
+        for sw in ("TA_EXP_NO_BOUND", "TA_NO_BITS"):
+            monkeypatch.setenv(sw, "1")
+            got = B.levenshtein_exp_batch(sa, sb, (1, 1, 0, None)).cpu().numpy().view(np.uint32)
+            monkeypatch.delenv(sw)
+            assert np.array_equal(got, O.levenshtein_exp_batch(ca, cb, (1, 1, 0, None))), (name, sw)
+    # the whole call inside a captured graph (fixed-length batch: nothing of it needs the host), replayed on fresh inputs of the same shape
+    name, sa, sb, ca, cb = cases[0]
+    out = torch.empty(sa.n, dtype=torch.int32, device="cuda")
+    B.levenshtein_exp_batch(sa, sb, (1, 1, 0, None), out=out)                 # (scratch sized outside the capture)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gr, stream=st):
+            B.levenshtein_exp_batch(sa, sb, (1, 1, 0, None), out=out)
+    out.fill_(7)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), O.levenshtein_exp_batch(ca, cb, (1, 1, 0, None)))
+
+
+@pytest.mark.parametrize("costs,k", [((2, 3, 1, None), 32), ((2, 2, 1, 3), 8), ((2, 3, 0, None), 32), ((3, 1, 0, None), 20), ((1, 2, 0, None), 12),
+                                     ((4, 3, 3, 5), 40), ((3, 2, 0, 1), 9), ((2, 2, 2, 3), 12)])
+def test_unit_prefilter_option(costs, k):
+    """ta_set_option(TA_OPT_UNIT_PREFILTER): a weighted batch runs the unit-cost pass with k' = lev_unit_filter_k first and the DP band
+    kernel prices only the pairs that pass answered -- the oracle's answers, fixed-length and ragged, pairs at / just above / far above k,
+    costs whose cheapest edit is the mismatch, the gap or the transposition."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0x9F1 + k)
+    L = 200
+    am, bm = Dg.pairs_mutated_fixed(0x9F2 + k, 6000, L, max(2, k // (2 * max(costs[0], costs[1]))), swaps=costs[3] is not None)
+    bm[::4] = Dg.pairs_random(0x9F3 + k, len(bm[::4]), L)[1]
+    a, b = [], []
+    for i in range(5000):
+        s = Dg.rand_str(g, int(g.integers(1, 300)))
+        t = Dg.mutate(g, s, int(g.integers(0, k // max(costs[0], costs[1]) + 3)), costs[3] is not None) if i % 3 else Dg.rand_str(g, int(g.integers(1, 300)))
+        a.append(s); b.append(t)
+    try:
+        T.set_option(T.OPT_UNIT_PREFILTER, True)
+        got = B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), k, costs).cpu().numpy().view(np.uint32)
+        name = T.last_kernel_name()
+        got_r = B.levenshtein_k_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs).cpu().numpy().view(np.uint32)
+    finally:
+        T.set_option(T.OPT_UNIT_PREFILTER, False)
+    want = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), k, costs)
+    assert np.array_equal(got, want), (costs, k, np.flatnonzero(got != want)[:10])
+    assert "band" in name, name                                   # the second pass of the call is the DP band kernel's
+    want_r = O.levenshtein_k_batch(O.csr_from_list(a), O.csr_from_list(b), k, costs)
+    assert np.array_equal(got_r, want_r), (costs, k, np.flatnonzero(got_r != want_r)[:10])
+    assert (want != 0xFFFFFFFF).sum() > 100 and (want == 0xFFFFFFFF).sum() > 100

@@ -402,8 +402,10 @@ def test_hamming_search_forms_and_fused_nul_scan(monkeypatch):
     g = Dg.rng(77)
     hay_np = Dg.random_bytes(g, 700_000)
     hay_np[hay_np == 0] = 1
-    for n, k, kern in [(4, 1, "swar16"), (8, 2, "swar16"), (12, 3, "bits"), (16, 7, "bits"), (16, 8, "swar16"), (24, 6, "bits"), (32, 8, "bits"),
-                       (32, 31, "bits"), (32, 32, "swar16"), (40, 9, "swar16"), (64, 20, "swar16"), (9, 1, "bits"), (70, 10, "hamming_search_kernel")]:
+    for n, k, kern in [(4, 1, "swar16"), (8, 2, "swar16"), (12, 3, "phase_kernel<1,2>"), (16, 7, "phase_kernel<1,3>"), (16, 8, "swar16"),
+                       (24, 6, "phase_kernel<2,3>"), (32, 8, "phase_kernel<2,4>"), (32, 2, "phase_kernel<4,2>"), (32, 31, "phase_kernel<1,5>"),
+                       (32, 32, "swar16"), (40, 9, "phase_kernel<1,4>"), (64, 16, "phase_kernel<1,5>"), (64, 20, "swar16"), (9, 1, "phase_kernel<1,1>"),
+                       (70, 10, "phase_kernel<1,4>"), (300, 40, "hamming_search_kernel")]:
         needle = bytes(int(c) or 1 for c in Dg.random_bytes(g, n))
         hay = hay_np.copy()
         nd = np.frombuffer(needle, dtype=np.uint8)
@@ -415,20 +417,64 @@ def test_hamming_search_forms_and_fused_nul_scan(monkeypatch):
         want = O.hamming_search_naive_with_opts(needle, hay.tobytes(), k, O.ALL)
         assert len(want) >= 25
         got = [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, dev, k)]
-        assert kern in T.last_kernel_name() or n > 64, (n, k, T.last_kernel_name())
+        assert kern in T.last_kernel_name(), (n, k, T.last_kernel_name())
         assert got == want, (n, k)
-        for sw in ("TA_HAMMING_SEARCH_NO_BITS", "TA_HAMMING_SEARCH_SA", "TA_HAMMING_SEARCH_SWAR"):
+        for sw in ("TA_HAMMING_SEARCH_NO_PHASE", "TA_HAMMING_SEARCH_NO_BITS", "TA_HAMMING_SEARCH_SA", "TA_HAMMING_SEARCH_SWAR"):
             if sw == "TA_HAMMING_SEARCH_SA" and n > 32:
                 continue
             monkeypatch.setenv(sw, "1")
             assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, dev, k)] == want, (n, k, sw)
+            assert "phase" not in T.last_kernel_name()
+            if sw == "TA_HAMMING_SEARCH_NO_PHASE" and 9 <= n <= 32 and k < 16:
+                assert "bits_kernel" in T.last_kernel_name() or "swar16" in T.last_kernel_name()
             monkeypatch.delenv(sw)
-        if n in (8, 24):
+        if n in (8, 24, 40) or (n, k) == (32, 2):
             for zpos in (0, hay.size - 1, hay.size - n + 1, 128 * 5, 262143, 300_001):
                 hz = hay.copy()
                 hz[zpos] = 0
                 with pytest.raises(T.PanicError):
                     B.hamming_search_dev(needle, B.haystack_tensor(hz), k)
+
+
+def test_hamming_search_phase_form_every_length(monkeypatch):
+    """Bit-sliced counters over a subset of the needle's positions (ham_phase_body.h) on the device: every needle length 9..72 plus long
+    needles, k from 0 to n / 2, the plan's phase count and every smaller one forced, a haystack whose length is no multiple of four, planted
+    near-copies (also across tile boundaries and at both ends); four-letter text, where the filter passes thousands of candidates."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(91)
+    base = Dg.random_bytes(g, 300_003)
+    base[base == 0] = 1
+    dna = (g.integers(0, 4, size=200_001).astype(np.uint8) + 97)
+    used = set()
+    for n in list(range(9, 73)) + [100, 128, 255, 1000]:
+        needle_r = bytes(int(c) or 1 for c in Dg.random_bytes(g, n))
+        needle_d = bytes(dna[1000:1000 + n])
+        for k in sorted({0, 1, 2, n // 8, n // 4, n // 3, n // 2}):
+            for text, needle in ((base, needle_r), (dna, needle_d)):
+                if text is dna and (n % 7 or k > 12):
+                    continue
+                hay = text.copy()
+                nd = np.frombuffer(needle, dtype=np.uint8)
+                for pos in list(range(31, hay.size - 2 * n, 20011)) + [0, hay.size - n, 65536 - n // 2]:
+                    hay[pos:pos + n] = nd
+                    for q in g.integers(0, n, size=int(g.integers(0, k + 2))):
+                        hay[pos + int(q)] = 7 if text is base else 97
+                dev = B.haystack_tensor(hay)
+                want = O.hamming_search_naive_with_opts(needle, hay.tobytes(), k, O.ALL)
+                for qf in (None, "2", "1"):
+                    if qf:
+                        monkeypatch.setenv("TA_HAMMING_PHASE_Q", qf)
+                    got = [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, dev, k)]
+                    name = T.last_kernel_name()
+                    if qf:
+                        monkeypatch.delenv("TA_HAMMING_PHASE_Q")
+                    assert got == want, (n, k, qf, name, text is dna)
+                    if "phase" in name:
+                        used.add(name)
+                    else:
+                        break
+    assert {"hamming_search_phase_kernel<%d,%d>" % (q, b) for q, b in ((1, 5), (1, 1), (2, 4), (2, 2), (4, 1), (4, 2))} <= used, used
 
 
 WEIGHTED = [(2, 2, 0, None), (2, 3, 1, None), (2, 2, 1, 3), (3, 1, 0, None), (1, 2, 0, None), (4, 3, 3, 5), (2, 2, 0, 2), (3, 2, 0, 1)]

@@ -157,3 +157,60 @@ def test_trace_batch_csr_side_without_max_len():
     for i in range(len(a)):
         wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], 16, True)
         assert (d[i] == wd and got[i] == we) if wd is not None else (d[i] == 0xFFFFFFFF and got[i] == []), i
+
+
+@pytest.mark.parametrize("trans,k", [(False, 32), (True, 30), (False, 5), (True, 9)])
+def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
+    """The unit-cost families with a band of up to 33 diagonals take the checkpoint-and-recompute kernel (lev_bits_trace_body.h: no per-cell
+    records): its scripts are the oracle's and the DP band kernel's (TA_TRACE_NO_BITS=1), edit for edit -- ragged batches with strings of
+    up to 1,500 bytes (dozens of tiles), both orientations, ties on a binary alphabet, None pairs inside a wavefront, tiles of 16 and 32
+    columns, fixed-length batches."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    costs = (1, 1, 0, 1) if trans else (1, 1, 0, None)
+    g = Dg.rng(0xCB7 + k + int(trans))
+    a, b = [], []
+    for i in range(2000):
+        t = i % 7
+        if t == 6:
+            x = g.integers(97, 99, size=int(g.integers(0, 60)), dtype=np.uint8).tobytes()
+            y = g.integers(97, 99, size=int(g.integers(0, 60)), dtype=np.uint8).tobytes()
+        else:
+            n = int(g.integers(0, 1500 if i % 50 == 0 else 260))
+            x = Dg.rand_str(g, n)
+            y = Dg.rand_str(g, int(g.integers(0, 260))) if t == 0 else Dg.mutate(g, x, int(g.integers(0, k + 2)), trans)
+            if t in (1, 2):
+                x, y = y, x
+        a.append(x); b.append(y)
+    sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+    out, edits, ne = B.levenshtein_trace_batch(sa, sb, k, costs)
+    assert "lev_bits_trace_kernel" in T.last_kernel_name() and T.last_launch_info()["kernel"] == 8
+    got_d, got_e = out.cpu().numpy().view(np.uint32), B.edits_to_lists(edits, ne)
+    monkeypatch.setenv("TA_TRACE_TILE", "32")
+    out32, edits32, ne32 = B.levenshtein_trace_batch(sa, sb, k, costs)
+    assert "32>" in T.last_kernel_name()
+    monkeypatch.delenv("TA_TRACE_TILE")
+    monkeypatch.setenv("TA_TRACE_NO_BITS", "1")
+    out_dp, edits_dp, ne_dp = B.levenshtein_trace_batch(sa, sb, k, costs)
+    assert "lev_band_trace_kernel" in T.last_kernel_name()
+    monkeypatch.delenv("TA_TRACE_NO_BITS")
+    assert np.array_equal(got_d, out_dp.cpu().numpy().view(np.uint32)) and np.array_equal(got_d, out32.cpu().numpy().view(np.uint32))
+    assert got_e == B.edits_to_lists(edits_dp, ne_dp) and got_e == B.edits_to_lists(edits32, ne32)
+    n_some = 0
+    for i in range(0, len(a), 3):
+        wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+        if wd is None:
+            assert got_d[i] == 0xFFFFFFFF and got_e[i] == [], i
+        else:
+            n_some += 1
+            assert got_d[i] == wd and got_e[i] == we, (i, a[i], b[i], got_e[i], we)
+    assert n_some > 300
+    # fixed-length, a longer than b and b longer than a
+    am, bm = Dg.pairs_mutated_fixed(0xCB8 + k, 3000, 200, max(2, k // 2), swaps=trans)
+    for xa, xb in ((am, np.ascontiguousarray(bm[:, :197])), (np.ascontiguousarray(am[:, :195]), bm)):
+        o2, e2, n2 = B.levenshtein_trace_batch(B.Strings.from_fixed(xa), B.Strings.from_fixed(xb), k, costs)
+        assert "lev_bits_trace_kernel" in T.last_kernel_name()
+        d2, l2 = o2.cpu().numpy().view(np.uint32), B.edits_to_lists(e2, n2)
+        for i in range(0, 3000, 41):
+            wd, we = O.levenshtein_simd_k_with_opts(xa[i].tobytes(), xb[i].tobytes(), k, True, costs)
+            assert (d2[i] == wd and l2[i] == we) if wd is not None else (d2[i] == 0xFFFFFFFF and l2[i] == []), i

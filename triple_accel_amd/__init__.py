@@ -363,11 +363,13 @@ class Queue:
 
 
 OPT_EARLY_OUT = 1
+OPT_UNIT_PREFILTER = 2
 
 
 def set_option(option, value):
     """Options of the calling thread (include/triple_accel_amd.h): OPT_EARLY_OUT -- the band kernels of fixed-length unit-cost
-    batches stop a wavefront once none of its pairs can end at or below k (same answers, data-dependent work)."""
+    batches stop a wavefront once none of its pairs can end at or below k; OPT_UNIT_PREFILTER -- batches under weighted EditCosts run the
+    unit-cost pass first and price only the pairs it could not rule out (both: same answers, data-dependent work)."""
     _n.check(_n.lib().ta_set_option(int(option), int(bool(value))))
 
 

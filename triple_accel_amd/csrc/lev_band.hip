@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include "lev_trace_emit.h"
 #include "lev_band_body.h"
 #include "lev_plan.h"
 #include "ta_internal.h"
@@ -14,8 +15,14 @@ constexpr int LEV_WAVES_PER_BLOCK = 4;
 template <int D, bool AFFINE, int TRANS, bool L1>
 __global__ __launch_bounds__(64 * LEV_WAVES_PER_BLOCK) void lev_band_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBand<DevWave, D, AFFINE, TRANS, false, L1>::run(P, blockIdx.x * LEV_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, w = blockIdx.x * LEV_WAVES_PER_BLOCK + wave;
+    if (P.n_dev) {                                     // a list a kernel before this one wrote (the rounds of ta_levenshtein_exp_batch): its length is read here
+        LevParams Q = P;
+        Q.n = *P.n_dev;
+        if ((uint64_t)w * P.PW < Q.n) LevBand<DevWave, D, AFFINE, TRANS, false, L1>::run(Q, w, lds + wave * P.lds_per_wave);
+        return;
+    }
+    LevBand<DevWave, D, AFFINE, TRANS, false, L1>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 template <int D>
@@ -150,32 +157,8 @@ __global__ __launch_bounds__(64) void lev_trace_walk_kernel(StrView a, StrView b
     }
     if (!some) return;
     if (steps & 15u) my_path[steps >> 4] = acc;
-    // ---- phase B: the path forwards, runs written as they close
-    ta_edit *slot = edits + (uint64_t)pair * cap;
-    uint32_t runs = 0, cur = 0xFFFFFFFFu, fi = 0, fj = 0, wcache = 0;
-    uint64_t cnt = 0;
-    // the strings eight bytes at a time (the blobs carry 16 bytes of slack): a load per eight steps instead of two per step
-    typedef uint64_t u64u __attribute__((aligned(1)));
-    uint64_t xc = 0, yc = 0;
-    uint32_t xb = 0xFFFFFFFFu, yb = 0xFFFFFFFFu;                 // which 8-byte group the caches hold
-    for (uint32_t t = steps; t-- > 0u;) {
-        if ((t & 15u) == 15u || t == steps - 1u) wcache = my_path[t >> 4];
-        const uint32_t code = (wcache >> (2u * (t & 15u))) & 3u;
-        uint32_t e;
-        if (code == 0u) {
-            if ((fi >> 3) != xb) { xb = fi >> 3; xc = *(const u64u *)(x + 8u * (uint64_t)xb); }
-            if ((fj >> 3) != yb) { yb = fj >> 3; yc = *(const u64u *)(y + 8u * (uint64_t)yb); }
-            e = (((xc >> (8u * (fi & 7u))) ^ (yc >> (8u * (fj & 7u)))) & 0xFFu) == 0u ? TA_EDIT_MATCH : TA_EDIT_MISMATCH; fi++; fj++;
-        }
-        else if (code == 1u) { e = swap ? TA_EDIT_BGAP : TA_EDIT_AGAP; fj++; }
-        else if (code == 2u) { e = swap ? TA_EDIT_AGAP : TA_EDIT_BGAP; fi++; }
-        else { e = TA_EDIT_TRANSPOSE; fi += 2u; fj += 2u; }
-        if (e == cur) { cnt++; continue; }
-        if (cur != 0xFFFFFFFFu) { if (runs < cap) slot[runs] = ta_edit{cur, 0u, cnt}; runs++; }
-        cur = e; cnt = 1;
-    }
-    if (cur != 0xFFFFFFFFu) { if (runs < cap) slot[runs] = ta_edit{cur, 0u, cnt}; runs++; }
-    n_edits[pair] = runs;
+    // ---- phase B: the path forwards, runs written as they close (lev_trace_emit.h)
+    n_edits[pair] = trace_emit_runs(my_path, steps, x, y, swap, edits + (uint64_t)pair * cap, cap);
 }
 
 // a chunk of a batch: pairs [pair_base, pair_base + n_chunk) through the trace kernel (records into `trace`), then the walk

@@ -33,6 +33,19 @@ constexpr uint32_t LEV_NEG = 0xC0000001u;   // the same in the score form: -LEV_
 // (slot order: the PW rings of `a`, then the PW rings of `b`).
 constexpr uint32_t lev_slot_bytes(uint32_t ch) { return 2u * ch + 4u; }
 
+// the checkpoint-and-recompute batch traceback of the unit-cost families (lev_bits_trace_body.h)
+struct LevBitsTraceParams {
+    StrView a, b;
+    const uint32_t *dist;        // distances of the batch (0xFFFFFFFF: None, no script)
+    uint32_t n;                  // pairs
+    uint32_t u;                  // unit_k of the pass: the band holds u + 1 (+ 2 with the transposition term) <= 33 diagonals
+    uint32_t *ckpt;              // scratch: [wave][tile][word][lane]
+    uint32_t ckpt_tiles;         // tiles per wavefront the scratch holds (>= ceil(longest column count / TILE))
+    uint32_t *path;              // [pair][path_words]: the codes of the walk, sixteen per word, first step of the WALK (the last edit) first
+    uint32_t path_words;
+    uint32_t *steps;             // [pair]: steps of the walk (0 for None)
+};
+
 struct LevParams {
     StrView a, b;
     const uint32_t *subset;   // optional: indices of the pairs to process (exp search), else nullptr

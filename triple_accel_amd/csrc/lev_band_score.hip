@@ -14,16 +14,28 @@ constexpr int LEV_SCORE_WAVES_PER_BLOCK = 4;      // as lev_band.hip (the launch
 template <int D, bool AFFINE, int TRANS, bool L1>
 __global__ __launch_bounds__(64 * LEV_SCORE_WAVES_PER_BLOCK) void lev_band_score_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBand<DevWave, D, AFFINE, TRANS, false, L1, true>::run(P, blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, w = blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave;
+    if (P.n_dev) {                                     // a list whose length only the device knows (lev_band.hip)
+        LevParams Q = P;
+        Q.n = *P.n_dev;
+        if ((uint64_t)w * P.PW < Q.n) LevBand<DevWave, D, AFFINE, TRANS, false, L1, true>::run(Q, w, lds + wave * P.lds_per_wave);
+        return;
+    }
+    LevBand<DevWave, D, AFFINE, TRANS, false, L1, true>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 // one lane per pair + a fixed-length batch: the LINE form of the fetch (every line of a string requested once, parked in registers)
 template <int D, bool AFFINE, int TRANS>
 __global__ __launch_bounds__(64 * LEV_SCORE_WAVES_PER_BLOCK) void lev_band_score_line_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBand<DevWave, D, AFFINE, TRANS, false, true, true, true>::run(P, blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, w = blockIdx.x * LEV_SCORE_WAVES_PER_BLOCK + wave;
+    if (P.n_dev) {                                     // a list whose length only the device knows (lev_band.hip)
+        LevParams Q = P;
+        Q.n = *P.n_dev;
+        if ((uint64_t)w * P.PW < Q.n) LevBand<DevWave, D, AFFINE, TRANS, false, true, true, true>::run(Q, w, lds + wave * P.lds_per_wave);
+        return;
+    }
+    LevBand<DevWave, D, AFFINE, TRANS, false, true, true, true>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 template <int D>

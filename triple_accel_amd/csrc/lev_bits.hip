@@ -55,8 +55,14 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(
 template <bool TRANS, bool EARLY = false>
 __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) TA_BITS2_ATTR void lev_bits2_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = threadIdx.x >> 6;
-    LevBits2<DevWave, TRANS, EARLY>::run(P, blockIdx.x * (blockDim.x >> 6) + wave, lds + wave * P.lds_per_wave);
+    const uint32_t wave = threadIdx.x >> 6, w = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (P.n_dev) {                                     // a list whose length only the device knows (the rounds of ta_levenshtein_exp_batch)
+        LevParams Q = P;
+        Q.n = *P.n_dev;
+        if ((uint64_t)w * 128u < Q.n) LevBits2<DevWave, TRANS, EARLY>::run(Q, w, lds + wave * P.lds_per_wave);
+        return;
+    }
+    LevBits2<DevWave, TRANS, EARLY>::run(P, w, lds + wave * P.lds_per_wave);
 }
 
 // two pairs per lane (lev_bits2_body.h): 128 pairs per wavefront
@@ -136,7 +142,8 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITS_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     uint32_t grid = (waves + wpb - 1) / wpb;
     if (const char *e = env_str("TA_BITS_PERSIST")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < grid) grid = (uint32_t)v; }   // A/B: persistent grid
-    if (P.n_dev && grid > 512u) grid = 512u;           // a list whose length only the device knows (usually empty): a small striding grid
+    if (P.n_dev && !(P.tune & 8u) && grid > 512u) grid = 512u;   // a list whose length only the device knows and that is usually empty (lev_bitsq's fallback): a small striding grid
+                                                                  // (tune bit 3, the rounds of ta_levenshtein_exp_batch: the grid of the list's upper bound; wavefronts behind its end leave at once)
     // CSR batches (chunk form, half lines fetched 64 iterations apart) with strings longer than one 128-byte line: three blocks
     // (12 waves) per CU instead of four -- a quarter fewer pairs in flight lets the 4 MB L2 keep more lines until their second
     // half is read.  Fixed-length batches (line form: every line requested once) run the four blocks the LDS allows: 16 waves

@@ -77,6 +77,7 @@ struct LevBits {
         U32 AW[NA];             // byte i = a[row(i) - 1] ^ 0x0C, row(i) = j - d_hi + i: window bit i <-> byte i
         U32 PMp[NW], D0p[NW];   // TRANS: previous column's match vector and D0
         U32 acc;                // D0 of the window's top diagonal (bit 0), the last columns' bits from bit 31 down; zeros below them
+        U32 rD0, rBot;          // step8<.., REC>: the column's D0 (window bits 0..31) and the bottom diagonal's D0 in bit 0 (lev_bits_trace_body.h)
     };
 
     // the window moves one row down: byte i <- byte i+1, the next byte of `a` enters on top
@@ -158,7 +159,7 @@ struct LevBits {
     // S8: iteration tp with C = tp % 8, warm-up or column.  Before it, register r holds the bytes of window bits
     // ((r - C) & 7) + 8 q; b_dw / a_raw = the dwords whose byte C & 3 is this iteration's column character / the byte of `a` that
     // enters (it is the bottom diagonal's byte now and the top byte of register C afterwards); a_x = a_raw ^ 0x0C0C0C0C.
-    template <bool CAP, int C, bool COLUMN>
+    template <bool CAP, int C, bool COLUMN, bool REC = false>
     static TA_HD inline __attribute__((always_inline)) void step8(State &st, U32 b_dw, U32 a_raw, U32 a_x, Bool live) {
         if (COLUMN) {
             const U32 Bs = W::template splat_byte_n<(C & 3)>(b_dw);
@@ -191,6 +192,7 @@ struct LevBits {
                 d0_bot = W::template byte_eq_or<(C & 3)>(a_raw, b_dw, cm);
             }
             st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0, W::splat(0)) : D0, st.acc);
+            if (REC) { st.rD0 = D0; st.rBot = d0_bot; }
             const U32 HP = st.VN[0] | ~(D0 | st.VP[0]);
             const U32 HN = D0 & st.VP[0];
             const U32 D0s = W::template alignbit<1>(d0_bot, D0);

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * BITSQW_MAX_WAVES_PER_BLOCK) __attribute__((amd
 }
 
 // P as for lev_bitsq_launch with P.q_shift / q_memb / q_hi / q_ns from lev_bitsqw_hash
+constexpr uint32_t BITSQW_TAIL_PAD = 1040;       // 4 * 0xFF + 8 bytes behind the last pair's rings, rounded up to 16
 hipError_t lev_bitsqw_launch(const LevParams &P0, bool trans, hipStream_t s, uint32_t *grid_out, uint32_t *lds_out) {
     using K = LevBitsQW<DevWave, false>;
     LevParams P = P0;
@@ -63,15 +64,17 @@ hipError_t lev_bitsqw_launch(const LevParams &P0, bool trans, hipStream_t s, uin
     uint32_t wpb = 1, best = 0;
     for (uint32_t blocks = 1; blocks <= 4; blocks++) {
         const uint32_t room = 156u * 1024u / blocks;    // (4 KB of the 160 left to the allocation granule)
-        if (room < K::TABLE_BYTES + P.lds_per_wave) break;
-        uint32_t w = (room - K::TABLE_BYTES) / P.lds_per_wave;
+        if (room < K::TABLE_BYTES + P.lds_per_wave + BITSQW_TAIL_PAD) break;
+        uint32_t w = (room - K::TABLE_BYTES - BITSQW_TAIL_PAD) / P.lds_per_wave;
         if (w > (uint32_t)BITSQW_MAX_WAVES_PER_BLOCK) w = BITSQW_MAX_WAVES_PER_BLOCK;
         const uint32_t total = w * blocks > 16u ? 16u : w * blocks;
         if (total > best) { best = total; wpb = w; }
     }
     if (const char *e = env_str("TA_BITS_WPB")) { const int v = atoi(e); if (v >= 1 && v <= BITSQW_MAX_WAVES_PER_BLOCK) wpb = (uint32_t)v; }
     const uint32_t waves = (P.n + 63u) / 64u, grid = (waves + wpb - 1) / wpb;
-    const size_t lds = K::TABLE_BYTES + (size_t)P.lds_per_wave * wpb;
+    // (+ the tail pad: a byte of `b` outside the alphabet looks its ring up at table entry 0xFF -- ring + 1020, an 8-byte read that no answer
+    // uses (the pair is re-answered by the byte-test kernel) but that must stay inside the workgroup's allocation for every pair of the block)
+    const size_t lds = K::TABLE_BYTES + (size_t)P.lds_per_wave * wpb + BITSQW_TAIL_PAD;
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;

@@ -308,4 +308,24 @@ inline LevSlicedPlan lev_sliced_make_plan(uint64_t a_len, uint64_t b_len, uint32
     return p;
 }
 
+// A unit-cost threshold that bounds a weighted one from below: for any EditCosts,
+//     k' = max( k / min(mc, tc),  (k - sg) / min(mc, gc, tc) )              (tc only when the costs have a transposition)
+// An alignment the reference's recurrence prices at C <= k (src/levenshtein.rs:1709-1806, :434-541: every cell value is the cost of one
+// concrete path) has x mismatches, g gap characters in o >= [g > 0] gap runs and t transpositions: C = x mc + g gc + o sg + t tc.
+// Its number of unit edits U = x + g + t (the unit restricted-Damerau recurrence counts a transposition as ONE edit) obeys
+// U min(mc, gc, tc) <= C - o sg: with a gap that is <= k - sg, without one g = 0 and U min(mc, tc) <= k.  The unit-cost distance is the
+// minimum over all paths, so it is <= U <= k': "unit distance > k'" implies "weighted distance > k".  Unit costs times g give k / g exactly.
+// Users: the search's candidate filter (lev_search_body.h: srch_filter_k) and the unit-cost pre-pass of weighted pair batches
+// (TA_OPT_UNIT_PREFILTER, ta_api.hip).
+static inline uint32_t lev_unit_filter_k(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc) {
+    uint32_t m_nogap = mc, m_all = mc < gc ? mc : gc;
+    if (has_t) {
+        if (tc < m_nogap) m_nogap = tc;
+        if (tc < m_all) m_all = tc;
+    }
+    if (m_all == 0) return 0xFFFFFFFFu;                       // (no bound: a free edit)
+    const uint32_t with_gap = (k > sg ? k - sg : 0u) / m_all, without = k / m_nogap;
+    return with_gap > without ? with_gap : without;
+}
+
 }  // namespace ta

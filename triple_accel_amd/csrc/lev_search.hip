@@ -6,6 +6,7 @@
 #include "ham_search_body.h"
 #include "ham_swar_body.h"
 #include "ham_bits_body.h"
+#include "ham_phase_body.h"
 #include "lev_filter_body.h"
 #include "lev_search_body.h"
 #include "lev_search_wave_body.h"
@@ -685,6 +686,133 @@ __global__ __launch_bounds__(512) void hamming_search_bits_kernel(SearchParams P
     if (nul_flag && nz != 0xFFFFFFFFu) atomicOr(nul_flag, 1u);
 }
 
+// Bit-sliced counters over a subset of the needle's positions, Q phases per dword (ham_phase_body.h): any needle length; one lane per tile of
+// P.tile bytes (a multiple of 128), the 256-entry phase-0 Mis table once per lane in LDS (64 KB, 512 threads), a whole 128-byte line per
+// lane per burst one line ahead.  A 16-byte piece is 16 / Q steps whose verdict words are AND-ed: only a piece that holds a candidate looks
+// at them one by one, and a candidate is recounted over the whole needle.  The NUL-byte scan rides along.
+template <int Q, int B>
+__global__ __launch_bounds__(512) void hamming_search_phase_kernel(SearchParams P, HamPhaseGeom G, uint32_t *nul_flag) {
+    __shared__ __attribute__((aligned(16))) uint32_t mis[256 * 64];
+    {
+        const uint32_t m = ham_phase_mis(P.needle_dev, G, threadIdx.x >> 1);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *row = (u32x4 *)(mis + (threadIdx.x >> 1) * 64 + (threadIdx.x & 1u) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) row[q] = u32x4{m, m, m, m};
+    }
+    __syncthreads();
+    constexpr uint32_t W = 32u / Q, STEPS = 16u / Q;
+    const uint32_t lane_off = (threadIdx.x & 63u) * 4u;
+    auto lookup = [&](uint32_t v, int b) -> uint32_t {
+        const uint32_t a = __builtin_amdgcn_perm(v, lane_off, 0x0C0C0000u | ((4u + (uint32_t)b) << 8));   // lane*4 | byte b << 8
+        return *(const uint32_t *)((const uint8_t *)mis + a);
+    };
+    const uint32_t n = P.needle_len, k = P.k, keep = G.keep, span = G.span;
+    const uint64_t h = P.hay_len, last = h - n;
+    const uint64_t tile = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b0 = tile * P.tile;                             // this lane reports the alignments whose VERDICT byte is in [b0, b1)
+    if (b0 >= h) return;
+    const uint64_t b1 = b0 + P.tile < h ? b0 + P.tile : h;
+    const uint8_t *hay = P.hay;
+    HamBitsState<B> st;
+    ham_phase_reset<B>(st, G);
+    uint32_t bias[B];
+    ham_phase_bias<B>(k, G, bias);
+    auto bytes_step = [&](uint64_t i) -> uint32_t {                // one step from single bytes (warm-up, the last partial line)
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = Q - 1; r >= 0; r--) {
+            const uint32_t c = i + (uint32_t)r < h ? hay[i + (uint32_t)r] : 0u;
+            const uint32_t t = lookup(c, 0);
+            m = Q == 1 ? t : ((m << (W & 31u)) | t);
+        }
+        return ham_phase_step<B, (Q > 1)>(st, m, bias, keep);
+    };
+    for (uint64_t i = b0 > span ? b0 - span : 0; i < b0; i += Q) bytes_step(i);   // the span bytes in front (b0 and span are multiples of Q)
+    auto verify = [&](uint64_t x) {                                // the alignment whose verdict byte is x passed the filter
+        if (x < span) return;                                      // (no alignment ends there: the verdict bits of a haystack's first bytes)
+        const uint64_t pos = x - span;
+        if (pos > last) return;
+        uint32_t cnt = 0;
+        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != P.needle_dev[j];
+        if (cnt > k) return;
+        const unsigned long long idx = atomicAdd(P.count, 1ull);
+        if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt, 0u};
+    };
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    uint64_t i = b0;
+    const uint64_t full_end = b0 + ((b1 - b0) & ~(uint64_t)127);
+    uint32_t nz = 0xFFFFFFFFu;                                     // AND of the byte tests: 0xFF per byte that is not NUL
+    u32x4u nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) nxt[q] = (i + 16u * q < b1) ? *(const u32x4u *)(hay + i + 16u * q) : u32x4u{0, 0, 0, 0};
+    while (i < full_end) {                                         // whole lines
+        u32x4u cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++)                                // blobs carry 16 bytes of slack
+            if (i + 128u + 16u * q < b1) nxt[q] = *(const u32x4u *)(hay + i + 128u + 16u * q);
+#pragma unroll 1
+        for (int part = 0; part < 4; part++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32x4u v = part == 0 ? cur[q] : part == 1 ? cur[2 + q] : part == 2 ? cur[4 + q] : cur[6 + q];
+                // windows of at most 8 steps: their verdict words are kept (8 registers) and AND-ed; only a window that holds a candidate
+                // looks at them one by one
+                constexpr uint32_t WIN = STEPS > 8u ? 8u : STEPS;
+#pragma unroll
+                for (uint32_t w0 = 0; w0 < STEPS; w0 += WIN) {
+                    uint32_t ov[WIN];
+#pragma unroll
+                    for (uint32_t s = 0; s < WIN; s++) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (int r = Q - 1; r >= 0; r--) {
+                            const uint32_t b = Q * (w0 + s) + (uint32_t)r;
+                            const uint32_t t = lookup(v[b >> 2], b & 3);
+                            m = Q == 1 ? t : ((m << (W & 31u)) | t);
+                        }
+                        ov[s] = ham_phase_step<B, (Q > 1)>(st, m, bias, keep);
+                    }
+                    uint32_t all = ov[0];
+#pragma unroll
+                    for (uint32_t s = 1; s < WIN; s++) all &= ov[s];
+                    if ((all | keep) != 0xFFFFFFFFu) {              // a phase top that is clear: a candidate somewhere in this window
+                        uint32_t cm = 0;                           // bit Q s + r: the verdict of byte Q (w0 + s) + r of the piece
+#pragma unroll
+                        for (uint32_t s = 0; s < WIN; s++) {
+                            uint32_t o = ov[s];
+                            asm volatile("" : "+v"(o));             // (keeps the sorting of the verdicts inside the rare branch: hipcc hoists it otherwise)
+#pragma unroll
+                            for (uint32_t r = 0; r < (uint32_t)Q; r++)
+                                cm |= ((~o >> (r * W + W - 1u)) & 1u) << (Q * s + r);
+                        }
+                        const uint64_t first = i + 32u * (uint32_t)part + 16u * (uint32_t)q + Q * w0;
+                        while (cm) {
+                            const uint32_t t = (uint32_t)__builtin_ctz(cm);
+                            cm &= cm - 1u;
+                            verify(first + t);
+                        }
+                    }
+                }
+                if (nul_flag) nz &= __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[0] ^ 0x0C0C0C0Cu) & __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[1] ^ 0x0C0C0C0Cu) &
+                                    __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[2] ^ 0x0C0C0C0Cu) & __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, v[3] ^ 0x0C0C0C0Cu);
+            }
+        }
+        i += 128;
+    }
+    for (; i < b1; i += Q) {                                       // the tile's last, partial line, step by step
+        const uint32_t ov = bytes_step(i);
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)Q; r++) {
+            if (!((ov >> (r * W + W - 1u)) & 1u)) verify(i + r);
+            if (nul_flag && i + r < h && hay[i + r] == 0u) nz = 0;
+        }
+    }
+    if (nul_flag && nz != 0xFFFFFFFFu) atomicOr(nul_flag, 1u);
+}
+
 // needles of up to 32 bytes: shift-add scan (ham_search_body.h), one lane per tile of P.tile offsets, table in LDS,
 // haystack requested 64 bytes per lane one block ahead
 template <int NWS>
@@ -749,6 +877,39 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     if (P.hay_len < P.needle_len || P.needle_len == 0) return hipSuccess;
     // needles of 9..32 bytes whose k needs few counter bits: bit-sliced counters, 3 B + 3 instructions per byte against the SWAR form's
     // 3 per needle dword + 3 (TA_HAMMING_SEARCH_NO_BITS=1 keeps the SWAR form)
+    // bit-sliced counters over a subset of the needle's positions, Q phases per dword (ham_phase_body.h): any needle length, where the
+    // subset is selective for k and the form costs fewer instructions per byte than the SWAR form (TA_HAMMING_SEARCH_NO_PHASE=1: without)
+    {
+        uint32_t Q = 0, L = 0; int B = 0;
+        const uint32_t swar_x4 = 4u * (3u * ((P.needle_len + 3u) / 4u) + 4u);
+        if (P.needle_dev && ham_phase_plan(P.needle_len, P.k, Q, L, B) && (P.needle_len > 64u || ham_phase_cost_x4(Q, B) < swar_x4) &&
+            !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA") && !env_str("TA_HAMMING_SEARCH_NO_BITS") &&
+            !env_str("TA_HAMMING_SEARCH_NO_PHASE")) {
+            if (const char *fq = env_str("TA_HAMMING_PHASE_Q")) {                    // tests: force fewer phases (1 or 2) where the plan allows them
+                const uint32_t q = (uint32_t)atoi(fq);
+                if ((q == 1u || q == 2u) && q < Q) {
+                    uint32_t l = (P.needle_len + q - 1u) / q;
+                    if (l > 32u / q) l = 32u / q;
+                    Q = q; L = l;
+                }
+            }
+            const HamPhaseGeom G = ham_phase_geom(Q, L);
+            uint64_t tile = (P.hay_len + 262143) / 262144;            // two sets of resident lanes
+            tile = (tile + 127) & ~(uint64_t)127;
+            if (tile < 256) tile = 256;
+            P.tile = (uint32_t)(tile > 0x7FFFFF80ull ? 0x7FFFFF80ull : tile);
+            const uint64_t lanes = (P.hay_len + P.tile - 1) / P.tile;
+            const dim3 grid((uint32_t)((lanes + 511) / 512)), block(512);
+            if (nul_done) *nul_done = nul_flag != nullptr;
+            set_last_kernel_name("hamming_search_phase_kernel<%u,%d>", Q, B);
+#define TA_HP(QQ, BB) hipLaunchKernelGGL((hamming_search_phase_kernel<QQ, BB>), grid, block, 0, s, P, G, nul_flag)
+#define TA_HPB(QQ) switch (B) { case 1: TA_HP(QQ, 1); break; case 2: TA_HP(QQ, 2); break; case 3: TA_HP(QQ, 3); break; case 4: TA_HP(QQ, 4); break; default: TA_HP(QQ, 5); break; }
+            if (Q == 4u) { TA_HPB(4) } else if (Q == 2u) { TA_HPB(2) } else { TA_HPB(1) }
+#undef TA_HPB
+#undef TA_HP
+            return hipGetLastError();
+        }
+    }
     const int planes = ham_bits_planes(P.k);
     if (P.needle_len >= 9 && P.needle_len <= 32 && planes && P.k < P.needle_len && 3 * planes + 3 < 3 * (int)((P.needle_len + 3) / 4) + 1 &&
         !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA") && !env_str("TA_HAMMING_SEARCH_NO_BITS")) {
@@ -792,6 +953,7 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
         const uint64_t lanes = (offsets + P.tile - 1) / P.tile;
         const uint32_t grid = (uint32_t)((lanes + 255) / 256);
         const uint32_t nws = (P.needle_len + 3) / 4;
+        set_last_kernel_name("hamming_search_sa_kernel<%u>", nws <= 2 ? 2u : nws <= 4 ? 4u : 8u);
         if (nws <= 2) hipLaunchKernelGGL(hamming_search_sa_kernel<2>, dim3(grid), dim3(256), 0, s, P);
         else if (nws <= 4) hipLaunchKernelGGL(hamming_search_sa_kernel<4>, dim3(grid), dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hamming_search_sa_kernel<8>, dim3(grid), dim3(256), 0, s, P);
@@ -799,6 +961,7 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     }
     const uint32_t delta = (uint32_t)((uintptr_t)P.hay & 3u);
     const uint64_t groups = (P.hay_len - P.needle_len + delta) / 4 + 1;
+    set_last_kernel_name("hamming_search_kernel");
     hipLaunchKernelGGL(hamming_search_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, P, delta);
     return hipGetLastError();
 }

@@ -14,6 +14,8 @@
 
 #include "wave.h"
 
+#include "lev_plan.h"
+
 namespace ta {
 
 constexpr uint32_t SRCH_INF = 0x3FFFFFFFu;
@@ -28,25 +30,12 @@ static inline bool srch_anchored_packed_ok(uint64_t h, uint32_t needle_len, uint
     return top < SRCH_PACKED_KINF;
 }
 
-// The candidate filter (lev_filter_body.h) scans with UNIT costs.  For any EditCosts it is still a SUPERSET filter when it runs with
-//     k' = max( k / min(mc, tc),  (k - sg) / min(mc, gc, tc) )              (tc only when the costs have a transposition)
-// An alignment the reference's recurrence prices at C <= k (src/levenshtein.rs:1709-1806: every cell value is the cost of one
-// concrete path) has x mismatches, g gap characters in o >= [g > 0] gap runs and t transpositions: C = x mc + g gc + o sg + t tc.
-// Its number of unit edits U = x + g + t (the unit restricted-Damerau scan counts a transposition as ONE edit) obeys
-// U min(mc, gc, tc) <= C - o sg: with a gap that is <= k - sg, without one g = 0 and U min(mc, tc) <= k.  The unit scan's cost at
-// that end position is the minimum over all paths, so it is <= U <= k': every block that holds a weighted hit is flagged, and
-// the exact kernel (which knows the real costs) runs on the flagged blocks only.  Unit costs times g give k / g exactly.
-// The scan's left context must cover a unit-cost match of k' edits: needle_len + k' + 2 columns (>= the exact kernel's halo,
-// since k' >= unit_k = (k - sg) / gc).
+// The candidate filter (lev_filter_body.h) scans with UNIT costs; under any other EditCosts it runs with k' = lev_unit_filter_k
+// (lev_plan.h) and is still a SUPERSET filter: every block that holds a weighted hit is flagged, and the exact kernel (which knows the
+// real costs) runs on the flagged blocks only.  The scan's left context must cover a unit-cost match of k' edits: needle_len + k' + 2
+// columns (>= the exact kernel's halo, since k' >= unit_k = (k - sg) / gc).
 static inline uint32_t srch_filter_k(uint32_t k, uint32_t mc, uint32_t gc, uint32_t sg, bool has_t, uint32_t tc) {
-    uint32_t m_nogap = mc, m_all = mc < gc ? mc : gc;
-    if (has_t) {
-        if (tc < m_nogap) m_nogap = tc;
-        if (tc < m_all) m_all = tc;
-    }
-    if (m_all == 0) return 0xFFFFFFFFu;                       // (check_search refuses such costs: no filter)
-    const uint32_t with_gap = (k > sg ? k - sg : 0u) / m_all, without = k / m_nogap;
-    return with_gap > without ? with_gap : without;
+    return lev_unit_filter_k(k, mc, gc, sg, has_t, tc);
 }
 
 struct SearchCosts {

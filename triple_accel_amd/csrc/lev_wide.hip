@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64) void lev_wide_kernel(LevParams P, WideScratch S
     uint32_t *line_base = S.buf + (uint64_t)blockIdx.x * (6 * S.line);
     auto col0 = [&](uint32_t i) -> uint32_t { return i ? i * gc + sg : 0u; };   // dp(i, 0)
 
-    for (uint32_t slot = blockIdx.x; slot < P.n; slot += gridDim.x) {
+    const uint32_t n_pairs = P.n_dev ? *P.n_dev : P.n;   // (a list whose length only the device knows: the rounds of ta_levenshtein_exp_batch)
+    for (uint32_t slot = blockIdx.x; slot < n_pairs; slot += gridDim.x) {
         const uint32_t pair = P.subset ? P.subset[slot] : slot;
         const uint8_t *ap, *bp;
         uint32_t n, m;

@@ -10,6 +10,12 @@ namespace ta {
 template <int NWL, bool TRANS>
 __global__ __launch_bounds__(64) void lev_widebits_kernel(LevParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (P.n_dev) {                                     // a list whose length only the device knows (the rounds of ta_levenshtein_exp_batch)
+        LevParams Q = P;
+        Q.n = *P.n_dev;
+        LevWideBits<DevWave, NWL, TRANS>::run(Q, blockIdx.x, gridDim.x, lds);
+        return;
+    }
     LevWideBits<DevWave, NWL, TRANS>::run(P, blockIdx.x, gridDim.x, lds);
 }
 

@@ -140,6 +140,8 @@ int env_int(const char *name) {
 
 static thread_local bool g_opt_early_out = false;
 bool early_out_enabled() { return g_opt_early_out || env_int("TA_EARLY_OUT"); }
+static thread_local bool g_opt_unit_prefilter = false;
+bool unit_prefilter_enabled() { return g_opt_unit_prefilter || env_int("TA_UNIT_PREFILTER"); }
 
 static bool costs_ok(const ta_edit_costs *c) {   // EditCosts::new, src/levenshtein.rs:44-52
     if (!c) return false;
@@ -173,16 +175,20 @@ static int side_max_len(const ta_strings *s, uint32_t n, hipStream_t st, uint64_
 // One k-bounded distance pass over the batch (or over `subset`); the heart of every distance entry point.
 // columns_ordered: `subset` lists the pairs by their exact column count (length_order_launch): 64 consecutive ones share it -- what
 // the VLINE form of the bit-parallel band kernel wants (one pass per wavefront)
+// n_dev (optional): the length of `subset` as a kernel before this pass left it on the device -- n_work is then its upper bound (grids,
+// kernel choice) and the kernels read the real count themselves (the rounds of ta_levenshtein_exp_batch: no host round trip between them)
 static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, const uint32_t *subset, uint32_t k,
-                    const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st, bool columns_ordered = false) {
+                    const ta_edit_costs *c, uint64_t max_len, uint32_t *out_dev, hipStream_t st, bool columns_ordered = false,
+                    const uint32_t *n_dev = nullptr) {
     const uint32_t gc = c->gap_cost, sg = c->start_gap_cost;
+    if (env_int("TA_FAIL_PASS")) { set_last_error_msg("TA_FAIL_PASS: a distance pass that fails (tests)"); return TA_ERR_UNSUPPORTED; }
     // unit costs times g: the unit-cost kernels with k / g, then the answers times g (lev_plan.h: lev_unit_scale)
     if (const uint32_t g = lev_unit_scale(c->mismatch_cost, gc, sg, c->has_transpose != 0, c->transpose_cost);
         g && !env_int("TA_NO_BITS") && !env_int("TA_NO_UNIT_SCALE") && !env_int("TA_FORCE_D") && !env_int("TA_FORCE_L")) {
         const ta_edit_costs uc = {1, 1, 0, (uint8_t)(c->has_transpose ? 1 : 0), (uint8_t)(c->has_transpose ? 1 : 0)};
-        int rc = lev_pass(a, b, n_work, subset, k / g, &uc, max_len, out_dev, st, columns_ordered);
+        int rc = lev_pass(a, b, n_work, subset, k / g, &uc, max_len, out_dev, st, columns_ordered, n_dev);
         if (rc) return rc;
-        TA_HIP(scale_results_launch(out_dev, subset, n_work, g, st));
+        TA_HIP(scale_results_launch(out_dev, subset, n_work, n_dev, g, st));
         g_answer_single_store = false;                 // two stores to the result slot: the single-call path waits for the stream
         ta_lev_select sel;
         ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, c, &sel);
@@ -196,6 +202,7 @@ static int lev_pass(const ta_strings *a, const ta_strings *b, uint32_t n_work, c
     P.mc = c->mismatch_cost; P.gc = gc; P.sg = sg; P.tc = c->has_transpose ? c->transpose_cost : 0;
     P.u = pl.u; P.o = pl.o;
     if (columns_ordered && subset) P.tune |= 4u;
+    if (n_dev) { P.n_dev = n_dev; P.tune |= 8u; }     // (tune bit 3: the grid of the upper bound, lev_bits.hip)
     const bool affine = sg > 0 || env_int("TA_FORCE_AFFINE"), trans = c->has_transpose != 0;
     ta_launch_info li = {};
     li.band_offset = pl.o; li.affine = affine; li.transpose = trans;
@@ -384,6 +391,7 @@ const char *ta_last_error(void) { return g_last_error.c_str(); }
 const char *ta_last_kernel_name(void) { return g_last_kernel_name; }
 int ta_set_option(int option, int value) {
     if (option == TA_OPT_EARLY_OUT) { g_opt_early_out = value != 0; return TA_OK; }
+    if (option == TA_OPT_UNIT_PREFILTER) { g_opt_unit_prefilter = value != 0; return TA_OK; }
     set_last_error_msg("unknown option");
     return TA_ERR_ARG;
 }
@@ -476,6 +484,27 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
                           lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, costs->transpose_cost);
         const bool by_steps = !unit || env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L");
         if ((rc = order_pairs(a, b, (uint32_t)n, u, max_len, by_steps, env_int("TA_BITS_VLINE") != 0, st, &order, &exact_columns))) return rc;
+    }
+    // TA_OPT_UNIT_PREFILTER (an option, off by default: the work then depends on the data): a weighted batch first runs the UNIT-cost
+    // bit-parallel band pass with k' = lev_unit_filter_k -- "unit distance > k'" implies "weighted distance > k", i.e. None
+    // (src/levenshtein.rs:539-541) -- and the DP band kernel prices only the pairs that pass answered (a list whose length stays on the
+    // device).  Dissimilar batches cost the unit pass alone; a batch of near pairs pays for both.
+    if (unit_prefilter_enabled() && n >= 1024 && !env_int("TA_NO_BITS") && !env_int("TA_FORCE_D") && !env_int("TA_FORCE_L")) {
+        const bool trans = costs->has_transpose != 0;
+        const bool unit_family = (costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!trans || costs->transpose_cost == 1)) ||
+                                 lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, costs->transpose_cost);
+        const uint32_t kf = lev_unit_filter_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, costs->transpose_cost);
+        if (!unit_family && kf != 0xFFFFFFFFu && lev_choose(kf, 1, 1, 0, trans, trans ? 1u : 0u, max_len, false, (uint32_t)n).kernel == LEV_K_BITS) {
+            const ta_edit_costs uc = {1, 1, 0, (uint8_t)(trans ? 1 : 0), (uint8_t)(trans ? 1 : 0)};
+            Scratch &lst = tls_scratch(4), &cnt = tls_scratch(3);
+            if ((rc = lst.ensure(n * 4)) || (rc = cnt.ensure(16))) return rc;
+            if ((rc = lev_pass(a, b, (uint32_t)n, order, kf, &uc, max_len, out_dev, st, false))) return rc;
+            TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
+            TA_HIP(compact_some_launch(out_dev, order, (uint32_t)n, (uint32_t *)lst.dev, (uint32_t *)cnt.dev, st));
+            rc = lev_pass(a, b, (uint32_t)n, (const uint32_t *)lst.dev, k, costs, max_len, out_dev, st, false, (const uint32_t *)cnt.dev);
+            g_answer_single_store = false;
+            return rc;
+        }
     }
     return lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st, exact_columns);
 }
@@ -608,6 +637,44 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     int flip = 0;
     const uint32_t tcx = costs->has_transpose ? costs->transpose_cost : 0;
     const bool dpo = env_int("TA_NO_BITS") != 0, faithful = env_int("TA_EXP_FAITHFUL") != 0;
+    // Big batches: the rounds are DEVICE-DRIVEN -- every list (the pairs a round works on, the pairs it leaves unresolved) carries its
+    // length in a device counter that the next kernel reads, every launch is sized for the list's upper bound (the batch) and the
+    // wavefronts behind its end leave at once: the whole k schedule is enqueued without a host round trip between rounds, the call
+    // returns while the device works (and can be captured in a hipGraph).  The schedule itself is the host-driven one's for a list that
+    // never shrinks: k = 30, 60, ... until a bounded pass would cost more than a quarter of the unbounded one, then k = u32::MAX -- a
+    // round whose list is empty costs its (empty) launches, 10-15 us.  Small batches (a lone pair's first round is the unbounded one;
+    // the kernel choice follows the number of pairs left) keep the host-driven loop below.  TA_EXP_HOST_ROUNDS=1 pins it.
+    if (n >= 1024 && !faithful && !env_int("TA_EXP_HOST_ROUNDS")) {
+        constexpr int MAX_ROUNDS = 40;
+        if ((rc = cnt.ensure(2 * MAX_ROUNDS * 4))) return rc;
+        TA_HIP(hipMemsetAsync(cnt.dev, 0, 2 * MAX_ROUNDS * 4, st));
+        uint32_t *counters = (uint32_t *)cnt.dev;
+        const uint32_t *n_in_dev = nullptr;                 // the length of sub_in (nullptr: n, exactly)
+        for (int round = 0; round < MAX_ROUNDS; round++) {
+            if (!faithful && k != 0xFFFFFFFFu) {
+                const double c_this = lev_choose(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo, (uint32_t)n).cost;
+                const double c_full = lev_choose(0xFFFFFFFFu, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, tcx, max_len, dpo, (uint32_t)n).cost;
+                if (c_this > 0.25 * c_full) k = 0xFFFFFFFFu;
+            }
+            const uint32_t *work = sub_in, *work_n_dev = n_in_dev;
+            if (bounded && k != 0xFFFFFFFFu) {
+                TA_HIP(compact_bound_launch(out_dev, (const uint32_t *)bnd.dev, k, sub_in, (uint32_t)n, n_in_dev, (uint32_t *)wrk.dev, counters + 2 * round, st));
+                work = (const uint32_t *)wrk.dev;
+                work_n_dev = counters + 2 * round;
+            }
+            rc = lev_pass(a, b, (uint32_t)n, work, k, costs, max_len, out_dev, st, false, work_n_dev);
+            g_exp_passes++;
+            if (rc) return rc;
+            if (k == 0xFFFFFFFFu) break;                    // the unbounded pass answers every pair it is given (all that were left)
+            TA_HIP(compact_none_launch(out_dev, sub_in, (uint32_t)n, n_in_dev, bufs[flip], counters + 2 * round + 1, st));
+            sub_in = bufs[flip];
+            n_in_dev = counters + 2 * round + 1;
+            flip ^= 1;
+            k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;    // k *= 2 (:1452); saturate instead of wrapping
+        }
+        g_answer_single_store = false;
+        return TA_OK;
+    }
     for (int round = 0; round < 40 && n_left > 0; round++) {
         // Once a bounded pass would cost more than a quarter of the unbounded one (kernel cost model, lev_plan.h: per pair for
         // big passes, per wavefront for small ones), it is cheaper in expectation to finish the unresolved pairs with
@@ -621,7 +688,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
         uint32_t n_work = n_left;
         if (bounded && k != 0xFFFFFFFFu) {
             TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
-            TA_HIP(compact_bound_launch(out_dev, (const uint32_t *)bnd.dev, k, sub_in, n_left, (uint32_t *)wrk.dev, (uint32_t *)cnt.dev, st));
+            TA_HIP(compact_bound_launch(out_dev, (const uint32_t *)bnd.dev, k, sub_in, n_left, nullptr, (uint32_t *)wrk.dev, (uint32_t *)cnt.dev, st));
             TA_HIP(hipMemcpyAsync(&n_work, cnt.dev, 4, hipMemcpyDeviceToHost, st));
             TA_HIP(hipStreamSynchronize(st));
             work = (const uint32_t *)wrk.dev;
@@ -634,7 +701,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
             if (rc) return rc;
             if (k == 0xFFFFFFFFu) break;                    // the unbounded pass answers every pair it is given (all that were left)
             TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
-            TA_HIP(compact_none_launch(out_dev, sub_in, n_left, bufs[flip], (uint32_t *)cnt.dev, st));
+            TA_HIP(compact_none_launch(out_dev, sub_in, n_left, nullptr, bufs[flip], (uint32_t *)cnt.dev, st));
             uint32_t left = 0;
             TA_HIP(hipMemcpyAsync(&left, cnt.dev, 4, hipMemcpyDeviceToHost, st));
             TA_HIP(hipStreamSynchronize(st));
@@ -1065,6 +1132,32 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
     uint64_t max_len = 0;
     if ((rc = batch_max_len(a, b, (uint32_t)n, st, &max_len))) return rc;
     const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
+    // LEVENSHTEIN_COSTS / RDAMERAU_COSTS with a band of up to 33 diagonals (k <= 32; 30 with the transposition term): no per-cell records --
+    // the distance pass, then ONE kernel that sweeps the columns forwards with a checkpoint (8 bytes per pair) every 16 columns, recomputes
+    // tile after tile backwards with the column states of the tile in LDS, walks, and writes the runs (lev_bits_trace_body.h): 2 x the
+    // strings' bytes instead of 21 x.  TA_TRACE_NO_BITS=1 keeps the DP band kernel's records for these cost sets too.
+    {
+        const bool trans = costs->has_transpose != 0;
+        const bool unit = costs->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || costs->transpose_cost == 1);
+        const uint32_t u = lev_batch_unit_k(k, 1, 1, 0, max_len);
+        if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len <= 0x7FFFFFF0ull && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
+            if ((rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
+            const uint32_t tile = lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
+            const uint32_t path_words = (uint32_t)((2 * max_len) / 16 + 2);
+            Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
+            if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (rc = ps.ensure((size_t)n * path_words * 4u)) ||
+                (rc = ss.ensure((size_t)n * 4u))) return rc;
+            LevBitsTraceParams T;
+            T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
+            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.path = (uint32_t *)ps.dev; T.path_words = path_words; T.steps = (uint32_t *)ss.dev;
+            ta_launch_info li = g_last_launch;                 // (the distance pass's: kernel 3)
+            uint32_t grid = 0, lds = 0;
+            TA_HIP(lev_bits_trace_launch(T, trans, edits_dev, n_edits_dev, cap, st, &grid, &lds));
+            li.kernel = 8; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
+            g_last_launch = li;
+            return TA_OK;
+        }
+    }
     // the trace kernels exist for 16, 34 and 66 diagonals per lane: the cheapest layout per pair that holds the band
     LevPlan pl = {};
     pl.ok = false;
@@ -1078,8 +1171,14 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
     const uint32_t tw = (uint32_t)lev_trace_words(pl.D);
     const uint64_t taus = (2 * max_len + 1) / 2 + 1;
     const uint64_t wave_words = taus * 2 * 64 * tw;
-    // the records of one chunk: at most ~4 GiB (or one wavefront's, if that is more)
-    uint64_t waves_per_chunk = ((4ull << 30) / 4) / wave_words;
+    // the records of one chunk: at most ~4 GiB and at most a quarter of the device memory that is free right now (or one wavefront's, if
+    // that is more)
+    uint64_t rec_budget = 4ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < rec_budget) rec_budget = free_b / 4;
+    }
+    uint64_t waves_per_chunk = (rec_budget / 4) / wave_words;
     if (waves_per_chunk == 0) waves_per_chunk = 1;
     const uint64_t waves_all = (n + pl.PW - 1) / pl.PW;
     if (waves_per_chunk > waves_all) waves_per_chunk = waves_all;

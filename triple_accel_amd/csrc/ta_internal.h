@@ -66,6 +66,7 @@ int env_int(const char *name);
 
 // ta_set_option(TA_OPT_EARLY_OUT) of the calling thread
 bool early_out_enabled();
+bool unit_prefilter_enabled();
 // true when a HIP device is usable (lazy, cached)
 bool device_ready();
 
@@ -99,11 +100,17 @@ hipError_t lev_wide_launch(const LevParams &P, bool trans, hipStream_t s, uint32
                            uint32_t *threads_out, uint32_t *dpt_out);
 hipError_t hamming_batch_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t *out, hipStream_t s);
 hipError_t strings_maxlen_launch(const StrView &s, uint32_t n, uint32_t *out_max /*device, pre-zeroed*/, hipStream_t st);
-hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out,
-                               uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
-hipError_t scale_results_launch(uint32_t *out, const uint32_t *list /*pairs, or nullptr: 0..n*/, uint32_t n, uint32_t g, hipStream_t st);
+hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, const uint32_t *n_in_dev /*optional: the list's length on the device*/,
+                               uint32_t *subset_out, uint32_t *count, hipStream_t st);
+// batch tracebacks of the unit-cost families by checkpoints + recomputation (lev_bits_trace.hip; bands of up to 33 diagonals)
+uint32_t lev_bits_trace_ckpt_words(bool trans);
+uint32_t lev_bits_trace_tile();
+hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
+                                 uint32_t *grid_out, uint32_t *lds_out);
+hipError_t compact_some_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
+hipError_t scale_results_launch(uint32_t *out, const uint32_t *list /*pairs, or nullptr: 0..n*/, uint32_t n, const uint32_t *n_dev, uint32_t g, hipStream_t st);
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
-                                uint32_t *list_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
+                                const uint32_t *n_in_dev, uint32_t *list_out, uint32_t *count, hipStream_t st);
 hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st);
 hipError_t hits_best_launch(const ta_match *hits, uint64_t n, uint32_t *min_k /*device, preset to ~0*/, ta_match *out, uint32_t cap,
                             uint32_t *count /*device, pre-zeroed*/, hipStream_t st);

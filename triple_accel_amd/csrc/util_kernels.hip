@@ -80,48 +80,74 @@ hipError_t strings_maxlen_launch(const StrView &s, uint32_t n, uint32_t *out_max
     return hipGetLastError();
 }
 
-// exp search: collect the pairs whose result is still None into the next round's subset
-__global__ void compact_none_kernel(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in,
-                                    uint32_t *subset_out, uint32_t *count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
-    uint32_t pair = subset_in ? subset_in[i] : i;
-    if (out[pair] == 0xFFFFFFFFu) subset_out[atomicAdd(count, 1u)] = pair;
+// exp search: collect the pairs whose result is still None into the next round's subset.  n_in_dev (optional): the input list's length as
+// a kernel before this one left it on the device (n_in is then its upper bound: the grid).  One atomic per wavefront: the lanes that keep
+// their pair take consecutive places in lane order.
+__device__ __forceinline__ void compact_append(bool keep, uint32_t pair, uint32_t *list_out, uint32_t *count) {
+    const unsigned long long mask = __ballot(keep);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (keep) list_out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = pair;
 }
-hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out,
+__global__ void compact_none_kernel(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, const uint32_t *n_in_dev,
+                                    uint32_t *subset_out, uint32_t *count) {
+    if (n_in_dev) n_in = *n_in_dev;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n_in;
+    const uint32_t pair = in ? (subset_in ? subset_in[i] : i) : 0u;
+    compact_append(in && out[pair] == 0xFFFFFFFFu, pair, subset_out, count);
+}
+// the complement: the pairs a pass ANSWERED (the unit-cost pre-pass of weighted batches, TA_OPT_UNIT_PREFILTER: its survivors)
+__global__ void compact_some_kernel(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n_in;
+    const uint32_t pair = in ? (subset_in ? subset_in[i] : i) : 0u;
+    compact_append(in && out[pair] != 0xFFFFFFFFu, pair, subset_out, count);
+}
+hipError_t compact_some_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count, hipStream_t st) {
+    if (n_in == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_some_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, subset_in, n_in, subset_out, count);
+    return hipGetLastError();
+}
+hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, const uint32_t *n_in_dev, uint32_t *subset_out,
                                uint32_t *count, hipStream_t st) {
     if (n_in == 0) return hipSuccess;
-    hipLaunchKernelGGL(compact_none_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, subset_in, n_in,
+    hipLaunchKernelGGL(compact_none_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, subset_in, n_in, n_in_dev,
                        subset_out, count);
     return hipGetLastError();
 }
 
 // costs that are the unit costs times g (lev_unit_scale, lev_plan.h): the pass ran on unit costs with k / g, its answers times g
-__global__ void scale_results_kernel(uint32_t *out, const uint32_t *list, uint32_t n, uint32_t g) {
+__global__ void scale_results_kernel(uint32_t *out, const uint32_t *list, uint32_t n, const uint32_t *n_dev, uint32_t g) {
+    if (n_dev) n = *n_dev;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t pair = list ? list[i] : i;
     const uint32_t d = out[pair];
     if (d != 0xFFFFFFFFu) out[pair] = d * g;
 }
-hipError_t scale_results_launch(uint32_t *out, const uint32_t *list, uint32_t n, uint32_t g, hipStream_t st) {
+hipError_t scale_results_launch(uint32_t *out, const uint32_t *list, uint32_t n, const uint32_t *n_dev, uint32_t g, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(scale_results_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, list, n, g);
+    hipLaunchKernelGGL(scale_results_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, list, n, n_dev, g);
     return hipGetLastError();
 }
 
 // exp search with a lower bound: next round's work list = unresolved pairs whose bound admits the next threshold
 __global__ void compact_bound_kernel(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
-                                     uint32_t *list_out, uint32_t *count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
-    uint32_t pair = list_in ? list_in[i] : i;
-    if (out[pair] == 0xFFFFFFFFu && bound[pair] <= k) list_out[atomicAdd(count, 1u)] = pair;
+                                     const uint32_t *n_in_dev, uint32_t *list_out, uint32_t *count) {
+    if (n_in_dev) n_in = *n_in_dev;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n_in;
+    const uint32_t pair = in ? (list_in ? list_in[i] : i) : 0u;
+    compact_append(in && out[pair] == 0xFFFFFFFFu && bound[pair] <= k, pair, list_out, count);
 }
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
-                                uint32_t *list_out, uint32_t *count, hipStream_t st) {
+                                const uint32_t *n_in_dev, uint32_t *list_out, uint32_t *count, hipStream_t st) {
     if (n_in == 0) return hipSuccess;
-    hipLaunchKernelGGL(compact_bound_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, bound, k, list_in, n_in, list_out, count);
+    hipLaunchKernelGGL(compact_bound_kernel, dim3((n_in + 255) / 256), dim3(256), 0, st, out, bound, k, list_in, n_in, n_in_dev, list_out, count);
     return hipGetLastError();
 }
 

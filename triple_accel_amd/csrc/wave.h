@@ -91,6 +91,7 @@ struct DevWave {
     // (a << s) + b -> v_lshl_add_u32
     static __device__ __forceinline__ U32 lshl_add(U32 a, uint32_t s, U32 b) { return (a << s) + b; }
     // per-lane shift amounts (< 32)
+    static __device__ __forceinline__ U32 clz(U32 x) { return (U32)__clz((int)x); }        // leading zero bits, 32 for 0
     static __device__ __forceinline__ U32 shlv(U32 x, U32 s) { return x << s; }
     static __device__ __forceinline__ U32 shrv(U32 x, U32 s) { return x >> s; }
     // byte N of x, zero-extended (folds into the consumer as an SDWA byte select)
