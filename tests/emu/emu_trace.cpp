@@ -10,14 +10,14 @@
 
 using namespace ta;
 
-// ---- batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): distances in, the walk's 2-bit codes out
+// ---- batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): distances in, the scripts' runs (last run first) out
 #include "lev_bits_trace_body.h"
-// dist[n]: the pass's answers (0xFFFFFFFF = None); path[n * path_words], steps[n] out.  tile = 16 or 32.  Reads are range-checked: a byte
+// dist[n]: the pass's answers (0xFFFFFFFF = None); runs[n * runs_cap] ((edit type << 29) | count), n_runs[n] out.  tile = 8, 16 or 32.  Reads are range-checked: a byte
 // outside the blobs (+ 16 of slack) reads as 0xA5.
 extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, uint64_t a_len, const uint8_t *b_blob, const uint64_t *b_off,
                                   uint64_t b_len, uint32_t n, uint32_t u, int has_t, int tile, const uint32_t *dist, uint64_t max_len,
-                                  uint32_t *path, uint32_t path_words, uint32_t *steps) {
-    if (u + 1u + (has_t ? 2u : 0u) > 33u || (tile != 16 && tile != 32)) return 1;
+                                  uint32_t *runs, uint32_t runs_cap, uint32_t *n_runs) {
+    if (u + 1u + (has_t ? 2u : 0u) > 33u || (tile != 8 && tile != 16 && tile != 32)) return 1;
     LevBitsTraceParams P;
     P.a = StrView{a_blob, a_off, a_off ? 0 : a_len, a_off ? 0 : a_len};
     P.b = StrView{b_blob, b_off, b_off ? 0 : b_len, b_off ? 0 : b_len};
@@ -25,7 +25,7 @@ extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, 
     P.ckpt_tiles = (uint32_t)((max_len + (uint64_t)tile - 1) / (uint64_t)tile) + 1u;
     const uint32_t waves = (n + 63) / 64;
     std::vector<uint32_t> ck((size_t)waves * P.ckpt_tiles * 5u * 64u, 0xDEADBEEFu);
-    P.ckpt = ck.data(); P.path = path; P.path_words = path_words; P.steps = steps;
+    P.ckpt = ck.data(); P.runs = runs; P.runs_cap = runs_cap; P.n_runs = n_runs;
     struct RangeGuard { ~RangeGuard() { EmuWave::clear_ranges(); } } range_guard;
     EmuWave::clear_ranges();
     EmuWave::add_range(a_blob, (a_off ? a_off[n] : (uint64_t)n * a_len) + 16);
@@ -34,8 +34,10 @@ extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, 
     uint8_t *lds = (uint8_t *)malloc(lds_bytes);
     for (uint32_t w = 0; w < waves; w++) {
         memset(lds, 0xA5, lds_bytes);
-        if (tile == 16) { if (has_t) LevBitsTrace<EmuWave, true, 16>::run(P, w, lds); else LevBitsTrace<EmuWave, false, 16>::run(P, w, lds); }
-        else { if (has_t) LevBitsTrace<EmuWave, true, 32>::run(P, w, lds); else LevBitsTrace<EmuWave, false, 32>::run(P, w, lds); }
+        // (tile 8: string tiles of 32 columns, the device's default; 16: of 64; 32: of 64)
+        if (tile == 8) { if (has_t) LevBitsTrace<EmuWave, true, 8, 32>::run(P, w, lds); else LevBitsTrace<EmuWave, false, 8, 32>::run(P, w, lds); }
+        else if (tile == 16) { if (has_t) LevBitsTrace<EmuWave, true, 16, 64>::run(P, w, lds); else LevBitsTrace<EmuWave, false, 16, 64>::run(P, w, lds); }
+        else { if (has_t) LevBitsTrace<EmuWave, true, 32, 64>::run(P, w, lds); else LevBitsTrace<EmuWave, false, 32, 64>::run(P, w, lds); }
     }
     free(lds);
     return 0;

@@ -124,16 +124,17 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
 
 
 def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False):
-    """Batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): the walk's codes turned into the run-length script the
-    reference returns -- [(edit name, count)] per pair, None for a pair whose distance is None.  dists: the pass's answers (None = no
-    script); u: the pass's unit_k.  fixed: the strided (fixed-length) view of the batch instead of CSR."""
+    """Batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): the run-length script the reference returns --
+    [(edit name, count)] per pair, None for a pair whose distance is None (the body leaves the runs last run first: turned round here, as
+    the kernel's last step does).  dists: the pass's answers (None = no script); u: the pass's unit_k.  fixed: the strided (fixed-length)
+    view of the batch instead of CSR."""
     n = len(a_list)
     ab, ao = pack(a_list)
     bb, bo = pack(b_list)
     max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
-    pw = 2 * max_len // 16 + 2
-    path = np.full(n * pw, 0xDEADBEEF, dtype=np.uint32)
-    steps = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    cap = min(2 * max_len + 1, 2 * u + 2)
+    runs = np.full(n * cap, 0xDEADBEEF, dtype=np.uint32)
+    n_runs = np.full(n, 0xDEADBEEF, dtype=np.uint32)
     dist = np.array([0xFFFFFFFF if d is None else d for d in dists], dtype=np.uint32)
     f = lib().emu_lev_bits_trace
     f.restype = C.c_int
@@ -142,37 +143,22 @@ def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False):
     if fixed:
         la, lb = len(a_list[0]), len(b_list[0])
         assert all(len(x) == la for x in a_list) and all(len(x) == lb for x in b_list)
-        rc = f(ab.ctypes.data, None, la, bb.ctypes.data, None, lb, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, path.ctypes.data, pw, steps.ctypes.data)
+        rc = f(ab.ctypes.data, None, la, bb.ctypes.data, None, lb, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, runs.ctypes.data, cap, n_runs.ctypes.data)
     else:
-        rc = f(ab.ctypes.data, ao.ctypes.data, 0, bb.ctypes.data, bo.ctypes.data, 0, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, path.ctypes.data, pw, steps.ctypes.data)
+        rc = f(ab.ctypes.data, ao.ctypes.data, 0, bb.ctypes.data, bo.ctypes.data, 0, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, runs.ctypes.data, cap, n_runs.ctypes.data)
     if rc:
         raise RuntimeError("emu_lev_bits_trace rc=%d" % rc)
+    names = ["Match", "Mismatch", "AGap", "BGap", "Transpose"]
     out = []
     for p in range(n):
         if dists[p] is None:
-            assert steps[p] == 0
+            assert n_runs[p] == 0
             out.append(None)
             continue
-        a, b = a_list[p], b_list[p]
-        swap = len(a) > len(b)
-        x, y = (b, a) if swap else (a, b)
-        runs, fi, fj = [], 0, 0
-        for t in range(int(steps[p]) - 1, -1, -1):                          # the walk's last step is the script's first edit
-            code = (int(path[p * pw + (t >> 4)]) >> (2 * (t & 15))) & 3
-            if code == 0:
-                e = "Match" if x[fi] == y[fj] else "Mismatch"; fi += 1; fj += 1
-            elif code == 1:
-                e = "BGap" if swap else "AGap"; fj += 1
-            elif code == 2:
-                e = "AGap" if swap else "BGap"; fi += 1
-            else:
-                e = "Transpose"; fi += 2; fj += 2
-            if runs and runs[-1][0] == e:
-                runs[-1] = (e, runs[-1][1] + 1)
-            else:
-                runs.append((e, 1))
-        assert fi == len(x) and fj == len(y), (p, fi, fj, len(x), len(y))
-        out.append(runs)
+        nr = int(n_runs[p])
+        assert nr <= cap, (p, nr, cap)
+        ws = [int(w) for w in runs[p * cap:p * cap + nr]][::-1]
+        out.append([(names[w >> 29], w & 0x1FFFFFFF) for w in ws])
     return out
 
 

@@ -21,7 +21,7 @@ def _check(a, b, k, trans, tile, fixed=False):
 
 
 @pytest.mark.parametrize("trans", [False, True])
-@pytest.mark.parametrize("tile", [16, 32])
+@pytest.mark.parametrize("tile", [8, 16, 32])
 def test_trace_mutated_ragged(trans, tile):
     g = Dg.rng(0x7B1 + tile + int(trans))
     for k in (3, 8, 17, 30, 32):
@@ -59,6 +59,7 @@ def test_trace_small_alphabet_ties(trans):
                     del y[pos]
             a.append(x); b.append(bytes(y))
         assert _check(a, b, k, trans, 16) > 40
+        _check(a, b, k, trans, 8)
 
 
 @pytest.mark.parametrize("trans", [False, True])
@@ -71,7 +72,9 @@ def test_trace_fixed_length_and_long(trans):
     b[9] = bytes(g.integers(1, 255, size=256).astype(np.uint8))
     assert _check(a, b, 30 if trans else 32, trans, 16, fixed=True) > 90
     assert _check(a, b, 30 if trans else 32, trans, 32, fixed=True) > 90
+    assert _check(a, b, 30 if trans else 32, trans, 8, fixed=True) > 90
     a2 = [b"", b"abc", b"", b"kitten", b"ab", b"ba", b"abcdefgh" * 40, b"x" * 300]
     b2 = [b"", b"", b"xyz", b"sitting", b"ba", b"ab", (b"abcdefgh" * 40)[3:] + b"zz", b"x" * 290 + b"y" * 5]
     _check(a2, b2, 20, trans, 16)
+    _check(a2, b2, 20, trans, 8)
     _check(a2, b2, 20, trans, 32)

@@ -188,7 +188,7 @@ def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
     got_d, got_e = out.cpu().numpy().view(np.uint32), B.edits_to_lists(edits, ne)
     monkeypatch.setenv("TA_TRACE_TILE", "32")
     out32, edits32, ne32 = B.levenshtein_trace_batch(sa, sb, k, costs)
-    assert "32>" in T.last_kernel_name()
+    assert ", 32, " in T.last_kernel_name()
     monkeypatch.delenv("TA_TRACE_TILE")
     monkeypatch.setenv("TA_TRACE_NO_BITS", "1")
     out_dp, edits_dp, ne_dp = B.levenshtein_trace_batch(sa, sb, k, costs)

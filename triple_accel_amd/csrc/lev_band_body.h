@@ -41,9 +41,9 @@ struct LevBitsTraceParams {
     uint32_t u;                  // unit_k of the pass: the band holds u + 1 (+ 2 with the transposition term) <= 33 diagonals
     uint32_t *ckpt;              // scratch: [wave][tile][word][lane]
     uint32_t ckpt_tiles;         // tiles per wavefront the scratch holds (>= ceil(longest column count / TILE))
-    uint32_t *path;              // [pair][path_words]: the codes of the walk, sixteen per word, first step of the WALK (the last edit) first
-    uint32_t path_words;
-    uint32_t *steps;             // [pair]: steps of the walk (0 for None)
+    uint32_t *runs;              // [pair][runs_cap]: the runs of the script as the walk closes them -- LAST run first -- (edit type << 29) | count
+    uint32_t runs_cap;           // >= 2 u + 2 (a script of cost <= u has at most 2 u + 1 runs) and >= the longest n + m where that is smaller
+    uint32_t *n_runs;            // [pair]: runs of the script (0 for None)
 };
 
 struct LevParams {

@@ -11,11 +11,11 @@
 //      column: 8 bytes per pair and checkpoint, in scratch memory;
 //   B. tile by tile from the last one down: restore the tile's checkpoint, run its TILE columns again -- the same step8 -- and keep what
 //      the walk needs of EVERY column of the tile in LDS (3 words per column and lane); then every lane walks its path through the tile,
-//      from where it entered it to the tile's first column, packing the 2-bit codes it takes (0 diagonal, 1 left, 2 up, 3 transposition --
-//      lev_trace_walk.h's) sixteen per word into the pair's path words.
+//      from where it entered it to the tile's first column, and counts the RUNS of the script as it goes -- the characters are in LDS, so a
+//      diagonal step is a Match or a Mismatch on the spot -- storing a run (edit type, count: one word) when it closes: last run first.
 // The strings go straight from memory into a per-lane LDS slot, a tile's bytes at a time (a lane's 16-byte loads; every line of a string
-// is touched twice -- forwards, backwards -- instead of the records' 16 x).  The caller replays the path forwards and writes the runs
-// (lev_band.hip: trace_emit_runs, shared with the DP kernel's walk).
+// is touched a few times -- forwards, backwards -- instead of the records' 16 x).  A last step turns the pair's runs round and writes them as
+// ta_edit records (lev_bits_trace.hip).
 //
 // The distances come from the distance kernel (the caller runs it first): a pair it answered None has no script, and the walk needs no
 // absolute value.  Rows = the SHORTER string (the reference swaps, :386-390: the tie order depends on it); swap is per lane.
@@ -26,9 +26,13 @@ namespace ta {
 
 // (LevBitsTraceParams: lev_band_body.h, next to LevParams)
 
-template <class W, bool TRANS, int TILE = 16>
+// TILE: columns per checkpoint / per set of records in LDS; STILE: columns whose characters one fill of the string slots covers (a multiple
+// of TILE: every 128-byte line of a string is then touched STILE / 16 times less often -- with one fill per TILE columns the kernel read
+// 90 lines per 256-byte pair, 11.5 GB per million pairs at the L2's fabric side, and waited for them)
+template <class W, bool TRANS, int TILE = 16, int STILE = 64>
 struct LevBitsTrace {
-    static_assert(TILE == 16 || TILE == 32, "tiles of one or two 16-byte pieces of b");
+    static_assert(TILE == 8 || TILE == 16 || TILE == 32, "tiles of whole 8-column blocks");
+    static_assert(STILE % TILE == 0 && STILE >= TILE && STILE <= 128, "string tiles hold whole tiles");
     using K = LevBits<W, 8, TRANS, false, false, true>;
     using State = typename K::State;
     using U32 = typename W::U32;
@@ -39,7 +43,7 @@ struct LevBitsTrace {
     static constexpr uint32_t CK_WORDS = TRANS ? 5 : 2;                  // VP, VN (, PM', bottom PM', D0')
     // per-lane string slot: a = PA pieces covering a-indices [a_lo, a_lo + 16 PA) -- the tile's bytes, the 32 before them (the window is
     // rebuilt from those) and 8 more (the walk compares the eight characters up to a[i - 1] at once); b = PB pieces from 16 bytes before the tile
-    static constexpr uint32_t PA = (40 + TILE + 15 + 15) / 16, PB = 1 + TILE / 16;
+    static constexpr uint32_t PA = (40 + STILE + 15 + 15) / 16, PB = 1 + STILE / 16, RT = STILE / TILE;
     static constexpr uint32_t SLOT = 16 * (PA + PB) + 4;                 // bytes per lane (an odd number of dwords)
     // records, [word][lane]: pre-column VP / VN of columns 0 .. TILE (TILE = the column behind the tile), D0 of columns 0 .. TILE - 1,
     // one word of bottom-diagonal D0 bits (bit c = column c), and for the transposition test the D0 of the column in front of the tile
@@ -53,14 +57,15 @@ struct LevBitsTrace {
         const U32 pair = W::sel(in_batch, slot_idx, W::splat(0));
         Ptr xp, yp;
         U32 n, m;
+        Bool swapped = W::bfalse();
         {
             Ptr ap, bp;
             U32 al, bl;
             W::load_str(P.a, pair, in_batch, ap, al);
             W::load_str(P.b, pair, in_batch, bp, bl);
-            const Bool swap = al > bl;                                     // rows = the shorter string (:386-390)
-            xp = W::sel_ptr(swap, bp, ap); yp = W::sel_ptr(swap, ap, bp);
-            n = W::sel(swap, bl, al); m = W::sel(swap, al, bl);
+            swapped = al > bl;                                             // rows = the shorter string (:386-390)
+            xp = W::sel_ptr(swapped, bp, ap); yp = W::sel_ptr(swapped, ap, bp);
+            n = W::sel(swapped, bl, al); m = W::sel(swapped, al, bl);
         }
         const U32 dist = W::load_u32(P.dist, pair, in_batch, 0xFFFFFFFFu);
         const Bool some = in_batch & (dist != 0xFFFFFFFFu);                // (answered: inside the band, d <= k)
@@ -80,9 +85,12 @@ struct LevBitsTrace {
         // ---- the strings of tile t (iterations [tb, tb + TILE), tb = T0 + TILE t; iteration tp slides a[tp - T0 + nlo] in and runs column
         // tp - T0 + 1 with b[tp - T0]): pieces on the strings' own 16-byte grids, zeros outside the strings
         U32 a_lo = W::splat(0);                                            // a-index of the slot's first byte (may be "negative": two's complement)
-        auto load_tile = [&](uint32_t t) {
+        uint32_t b_lo = 0, loaded = 0xFFFFFFFFu;                           // b-index of the b slot's first byte; the string tile the slots hold
+        auto load_strings = [&](uint32_t T) {
+            if (T == loaded) return;
+            loaded = T;
             const Bool all = (lane == lane);
-            const U32 first = (W::splat((uint32_t)TILE * t) + nlo) - 40u;  // a-index the tile needs first (mod 2^32)
+            const U32 first = (W::splat((uint32_t)STILE * T) + nlo) - 40u; // a-index the string tile needs first (mod 2^32)
             a_lo = first & ~15u;
 #pragma unroll
             for (uint32_t p = 0; p < PA; p++) {
@@ -90,18 +98,19 @@ struct LevBitsTrace {
                 const Bool ok = some & (q0 < n);
                 W::lds_store16(lds, slot + 16u * p, W::gload16(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))), ok), all);
             }
+            b_lo = (uint32_t)STILE * T - 16u;
 #pragma unroll
             for (uint32_t p = 0; p < PB; p++) {
-                const bool front = t == 0u && p == 0u;                     // the piece in front of the string: zeros
-                const uint32_t q0 = front ? 0u : (uint32_t)TILE * t - 16u + 16u * p;
+                const bool front = T == 0u && p == 0u;                     // the piece in front of the string: zeros
+                const uint32_t q0 = front ? 0u : b_lo + 16u * p;
                 const Bool ok = front ? W::bfalse() : (some & (W::splat(q0) < m));
                 W::lds_store16(lds, slot + 16u * (PA + p), W::gload16(W::ptr_add(yp, W::splat(q0)), ok), all);
             }
             W::lds_wave_sync();
         };
-        // LDS addresses of the bytes of iteration tp (a) / column byte index c0 (b)
+        // LDS addresses of the bytes of iteration tp (a) / of b[tp - T0]
         auto a_addr = [&](uint32_t tp) { return slot + (((W::splat(tp - T0) + nlo) - a_lo)); };
-        auto b_addr = [&](uint32_t t, uint32_t tp) { return slot + 16u * PA + ((tp - T0) - ((uint32_t)TILE * t - 16u)); };
+        auto b_addr = [&](uint32_t tp) { return slot + 16u * PA + ((tp - T0) - b_lo); };
 
         State st;
         auto init_state = [&]() {
@@ -135,7 +144,7 @@ struct LevBitsTrace {
             U32 bot = W::splat(0);
             for (uint32_t c = 0; c < (uint32_t)TILE; c += 8u) {
                 const uint32_t tp = tb + c;
-                const U32 pa = a_addr(tp), pb = W::splat(0) + b_addr(t, tp);
+                const U32 pa = a_addr(tp), pb = W::splat(0) + b_addr(tp);
                 const U32 r0 = W::lds_read32u(lds, pa), r1 = W::lds_read32u(lds, pa + 4u);
                 const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
                 const U32 b0 = W::lds_read32u(lds, pb), b1 = W::lds_read32u(lds, pb + 4u);
@@ -169,33 +178,28 @@ struct LevBitsTrace {
         // ---- F: forwards, a checkpoint in front of every tile
         init_state();
         for (uint32_t t = 0; t < tiles; t++) {
-            load_tile(t);
+            load_strings(t / RT);
             if (t == 0) rebuild_window(T0);
             save_ckpt(t);
             run_tile(t, std::false_type());
         }
         // ---- B: backwards, tile by tile
         U32 i = W::sel(some, n, W::splat(0)), j = W::sel(some, m, W::splat(0));
-        U32 steps = W::splat(0), acc = W::splat(0);
-        uint32_t *my_path_base = P.path;
-        auto emit = [&](const U32 &code, const Bool &act) {
-            acc = W::sel(act, acc | W::shlv(code, (steps & 15u) << 1), acc);
-            const Bool full = act & ((steps & 15u) == 15u);
-            W::store_u32(my_path_base, pair * P.path_words + (steps >> 4), acc, full);
-            acc = W::sel(full, W::splat(0), acc);
-            steps = W::sel(act, steps + 1u, steps);
-        };
-        // r diagonal steps at once (code 0 = no bits): only the step counter moves, over a word boundary the finished word is stored
-        auto emit_zeros = [&](const U32 &r, const Bool &act) {
-            const Bool cross = act & (((steps & 15u) + r) >= 16u);
-            W::store_u32(my_path_base, pair * P.path_words + (steps >> 4), acc, cross);
-            acc = W::sel(cross, W::splat(0), acc);
-            steps = W::sel(act, steps + r, steps);
+        // the script's runs, last run first: r steps of edit e extend the open run or close it (one word to the pair's run list) and open another
+        const U32 e_left = W::sel(swapped, W::splat(3), W::splat(2)), e_up = W::sel(swapped, W::splat(2), W::splat(3));   // AGap = 2, BGap = 3 (:561-606, relabelled under the swap)
+        U32 cur = W::splat(7), cnt = W::splat(0), nruns = W::splat(0);
+        auto note = [&](const U32 &e, const U32 &r, const Bool &on) {
+            const Bool same = on & (e == cur);
+            const Bool close = on & !same & (cur != 7u);
+            W::store_u32(P.runs, pair * P.runs_cap + nruns, (cur << 29) | cnt, close & (nruns < P.runs_cap));
+            nruns = W::sel(close, nruns + 1u, nruns);
+            cnt = W::sel(same, cnt + r, W::sel(on, r, cnt));
+            cur = W::sel(on, e, cur);
         };
         U32 nxt_vp = st.VP[0], nxt_vn = st.VN[0];                          // the pre-state of the column behind the last tile
         for (uint32_t t = tiles; t-- > 0u;) {
             const uint32_t tb = T0 + (uint32_t)TILE * t, j_lo = (uint32_t)TILE * t;      // the tile's columns: j_lo + 1 .. j_lo + TILE
-            load_tile(t);
+            load_strings(t / RT);
             load_ckpt(t);
             rebuild_window(tb);
             W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
@@ -209,14 +213,14 @@ struct LevBitsTrace {
                 // never above a_gap or b_gap -- adjacent cells differ by at most one -- and a transposition of four equal characters
                 // costs one more), so a run of equal characters is a run of code 0: up to eight steps per iteration, no records read
                 {
-                    const U32 xo = W::sel(act, (i - 1u) - a_lo, W::splat(8)), yo = W::sel(act, (j - 1u) - (j_lo - 16u), W::splat(8));
+                    const U32 xo = W::sel(act, (i - 1u) - a_lo, W::splat(8)), yo = W::sel(act, (j - 1u) - b_lo, W::splat(8));
                     const U32 xh = W::lds_read32u(lds, slot + (xo - 3u)), yh = W::lds_read32u(lds, slot + 16u * PA + (yo - 3u));
                     const U32 xl = W::lds_read32u(lds, slot + (xo - 7u)), yl = W::lds_read32u(lds, slot + 16u * PA + (yo - 7u));
                     const U32 dh = xh ^ yh, dl = xl ^ yl;
                     U32 r = W::sel(dh == 0u, W::splat(4) + (W::clz(dl) >> 3), W::clz(dh) >> 3);      // equal bytes from x[i-1] / y[j-1] downwards
                     r = W::umin(r, W::umin(i, j - j_lo));
                     const Bool fast = act & (r > 0u);
-                    emit_zeros(r, fast);
+                    note(W::splat(0), r, fast);                                // r Matches
                     i = W::sel(fast, i - r, i); j = W::sel(fast, j - r, j);
                     act = act & (j > j_lo) & (i > 0u);
                     if (!W::any(act)) break;
@@ -242,7 +246,7 @@ struct LevBitsTrace {
                 const U32 up = W::sel(up_ok, W::splat(BIAS) - v_ij, W::splat(INF));
                 const U32 left = W::sel(left_ok, diag + v_l, W::splat(INF));
                 // the characters: x[i - 1], x[i - 2] (a-index - a_lo), y[j - 1], y[j - 2]
-                const U32 xa = slot + W::sel(act, (i - 1u) - a_lo, W::splat(4)), ya = slot + 16u * PA + W::sel(act, (j - 1u) - (j_lo - 16u), W::splat(4));
+                const U32 xa = slot + W::sel(act, (i - 1u) - a_lo, W::splat(4)), ya = slot + 16u * PA + W::sel(act, (j - 1u) - b_lo, W::splat(4));
                 const U32 x1 = W::lds_u8(lds, xa), y1 = W::lds_u8(lds, ya);
                 const U32 sub = diag + W::sel(x1 == y1, W::splat(0), W::splat(1)), ag = left + 1u, bg = up + 1u;
                 const U32 m1 = W::umin(sub, ag);
@@ -260,21 +264,17 @@ struct LevBitsTrace {
                     const U32 nv = W::umin(bg, m1);
                     code = W::sel(tt & (tval <= nv), W::splat(3), code);
                 }
-                emit(code, act);
+                note(W::sel(code == 0u, W::sel(x1 == y1, W::splat(0), W::splat(1)), W::sel(code == 1u, e_left, W::sel(code == 2u, e_up, W::splat(4)))), W::splat(1), act);
                 i = W::sel(act & (code != 1u), i - W::sel(code == 3u, W::splat(2), W::splat(1)), i);
                 j = W::sel(act & (code != 2u), j - W::sel(code == 3u, W::splat(2), W::splat(1)), j);
                 act = act & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u) & (i <= n);
             }
         }
-        // the borders: row 0 (j steps left) and column 0 (i steps up)
-        {
-            Bool act = some & (i == 0u) & (j > 0u) & (j <= m);
-            while (W::any(act)) { emit(W::splat(1), act); j = W::sel(act, j - 1u, j); act = act & (j > 0u); }
-            act = some & (j == 0u) & (i > 0u) & (i <= n);
-            while (W::any(act)) { emit(W::splat(2), act); i = W::sel(act, i - 1u, i); act = act & (i > 0u); }
-        }
-        W::store_u32(my_path_base, pair * P.path_words + (steps >> 4), acc, some & ((steps & 15u) != 0u));
-        W::store_u32(P.steps, pair, W::sel(some, steps, W::splat(0)), in_batch);
+        // the borders: row 0 (j steps left) and column 0 (i steps up), each one run
+        note(e_left, j, some & (i == 0u) & (j > 0u) & (j <= m));
+        note(e_up, i, some & (j == 0u) & (i > 0u) & (i <= n));
+        note(W::splat(7), W::splat(0), some & (cur != 7u));                // close the last run
+        W::store_u32(P.n_runs, pair, W::sel(some, nruns, W::splat(0)), in_batch);
     }
 
 };

@@ -116,13 +116,24 @@ static LastUse &last_use() {
 // it returns); a later call of the thread on ANOTHER stream waits for that event first.  Calls that touch no scratch -- the
 // fixed-length batch passes, ta_hamming_batch: the hot paths -- record nothing (an event record per call was a fifth of a small
 // batch call's cost).  The event is recorded while the stream is certainly alive: the caller may destroy it afterwards.
+// A stream that is being CAPTURED into a graph neither waits for the event nor records it: an event recorded inside a capture belongs to
+// the capture (a later wait on it from an ordinary stream is not a wait for the replayed graph's kernels -- it put the kernels of the
+// following calls out of order on gfx950: a memory fault in bench.py --unit-prefilter under its hipGraph), and the graph's own edges
+// order the captured calls.  Whoever replays a captured call next to ordinary calls of the same thread on ANOTHER stream orders them
+// himself (one stream, or an event of his own): the thread-local scratch is shared.
+static bool stream_is_capturing(hipStream_t s) {
+    if (!s) return false;                                 // (the null stream cannot be captured)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 StreamGuard::StreamGuard(hipStream_t s) : st(s) {
     LastUse &u = last_use();
-    if (u.pending && u.st != s && u.ev) (void)hipStreamWaitEvent(s, u.ev, 0);
+    if (u.pending && u.st != s && u.ev && !stream_is_capturing(s)) (void)hipStreamWaitEvent(s, u.ev, 0);
 }
 StreamGuard::~StreamGuard() {
     if (!g_scratch_in_use) return;
     g_scratch_in_use = false;
+    if (stream_is_capturing(st)) return;
     LastUse &u = last_use();
     if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) { u.ev = nullptr; return; }
     if (hipEventRecord(u.ev, st) == hipSuccess) { u.st = st; u.pending = true; }
@@ -499,7 +510,7 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
             Scratch &lst = tls_scratch(4), &cnt = tls_scratch(3);
             if ((rc = lst.ensure(n * 4)) || (rc = cnt.ensure(16))) return rc;
             if ((rc = lev_pass(a, b, (uint32_t)n, order, kf, &uc, max_len, out_dev, st, false))) return rc;
-            TA_HIP(hipMemsetAsync(cnt.dev, 0, 4, st));
+            TA_HIP(fill_u32_launch((uint32_t *)cnt.dev, 0u, 1, st));
             TA_HIP(compact_some_launch(out_dev, order, (uint32_t)n, (uint32_t *)lst.dev, (uint32_t *)cnt.dev, st));
             rc = lev_pass(a, b, (uint32_t)n, (const uint32_t *)lst.dev, k, costs, max_len, out_dev, st, false, (const uint32_t *)cnt.dev);
             g_answer_single_store = false;
@@ -617,7 +628,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     const bool bounded = n >= 64 && max_len >= 64 && !env_int("TA_EXP_NO_BOUND") && !env_int("TA_EXP_FAITHFUL");
     if (bounded) {
         if ((rc = bnd.ensure(n * 4)) || (rc = wrk.ensure(n * 4))) return rc;
-        TA_HIP(hipMemsetAsync(out_dev, 0xFF, n * 4, st));
+        TA_HIP(fill_u32_launch(out_dev, 0xFFFFFFFFu, (uint32_t)n, st));
         TA_HIP(bag_bound_launch(view_of(a), view_of(b), (uint32_t)n, costs->mismatch_cost, costs->gap_cost, (uint32_t *)bnd.dev, st));
     }
     g_exp_passes = 0;
@@ -647,7 +658,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     if (n >= 1024 && !faithful && !env_int("TA_EXP_HOST_ROUNDS")) {
         constexpr int MAX_ROUNDS = 40;
         if ((rc = cnt.ensure(2 * MAX_ROUNDS * 4))) return rc;
-        TA_HIP(hipMemsetAsync(cnt.dev, 0, 2 * MAX_ROUNDS * 4, st));
+        TA_HIP(fill_u32_launch((uint32_t *)cnt.dev, 0u, 2 * MAX_ROUNDS, st));
         uint32_t *counters = (uint32_t *)cnt.dev;
         const uint32_t *n_in_dev = nullptr;                 // the length of sub_in (nullptr: n, exactly)
         for (int round = 0; round < MAX_ROUNDS; round++) {
@@ -1143,13 +1154,14 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
         if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len <= 0x7FFFFFF0ull && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
             if ((rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
             const uint32_t tile = lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
-            const uint32_t path_words = (uint32_t)((2 * max_len) / 16 + 2);
+            // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
+            const uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
             Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
-            if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (rc = ps.ensure((size_t)n * path_words * 4u)) ||
+            if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (rc = ps.ensure((size_t)n * runs_cap * 4u)) ||
                 (rc = ss.ensure((size_t)n * 4u))) return rc;
             LevBitsTraceParams T;
             T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
-            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.path = (uint32_t *)ps.dev; T.path_words = path_words; T.steps = (uint32_t *)ss.dev;
+            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = runs_cap; T.n_runs = (uint32_t *)ss.dev;
             ta_launch_info li = g_last_launch;                 // (the distance pass's: kernel 3)
             uint32_t grid = 0, lds = 0;
             TA_HIP(lev_bits_trace_launch(T, trans, edits_dev, n_edits_dev, cap, st, &grid, &lds));

@@ -107,6 +107,7 @@ uint32_t lev_bits_trace_ckpt_words(bool trans);
 uint32_t lev_bits_trace_tile();
 hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
                                  uint32_t *grid_out, uint32_t *lds_out);
+hipError_t fill_u32_launch(uint32_t *p, uint32_t v, uint32_t n, hipStream_t st);   // p[0..n) = v, as a kernel (graph-safe)
 hipError_t compact_some_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 hipError_t scale_results_launch(uint32_t *out, const uint32_t *list /*pairs, or nullptr: 0..n*/, uint32_t n, const uint32_t *n_dev, uint32_t g, hipStream_t st);
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,

@@ -100,6 +100,18 @@ __global__ void compact_none_kernel(const uint32_t *out, const uint32_t *subset_
     const uint32_t pair = in ? (subset_in ? subset_in[i] : i) : 0u;
     compact_append(in && out[pair] == 0xFFFFFFFFu, pair, subset_out, count);
 }
+// n words set to v, as a kernel: calls that may be captured into a graph use it instead of hipMemsetAsync -- a 4-byte memset NODE of a
+// captured call was not ordered with the kernel nodes around it on gfx950 / ROCm 7.2 (the unit-cost pre-pass under bench.py's graph:
+// a stale counter, a memory fault; fine with AMD_SERIALIZE_KERNEL=3 and with this kernel)
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t fill_u32_launch(uint32_t *p, uint32_t v, uint32_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, p, v, n);
+    return hipGetLastError();
+}
 // the complement: the pairs a pass ANSWERED (the unit-cost pre-pass of weighted batches, TA_OPT_UNIT_PREFILTER: its survivors)
 __global__ void compact_some_kernel(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
