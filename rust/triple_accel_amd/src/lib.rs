@@ -64,6 +64,7 @@ mod ffi {
         pub fn ta_hamming_batch(a: *const TaStrings, b: *const TaStrings, n: usize, out_dev: *mut u32, stream: *mut c_void) -> c_int;
         pub fn ta_levenshtein_trace_batch(a: *const TaStrings, b: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
                                           out_dev: *mut u32, edits_dev: *mut TaEdit, n_edits_dev: *mut u32, cap: usize, stream: *mut c_void) -> c_int;
+        pub fn ta_set_option(option: c_int, value: c_int) -> c_int;
         pub fn ta_thread_release();
         pub fn ta_device_count() -> c_int;
         pub fn ta_queue_create(k: u32, costs: *const TaEditCosts, out: *mut *mut c_void) -> c_int;
@@ -383,6 +384,14 @@ pub mod device {
     use super::levenshtein::EditCosts;
     use super::*;
     pub use super::ffi::{TaEdit, TaStrings};
+    use std::os::raw::{c_int, c_void};
+
+    /// Options of the calling thread (include/triple_accel_amd.h; off by default, never a change of an answer -- only of how much work a
+    /// batch costs): `OPT_EARLY_OUT` -- wavefronts of fixed-length unit-cost batches stop once none of their pairs can end at or below k;
+    /// `OPT_UNIT_PREFILTER` -- batches under weighted `EditCosts` run the unit-cost pass first and price only the pairs it could not rule out.
+    pub const OPT_EARLY_OUT: c_int = 1;
+    pub const OPT_UNIT_PREFILTER: c_int = 2;
+    pub fn set_option(option: c_int, on: bool) { unsafe { check(ta_set_option(option, on as c_int)); } }
 
     /// N x `levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs)`
     pub unsafe fn levenshtein_k_batch(a: &TaStrings, b: &TaStrings, n: usize, k: u32, costs: EditCosts, out_dev: *mut u32, stream: *mut c_void) {

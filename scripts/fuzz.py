@@ -33,12 +33,21 @@ def rand_pairs(n, lo, hi, alpha, sim, edits):
 t_end, rounds, kinds = time.time() + 60 * minutes, 0, {}
 while time.time() < t_end:
     rounds += 1
-    kind = int(g.integers(0, 11))
+    kind = int(g.integers(0, 13))
     os.environ.pop("TA_BITS_VLINE", None)
     if g.random() < 0.3:
         os.environ["TA_BITS_VLINE"] = "1"                # round 4: CSR batches through the VLINE fetch form
     early = bool(g.random() < 0.3)                 # the early-out option must never change an answer
     T.set_option(T.OPT_EARLY_OUT, early)
+    T.set_option(T.OPT_UNIT_PREFILTER, bool(g.random() < 0.4))      # round 5: nor must the unit-cost pre-pass of weighted batches
+    for sw in ("TA_EXP_HOST_ROUNDS", "TA_TRACE_TILE", "TA_TRACE_STILE", "TA_HAMMING_PHASE_Q", "TA_TRACE_NO_BITS"):
+        os.environ.pop(sw, None)
+    if g.random() < 0.2:
+        os.environ["TA_EXP_HOST_ROUNDS"] = "1"           # the host-driven levenshtein_exp rounds (big batches are device-driven by default)
+    if g.random() < 0.5:
+        os.environ["TA_TRACE_TILE"] = str(g.choice([8, 16, 32])); os.environ["TA_TRACE_STILE"] = str(g.choice([32, 64]))
+    if g.random() < 0.3:
+        os.environ["TA_HAMMING_PHASE_Q"] = str(g.choice([1, 2]))
     alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
     costs = COSTS[int(g.integers(0, len(COSTS)))]
     if not O.costs_valid(costs):
@@ -58,8 +67,8 @@ while time.time() < t_end:
             want = O.levenshtein_k_batch(O.csr_from_list(a), O.csr_from_list(b), k, costs)
             ok = np.array_equal(got, want)
             what = ("k_batch", n, lo, hi, k, costs, alpha, T.last_launch_info()["kernel"])
-        elif kind == 2:         # exp batch
-            n = int(g.choice([1, 30, 64, 300]))
+        elif kind in (2, 11):   # exp batch (11, round 5: batches of >= 1024 pairs -- the device-driven rounds)
+            n = int(g.choice([1, 30, 64, 300])) if kind == 2 else int(g.choice([1024, 1500, 5000]))
             hi = int(g.choice([20, 100, 400, 1200]))
             a, b = rand_pairs(n, int(g.integers(0, hi + 1)), hi, alpha, 0.6, int(g.choice([3, 30, 200])))
             got = B.levenshtein_exp_batch(B.Strings.from_list(a), B.Strings.from_list(b), costs).cpu().numpy().view(np.uint32)
@@ -122,11 +131,14 @@ while time.time() < t_end:
                 want = O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), k, costs)
             ok = np.array_equal(got, want)
             what = ("big_batch", n, L, Lb, k, costs, small, early, T.last_launch_info()["kernel"], T.last_kernel_name())
-        elif kind == 9:         # round 4: batch tracebacks on the device
+        elif kind in (9, 12):   # round 4: batch tracebacks on the device; 12, round 5: the unit-cost families on the checkpoint-and-recompute kernel
             n = int(g.choice([1, 40, 700, 3000]))
             hi = int(g.choice([12, 60, 200, 500]))
+            if kind == 12:
+                costs = [(1, 1, 0, None), (1, 1, 0, 1)][int(g.integers(0, 2))]
+                hi = int(g.choice([12, 60, 200, 500, 1400]))
             a, b = rand_pairs(n, int(g.integers(0, hi + 1)), hi, alpha, 0.8, int(g.choice([2, 10, 30])))
-            k = int(g.choice([0, 3, 10, 32, 64, 200]))
+            k = int(g.choice([0, 3, 10, 32, 64, 200])) if kind == 9 else int(g.choice([0, 1, 3, 10, 20, 30, 32]))
             out, ed, ne = B.levenshtein_trace_batch(B.Strings.from_list(a), B.Strings.from_list(b), k, costs)
             gd = out.cpu().numpy().view(np.uint32); ge = B.edits_to_lists(ed, ne)
             ok = True
@@ -139,15 +151,17 @@ while time.time() < t_end:
                 if not ok:
                     print("pair", i, a[i], b[i], gd[i], ge[i], wd, we)
                     break
-            what = ("trace_batch", n, hi, k, costs, alpha)
+            what = ("trace_batch", n, hi, k, costs, alpha, T.last_kernel_name())
         elif kind == 10:        # round 4: hamming_search kernels by (needle length, k): SWAR16, bit-sliced, the long-needle form
-            n = int(g.choice([1, 3, 4, 8, 9, 12, 16, 17, 24, 31, 32, 33, 48, 64, 65]))
-            needle = g.integers(1, 256, n, dtype=np.uint8).tobytes()
-            hay = bytearray(g.integers(1, 256, int(g.choice([n, 700, 40000, 600000])), dtype=np.uint8).tobytes())
+            n = int(g.choice([1, 3, 4, 8, 9, 12, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 100, 300]))
+            lo_c = 97 if g.random() < 0.3 else 1                # (a four-letter text now and then: the subset filters pass many candidates)
+            hi_c = 101 if lo_c == 97 else 256
+            needle = g.integers(lo_c, hi_c, n, dtype=np.uint8).tobytes()
+            hay = bytearray(g.integers(lo_c, hi_c, int(g.choice([n, 700, 40000, 600000])), dtype=np.uint8).tobytes())
             for pos in range(0, max(1, len(hay) - n), max(n + 3, 3000)):
                 m = bytearray(needle)
                 for _ in range(int(g.integers(0, 9))):
-                    m[int(g.integers(0, n))] = int(g.integers(1, 256))
+                    m[int(g.integers(0, n))] = int(g.integers(lo_c, hi_c))
                 hay[pos:pos + n] = m
             hay = bytes(hay[: max(len(hay), n)])
             k = int(g.choice([0, 1, 2, 3, 4, 7, 8, 15, 16, 31, 32, n]))

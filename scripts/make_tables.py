@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 D = os.path.join(ROOT, "profiles", RND)
 
 
@@ -51,8 +51,10 @@ def main():
             "`SQ_INSTS_VALU` of the dominant kernel.", ""]
     out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
             "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
-    for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg3", "cfg5", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "cfg2_ragged", "cfg2_ragged_vline", "cfg2_dna",
-               "cfg2_dna5", "cfg2_protein_table", "hsearch8", "hsearch32", "hsearch64", "cfg2_early_out", "cfg2_2m"):
+    for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg4_mutated", "cfg3", "cfg3_mutated", "cfg3_mutated_host_rounds", "cfg5", "cfg5w_220", "cfg5w_231", "cfg5w_2213", "cfg5w_1101",
+               "cfg5w_231_nofilter", "cfg1", "cfg2w", "cfg2w_prefilter", "cfg2w_mutated", "cfg2w_mutated_prefilter", "cfg4w", "cfg4w_prefilter", "cfg2l", "cfg2s", "cfg2t", "cfg2t_dp",
+               "cfg2_ragged", "cfg2_ragged_vline", "cfg2_dna",
+               "cfg2_dna5", "cfg2_protein_table", "hsearch8", "hsearch16", "hsearch32", "hsearch32_r04", "hsearch64", "hsearch64_r04", "cfg2_early_out", "cfg2_2m"):
         b = J("bench_%s.json" % wl)
         if not b:
             continue
@@ -78,7 +80,12 @@ def main():
             "data-dependent work, NOT a headline figure; cfg2_2m: 2M pairs per pass; cfg2l / cfg2s: cfg2's geometry under EditCosts(2,3,0,None) -- DP band kernel, linear "
             "gaps -- and (2,2,0,None) = unit costs x 2 on the bit-parallel kernel; cfg2t: every pair traced, ta_levenshtein_trace_batch (bytes: strings + records are "
             "NOT counted, only strings, distances and the scripts written); cfg2_ragged_vline: the ragged batch through the VLINE fetch form, an A/B row; cfg2_dna5: strings over A C G T N -- the 5-bit-code small-alphabet kernel, the default there; cfg2_protein_table: the 20 amino acids FORCED through that kernel (TA_BITSQ_WIDE=1), an A/B row -- the default runs the byte test at cfg2's rate, ab_alphabet.md; "
-            "hsearchN: hamming_search of an N-byte needle over 1 GiB, k = N / 4, cells = N byte compares per offset.)", ""]
+            "hsearchN: hamming_search of an N-byte needle over 1 GiB, k = N / 4, cells = N byte compares per offset.  Round 5: cfg3_mutated / cfg4_mutated: similar strings "
+            "(cfg3_mutated: the levenshtein_exp rounds, device-driven; cfg3_mutated_host_rounds: TA_EXP_HOST_ROUNDS=1, an A/B row); cfg5w_<costs>: levenshtein_search of cfg5's "
+            "geometry under EditCosts(2,2,0,None) / (2,3,1,None) / (2,2,1,Some(3)) / RDAMERAU_COSTS through the superset filter, cfg5w_231_nofilter: round 4's route "
+            "(TA_SEARCH_NOWFILTER=1, an A/B row); cfgNw_prefilter / cfg2w_mutated_prefilter: ta_set_option(TA_OPT_UNIT_PREFILTER) -- same answers, data-dependent work, NOT a "
+            "headline figure; cfg2t: the checkpoint-and-recompute kernel (cfg2t_dp: the DP kernel's records, TA_TRACE_NO_BITS=1, an A/B row); hsearchN_r04: round 4's routing "
+            "(TA_HAMMING_SEARCH_NO_PHASE=1, A/B rows).)", ""]
     e2e = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg5", "cfg1", "cfg2_ragged")]
     out += ["## Host buffers in, answers out (`end_to_end_ms`: pinned H2D of the batch + the pass + D2H; never the headline)", "",
             "| config | ms per pass, inputs resident | ms end to end | untimed ramp passes before the timed region |", "|---|---|---|---|"]
@@ -101,7 +108,12 @@ def main():
                        ("cfg2_ragged", "lev_bits_"), ("cfg2_ragged", "len_hist"), ("cfg2_ragged", "len_scan"), ("cfg2_ragged", "len_scatter"),
                        ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8"), ("cfg2_dna5", "lev_bitsqw_kernel"), ("cfg2_protein_table", "lev_bitsqw_kernel"), ("cfg2_ragged_vline", "lev_bits_s8v"), ("cfg2_ragged_vline", "len_scatter"),
                        ("cfg2l", "lev_band_score"), ("cfg2s", "lev_bits_line"), ("cfg2s", "scale_results"), ("cfg2t", "lev_band_trace_kernel"), ("cfg2t", "lev_trace_walk"),
-                       ("hsearch8", "hamming_search"), ("hsearch32", "hamming_search"), ("hsearch64", "hamming_search")):
+                       ("cfg2t", "lev_bits_trace_kernel"), ("cfg2t", "lev_bits_s8_kernel"), ("cfg3_mutated", "lev_bits_"), ("cfg3_mutated", "lev_widebits_kernel"), ("cfg3_mutated", "compact_"),
+                       ("cfg3_mutated", "bag_bound"), ("cfg4_mutated", "lev_bits2"), ("cfg5w_231", "lev_filter_kernel"), ("cfg5w_231", "lev_search_wave_kernel"),
+                       ("cfg5w_2213", "lev_filter_kernel"), ("cfg5w_2213", "lev_search_wave_kernel"),
+                       ("cfg2w_prefilter", "lev_bits_"), ("cfg2w_prefilter", "compact_some"), ("cfg2w_prefilter", "lev_band_score"),
+                       ("cfg2w_mutated_prefilter", "lev_bits_"), ("cfg2w_mutated_prefilter", "lev_band_score"),
+                       ("hsearch8", "hamming_search"), ("hsearch16", "hamming_search"), ("hsearch32", "hamming_search"), ("hsearch64", "hamming_search")):
         k = kernel_us(wl, needle)
         if k:
             out.append("| %s | `%s` | %d | %.1f |" % (wl, needle, k[1], k[0]))
