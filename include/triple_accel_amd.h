@@ -233,14 +233,19 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
 int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                     const uint8_t *alphabet, size_t alphabet_len, uint32_t *out_dev, void *stream);
 /* N x levenshtein_exp_with_opts(a_i, b_i, false, costs): doubling k from 30 over the still-unresolved
- * subset (src/levenshtein.rs:1480-1494).  Synchronises the stream between rounds. */
+ * subset (src/levenshtein.rs:1480-1494).  Batches of >= 1024 pairs: the whole k schedule is enqueued at once -- every list's length stays on
+ * the device -- and the call returns without synchronising (capturable in a graph; a CSR side with max_len = 0 costs one synchronisation to
+ * measure it).  Smaller batches synchronise the stream between rounds. */
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
                              const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
 /* Batch form of ta_levenshtein_trace (no reference analogue: the reference's trace_on is per call, src/levenshtein.rs:714-720, :561-606):
  * out_dev[i] = distance | TA_NONE, n_edits_dev[i] = runs of pair i's script (0 for None), edits_dev[i * cap .. i * cap + n_edits_dev[i]) =
  * the script front to back -- edit for edit the reference's Vec<Edit>.  All buffers are device memory; the call enqueues kernels on
  * `stream` and returns (no synchronisation).  2 k + 1 records per pair always suffice; a longer script is cut at `cap` records and
- * n_edits_dev[i] says how many it has.  TA_ERR_UNSUPPORTED for bands beyond the register kernel (> 4222 diagonals). */
+ * n_edits_dev[i] says how many it has.  LEVENSHTEIN_COSTS / RDAMERAU_COSTS with k <= 32 (30): no per-cell records -- the distance pass leaves a
+ * checkpoint of its column state every 16th column, one more kernel recomputes tile after tile backwards and walks; any
+ * other costs / wider bands: 2-bit argmin codes of the DP band kernel + a walk kernel (3.4b).  TA_ERR_UNSUPPORTED for bands beyond the
+ * register kernel (> 4222 diagonals). */
 int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, void *stream);
 
@@ -276,6 +281,12 @@ int ta_levenshtein_search_dev(const uint8_t *needle_host, size_t needle_len,
 int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
                           const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
                           uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
+/* ta_hamming_search_dev with the hits on the host, sorted by end, library-allocated (ta_free): the hits of an ordinary search (up to 680)
+ * arrive through host-mapped pinned memory with the call's one stream synchronisation; more are copied from hits_dev (which must hold
+ * `cap` records either way).  Synchronises the stream.  (src/hamming.rs:454-554: the All-mode result of hamming_search_simd_with_opts.) */
+int ta_hamming_search_dev_sorted(const uint8_t *needle_host, size_t needle_len,
+                                 const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                                 uint64_t base, ta_match *hits_dev, size_t cap, ta_match **out, size_t *n_out, void *stream);
 
 /* The Best-mode pass over one shard in a single call (what `levenshtein_search` with SearchType::Best needs from a shard,
  * src/levenshtein.rs:1792-1835): ta_levenshtein_search_dev (unanchored) + ta_search_best_hits_dev fused.  The All-mode hits stay

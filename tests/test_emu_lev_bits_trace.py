@@ -72,6 +72,13 @@ def test_trace_fixed_length_and_long(trans):
     b[9] = bytes(g.integers(1, 255, size=256).astype(np.uint8))
     assert _check(a, b, 30 if trans else 32, trans, 16, fixed=True) > 90
     assert _check(a, b, 30 if trans else 32, trans, 32, fixed=True) > 90
+    # tile 116: the forward sweep done by the distance kernel's CKPT instantiation (the launcher's route for fixed-length batches), line form
+    assert _check(a, b, 30 if trans else 32, trans, 116, fixed=True) > 90
+    for la, lb, k in ((100, 96, 9), (96, 100, 9), (128, 128, 20), (40, 47, 3), (300, 290, 30), (17, 17, 32 if not trans else 30), (16, 32, 16), (1, 1, 2)):
+        am2, bm2 = Dg.pairs_mutated_fixed(0x7C5 + la + lb, 70, max(la, lb), max(1, k // 2), swaps=trans)
+        a3 = [bytes(r[:la]) for r in am2]; b3 = [bytes(r[:lb]) for r in bm2]
+        b3[3] = bytes(g.integers(1, 255, size=lb).astype(np.uint8))
+        _check(a3, b3, k, trans, 116, fixed=True)
     assert _check(a, b, 30 if trans else 32, trans, 8, fixed=True) > 90
     a2 = [b"", b"abc", b"", b"kitten", b"ab", b"ba", b"abcdefgh" * 40, b"x" * 300]
     b2 = [b"", b"", b"xyz", b"sitting", b"ba", b"ab", (b"abcdefgh" * 40)[3:] + b"zz", b"x" * 290 + b"y" * 5]

@@ -207,10 +207,17 @@ def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
     assert n_some > 300
     # fixed-length, a longer than b and b longer than a
     am, bm = Dg.pairs_mutated_fixed(0xCB8 + k, 3000, 200, max(2, k // 2), swaps=trans)
-    for xa, xb in ((am, np.ascontiguousarray(bm[:, :197])), (np.ascontiguousarray(am[:, :195]), bm)):
+    # (fixed-length batches: the distance pass is the forward sweep -- the stride-8 kernel's CKPT instantiation leaves the checkpoints,
+    # the trace kernel's HAVE_CKPT instantiation starts with the walk; TA_TRACE_OWN_SWEEP=1: the trace kernel's own sweep, an A/B)
+    for xa, xb in ((am, np.ascontiguousarray(bm[:, :197])), (np.ascontiguousarray(am[:, :195]), bm), (np.ascontiguousarray(am[:, :96]), np.ascontiguousarray(bm[:, :100]))):
         o2, e2, n2 = B.levenshtein_trace_batch(B.Strings.from_fixed(xa), B.Strings.from_fixed(xb), k, costs)
-        assert "lev_bits_trace_kernel" in T.last_kernel_name()
+        assert "lev_bits_trace_kernel" in T.last_kernel_name() and T.last_kernel_name().endswith("true>"), T.last_kernel_name()
         d2, l2 = o2.cpu().numpy().view(np.uint32), B.edits_to_lists(e2, n2)
+        monkeypatch.setenv("TA_TRACE_OWN_SWEEP", "1")
+        o3, e3, n3 = B.levenshtein_trace_batch(B.Strings.from_fixed(xa), B.Strings.from_fixed(xb), k, costs)
+        assert not T.last_kernel_name().endswith("true>")
+        monkeypatch.delenv("TA_TRACE_OWN_SWEEP")
+        assert np.array_equal(d2, o3.cpu().numpy().view(np.uint32)) and l2 == B.edits_to_lists(e3, n3)
         for i in range(0, 3000, 41):
             wd, we = O.levenshtein_simd_k_with_opts(xa[i].tobytes(), xb[i].tobytes(), k, True, costs)
             assert (d2[i] == wd and l2[i] == we) if wd is not None else (d2[i] == 0xFFFFFFFF and l2[i] == []), i

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
     "ta_hamming_search", "ta_hamming_search_naive_with_opts", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
-    "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch",
+    "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
                                            C.c_void_p, sz, C.POINTER(C.c_uint64), C.c_void_p])
     sig("ta_hamming_search_dev", i32, [u8p, sz, C.c_void_p, sz, u32, C.c_uint64, C.c_void_p, sz,
                                        C.POINTER(C.c_uint64), C.c_void_p])
+    sig("ta_hamming_search_dev_sorted", i32, [u8p, sz, C.c_void_p, sz, u32, C.c_uint64, C.c_void_p, sz, mpp, szp, C.c_void_p])
     sig("ta_search_fold_best", sz, [C.POINTER(MatchC), sz, u32, i32])
     sig("ta_levenshtein_search_best_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, C.c_uint64, C.c_uint64,
                                                 C.c_void_p, sz, C.POINTER(C.c_uint64), mpp, szp, C.c_void_p])

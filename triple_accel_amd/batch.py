@@ -241,11 +241,21 @@ def hamming_search_dev(needle, haystack, k, base=0, cap=None):
     needle = bytes(needle)
     cap = cap or min(length + 2, 1 << 22)
     hits = _hit_buffer(hay.device, cap)
-    count = _C.c_uint64()
-    rc = _n.lib().ta_hamming_search_dev(needle, len(needle), hay.data_ptr(), length, k, base, hits.data_ptr(), cap,
-                                        _C.byref(count), _stream())
+    # the hits on the host, sorted by end: the few hits of an ordinary search arrive through pinned memory with the call's one
+    # stream synchronisation (ta_hamming_search_dev_sorted; the count + a device-side sort + a copy cost 0.11 ms per call)
+    import numpy as np
+    out = _C.POINTER(_n.MatchC)()
+    n_out = _C.c_size_t()
+    rc = _n.lib().ta_hamming_search_dev_sorted(needle, len(needle), hay.data_ptr(), length, k, base, hits.data_ptr(), cap,
+                                               _C.byref(out), _C.byref(n_out), _stream())
     _raise(rc)
-    return _hits_to_numpy(hits, int(count.value))
+    n = n_out.value
+    if n == 0:
+        return np.empty((0, 3), dtype=np.int64)
+    raw = np.ctypeslib.as_array(_C.cast(out, _C.POINTER(_C.c_uint64)), shape=(n, 3)).astype(np.int64)     # (start, end, k | pad << 32)
+    _n.lib().ta_free(out)
+    raw[:, 2] &= 0xFFFFFFFF
+    return raw
 
 
 def haystack_tensor(data, device="cuda"):

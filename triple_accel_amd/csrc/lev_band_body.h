@@ -68,6 +68,8 @@ struct LevParams {
     uint32_t *q_bad_count = nullptr, *q_bad_list = nullptr;   // lev_bitsq: the pairs that hold a byte outside the alphabet
     uint32_t *q_next_count = nullptr;        // lev_bitsq: the NEXT pass's counter, zeroed by this pass (two counters taken in turn)
     const uint32_t *n_dev = nullptr;         // bit-parallel band kernels: the number of pairs, read on the device (a list a kernel before wrote)
+    uint32_t *ckpt = nullptr;                // stride-8 bit-parallel band kernel, CKPT instantiation: the column state every 16th column, [wave][tile][word][lane]
+    uint32_t ckpt_tiles = 0;                 //   (what lev_bits_trace_body.h walks backwards from; tiles per wavefront the scratch holds)
     uint32_t *bnd = nullptr;  // lev_widebits: per wave 6 boundary lines of bnd_line u32 (strings spanning several stripes)
     uint64_t bnd_line = 0;
     uint64_t trace_cols = 0;  // lev_widebits TRACE: columns per stripe in P.trace (>= b_len + 64)

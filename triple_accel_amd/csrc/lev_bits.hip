@@ -47,6 +47,15 @@ __global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_kernel(
         LevBits<DevWave, 8, TRANS, false, LINE, true, EARLY>::run(Q, w, lds + wave * P.lds_per_wave);
 }
 
+// stride-8 form with checkpoints (lev_bits_body.h, CKPT): the distance pass of ta_levenshtein_trace_batch over a fixed-length batch
+template <bool TRANS, bool LINE>
+__global__ __launch_bounds__(64 * BITS_WAVES_PER_BLOCK) void lev_bits_s8_ckpt_kernel(LevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, waves = (P.n + 63u) >> 6;
+    for (uint32_t w = blockIdx.x * wpb + wave; w < waves; w += gridDim.x * wpb)
+        LevBits<DevWave, 8, TRANS, false, LINE, true, false, false, true>::run(P, w, lds + wave * P.lds_per_wave);
+}
+
 #ifdef TA_BITS2_WAVES_PER_SIMD        // A/B builds only: cap the registers for this many wavefronts per SIMD
 #define TA_BITS2_ATTR __attribute__((amdgpu_waves_per_eu(TA_BITS2_WAVES_PER_SIMD, TA_BITS2_WAVES_PER_SIMD)))
 #else
@@ -156,9 +165,16 @@ hipError_t lev_bits_launch(const LevParams &P0, const LevBitsPlan &pl, bool tran
     if (grid_out) *grid_out = grid;
     if (lds_out) *lds_out = (uint32_t)lds;
     if (grid == 0) return hipSuccess;
-    const bool early = line_form && pl.s8 && (P.tune & 2u) != 0u;
+    const bool early = line_form && pl.s8 && (P.tune & 2u) != 0u && !P.ckpt;
     if (pl.s8) set_last_kernel_name("lev_bits_s8_kernel<%s, %s, %s>", trans ? "true" : "false", line_form ? "true" : "false", early ? "true" : "false");
     else set_last_kernel_name("%s<%d, %s, %s>", line_form ? "lev_bits_line_kernel" : "lev_bits_kernel", pl.NA, trans ? "true" : "false", pl.stat ? "true" : "false");
+    if (pl.s8 && P.ckpt) {                              // (the caller's promise: fixed-length batch, no subset list, no device-side count)
+        dim3 g(grid), b(64 * wpb);
+        set_last_kernel_name("lev_bits_s8_ckpt_kernel<%s, %s>", trans ? "true" : "false", line_form ? "true" : "false");
+        if (trans) { if (line_form) hipLaunchKernelGGL((lev_bits_s8_ckpt_kernel<true, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_ckpt_kernel<true, false>), g, b, lds, s, P); }
+        else { if (line_form) hipLaunchKernelGGL((lev_bits_s8_ckpt_kernel<false, true>), g, b, lds, s, P); else hipLaunchKernelGGL((lev_bits_s8_ckpt_kernel<false, false>), g, b, lds, s, P); }
+        return hipGetLastError();
+    }
     if (pl.s8) {
         dim3 g(grid), b(64 * wpb);
         if (early) {

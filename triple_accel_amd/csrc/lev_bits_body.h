@@ -44,8 +44,12 @@ namespace ta {
 // 39 VALU instructions per column instead of 48 (static form).
 // VLINE: the line form for batches whose pairs have their OWN geometry and alignment (CSR batches): every 128-byte line of memory that
 // holds bytes of a string is requested once, whole, by the pair's lane -- see run().
-template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false, bool VLINE = false>
+// CKPT (stride-8 form, fixed-length batches, no subset list): the column state (VP, VN; with the transposition term PM', the bottom
+// diagonal's PM', D0') goes to P.ckpt in front of every 16th column and behind the last one -- the forward sweep of the checkpoint-and-
+// recompute traceback (lev_bits_trace_body.h) done by the distance pass itself.
+template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false, bool VLINE = false, bool CKPT = false>
 struct LevBits {
+    static_assert(!CKPT || (S8 && !VLINE && !EARLY), "checkpoints live in the stride-8 form");
     static_assert(!(LINE && VLINE), "one fetch form per instantiation");
     static_assert(NA >= 1 && NA <= 32, "window of 4..128 diagonals");
     static_assert(!S8 || (NA == 8 && !STATIC), "the stride-8 form is its own window layout: 8 registers, 33 diagonals");
@@ -225,17 +229,17 @@ struct LevBits {
             while (W::any(todo)) {
                 const uint32_t cols = W::first_u32(blen, todo);
                 const Bool mine = todo & (blen == cols);
-                run_pass(P, lds, lane, mine, pair, aptr, alen, bptr, blen, cols);
+                run_pass(P, lds, lane, mine, pair, aptr, alen, bptr, blen, cols, wave_index);
                 todo = todo & !mine;
             }
         } else {
-            run_pass(P, lds, lane, in_batch, pair, aptr, alen, bptr, blen, 0u);
+            run_pass(P, lds, lane, in_batch, pair, aptr, alen, bptr, blen, 0u, wave_index);
         }
     }
 
     // `valid`: the lanes whose pair this pass answers; VLINE: all of them have blen == cols
     static TA_HD inline void run_pass(const LevParams &P, uint8_t *lds, const U32 &lane, const Bool &valid, const U32 &pair,
-                                      const Ptr &aptr, const U32 &alen, const Ptr &bptr, const U32 &blen, uint32_t cols) {
+                                      const Ptr &aptr, const U32 &alen, const Ptr &bptr, const U32 &blen, uint32_t cols, uint32_t wave_index = 0) {
         const U32 grp = lane;
         const Bool active = (lane == lane);
 
@@ -299,6 +303,17 @@ struct LevBits {
         const uint32_t iters = T0 + (VLINE ? cols : W::wave_max(blen));
         const U32 t_stop = blen + T0;                          // first iteration past the pair's last column
 
+        // CKPT: the state in front of column 16 t + 1 (iteration T0 + 16 t) and behind the last column, [tile][word][lane]
+        constexpr uint32_t CKW = TRANS ? 5u : 2u;
+        uint32_t *ck = CKPT ? P.ckpt + (uint64_t)wave_index * P.ckpt_tiles * (CKW * 64u) : nullptr;
+        auto save_ck = [&](uint32_t t) {
+            uint32_t *c = ck + (uint64_t)t * (CKW * 64u);
+            W::store_u32(c, lane, st.VP[0], active); W::store_u32(c + 64, lane, st.VN[0], active);
+            if (TRANS) {
+                W::store_u32(c + 128, lane, st.PMp[0], active); W::store_u32(c + 192, lane, st.PMp[NW - 1], active);
+                W::store_u32(c + 256, lane, st.D0p[0], active);
+            }
+        };
         // ---- one span of iterations [tp, p_hi) on LDS-resident characters; addr_a(tp) / addr_b(tp) = LDS byte address of the
         // character(s) iteration tp needs (STATIC: the dword whose bytes are iterations tp..tp+3).
         // A pair whose last column has just run takes its way down from the state as it is now:
@@ -324,6 +339,7 @@ struct LevBits {
                 const bool cap = UNI ? false : W::any(t_stop < p_hi);
                 if (!cap) {
                     for (; tp + 8u <= p_hi; tp += 8u) {    // the hot loop: whole blocks, every pair live
+                        if (CKPT && ((tp - T0) & 15u) == 0u) save_ck((tp - T0) >> 4);
                         if (__builtin_expect(nacc > 24u, 0)) {
                             flush();
                             if (EARLY && UNI && early) {   // tp - T0 columns are done
@@ -344,6 +360,7 @@ struct LevBits {
                     if (!UNI && tp >= p_hi) finished(t_stop == p_hi);
                 }
                 for (; tp < p_hi; tp += 8u) {              // capped blocks, and the last one when the columns end inside it
+                    if (CKPT && ((tp - T0) & 15u) == 0u) save_ck((tp - T0) >> 4);
                     if (nacc > 24u) flush();
                     const U32 pa_c = addr_a(tp), pb_c = addr_b(tp);
                     const U32 r0 = W::lds_read32u(lds, pa_c), r1 = W::lds_read32u(lds, VLINE ? pa_c + 4u : addr_a(tp + 4u));
@@ -653,6 +670,7 @@ struct LevBits {
         }
         }
 
+        if (CKPT) save_ck((W::wave_max(W::sel(valid, blen, W::splat(0))) + 15u) >> 4);     // the state behind the last column (whole tiles: the walk's first look)
         if (nacc) flush();
         const U32 d = (dhi + blen) - cnt + tail;               // the top diagonal starts at d_hi; + columns - zero-difference steps + way down
         const Bool some = inband & (d <= P.k) & (W::splat(dead ? 1u : 0u) == 0u);                 // :539-541, :1166-1168

@@ -12,10 +12,10 @@ namespace ta {
 // first, into the pair's run list); then every lane turns its own list round and writes it as ta_edit records -- the reference's Vec<Edit> in
 // its final order (src/levenshtein.rs:561-606: the reference walks backwards and reverses) -- into the pair's slot of `cap` records (a script
 // of more runs is cut: n_edits says how long it is).
-template <bool TRANS, int TILE, int STILE>
+template <bool TRANS, int TILE, int STILE, bool HAVE_CKPT = false>
 __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P, ta_edit *edits, uint32_t *n_edits, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    LevBitsTrace<DevWave, TRANS, TILE, STILE>::run(P, blockIdx.x, lds);
+    LevBitsTrace<DevWave, TRANS, TILE, STILE, HAVE_CKPT>::run(P, blockIdx.x, lds);
     const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
     if (pair >= P.n) return;
     const uint32_t nr = P.n_runs[pair];                        // (this lane's own stores: program order)
@@ -41,11 +41,21 @@ static uint32_t lev_bits_trace_stile(uint32_t tile) {
     return st < tile ? tile : st;
 }
 
-hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
+// have_ckpt: the distance pass (lev_bits_s8_ckpt_kernel) left the checkpoints of tiles of 16 columns in P.ckpt: no forward sweep here
+hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool have_ckpt, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
                                  uint32_t *grid_out, uint32_t *lds_out) {
-    const uint32_t waves = (P.n + 63u) / 64u, tile = lev_bits_trace_tile(), stile = lev_bits_trace_stile(tile);
+    const uint32_t waves = (P.n + 63u) / 64u, tile = have_ckpt ? 16u : lev_bits_trace_tile(), stile = lev_bits_trace_stile(tile);
     if (grid_out) *grid_out = waves;
     if (waves == 0) return hipSuccess;
+    if (have_ckpt) {
+        set_last_kernel_name("lev_bits_trace_kernel<%s, 16, %u, true>", trans ? "true" : "false", stile);
+#define TA_BTC(T_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, 16, SL_, true>::LDS_PER_WAVE; if (lds_out) *lds_out = lds; \
+        hipLaunchKernelGGL((lev_bits_trace_kernel<T_, 16, SL_, true>), dim3(waves), dim3(64), lds, s, P, edits, n_edits, cap); } while (0)
+        if (stile == 64u) { if (trans) TA_BTC(true, 64); else TA_BTC(false, 64); }
+        else { if (trans) TA_BTC(true, 32); else TA_BTC(false, 32); }
+#undef TA_BTC
+        return hipGetLastError();
+    }
     set_last_kernel_name("lev_bits_trace_kernel<%s, %u, %u>", trans ? "true" : "false", tile, stile);
 #define TA_BT(T_, TL_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, TL_, SL_>::LDS_PER_WAVE; if (lds_out) *lds_out = lds; \
         hipLaunchKernelGGL((lev_bits_trace_kernel<T_, TL_, SL_>), dim3(waves), dim3(64), lds, s, P, edits, n_edits, cap); } while (0)

@@ -29,8 +29,11 @@ namespace ta {
 // TILE: columns per checkpoint / per set of records in LDS; STILE: columns whose characters one fill of the string slots covers (a multiple
 // of TILE: every 128-byte line of a string is then touched STILE / 16 times less often -- with one fill per TILE columns the kernel read
 // 90 lines per 256-byte pair, 11.5 GB per million pairs at the L2's fabric side, and waited for them)
-template <class W, bool TRANS, int TILE = 16, int STILE = 64>
+// HAVE_CKPT: the forward sweep was the distance pass's (LevBits<.., CKPT>: fixed-length batches; it left the checkpoints of tiles of 16
+// columns and the state behind the last column in P.ckpt) -- phase F is skipped.
+template <class W, bool TRANS, int TILE = 16, int STILE = 64, bool HAVE_CKPT = false>
 struct LevBitsTrace {
+    static_assert(!HAVE_CKPT || TILE == 16, "the distance pass checkpoints every 16th column");
     static_assert(TILE == 8 || TILE == 16 || TILE == 32, "tiles of whole 8-column blocks");
     static_assert(STILE % TILE == 0 && STILE >= TILE && STILE <= 128, "string tiles hold whole tiles");
     using K = LevBits<W, 8, TRANS, false, false, true>;
@@ -175,13 +178,18 @@ struct LevBitsTrace {
             }
         };
 
-        // ---- F: forwards, a checkpoint in front of every tile
+        // ---- F: forwards, a checkpoint in front of every tile (HAVE_CKPT: the distance pass did it; the state behind the last tile is its
+        // last checkpoint)
         init_state();
-        for (uint32_t t = 0; t < tiles; t++) {
-            load_strings(t / RT);
-            if (t == 0) rebuild_window(T0);
-            save_ckpt(t);
-            run_tile(t, std::false_type());
+        if (HAVE_CKPT) {
+            load_ckpt(tiles);
+        } else {
+            for (uint32_t t = 0; t < tiles; t++) {
+                load_strings(t / RT);
+                if (t == 0) rebuild_window(T0);
+                save_ckpt(t);
+                run_tile(t, std::false_type());
+            }
         }
         // ---- B: backwards, tile by tile
         U32 i = W::sel(some, n, W::splat(0)), j = W::sel(some, m, W::splat(0));

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void hamming_search_bits_kernel(SearchParams P
         const uint64_t pos = x - (n - 1u);
         if (pos > last) return;
         uint32_t cnt = 0;
-        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != P.needle_dev[j];
+        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != P.needle[j];           // (n <= 32: the kernarg copy)
         const unsigned long long idx = atomicAdd(P.count, 1ull);
         if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt, 0u};
     };
@@ -694,7 +694,7 @@ template <int Q, int B>
 __global__ __launch_bounds__(512) void hamming_search_phase_kernel(SearchParams P, HamPhaseGeom G, uint32_t *nul_flag) {
     __shared__ __attribute__((aligned(16))) uint32_t mis[256 * 64];
     {
-        const uint32_t m = ham_phase_mis(P.needle_dev, G, threadIdx.x >> 1);
+        const uint32_t m = ham_phase_mis(P.needle_len <= 64u ? P.needle : P.needle_dev, G, threadIdx.x >> 1);   // (up to 64 bytes: the kernarg copy, no upload)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4 *row = (u32x4 *)(mis + (threadIdx.x >> 1) * 64 + (threadIdx.x & 1u) * 32);
 #pragma unroll
@@ -734,7 +734,8 @@ __global__ __launch_bounds__(512) void hamming_search_phase_kernel(SearchParams 
         const uint64_t pos = x - span;
         if (pos > last) return;
         uint32_t cnt = 0;
-        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != P.needle_dev[j];
+        const uint8_t *nd = n <= 64u ? P.needle : P.needle_dev;
+        for (uint32_t j = 0; j < n; j++) cnt += hay[pos + j] != nd[j];
         if (cnt > k) return;
         const unsigned long long idx = atomicAdd(P.count, 1ull);
         if (idx < P.cap) P.hits[idx] = ta_match{P.base + pos, P.base + pos + n, cnt, 0u};
@@ -882,7 +883,7 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     {
         uint32_t Q = 0, L = 0; int B = 0;
         const uint32_t swar_x4 = 4u * (3u * ((P.needle_len + 3u) / 4u) + 4u);
-        if (P.needle_dev && ham_phase_plan(P.needle_len, P.k, Q, L, B) && (P.needle_len > 64u || ham_phase_cost_x4(Q, B) < swar_x4) &&
+        if ((P.needle_dev || P.needle_len <= 64u) && ham_phase_plan(P.needle_len, P.k, Q, L, B) && (P.needle_len > 64u || ham_phase_cost_x4(Q, B) < swar_x4) &&
             !env_str("TA_HAMMING_SEARCH_SWAR") && !env_str("TA_HAMMING_SEARCH_SA") && !env_str("TA_HAMMING_SEARCH_NO_BITS") &&
             !env_str("TA_HAMMING_SEARCH_NO_PHASE")) {
             if (const char *fq = env_str("TA_HAMMING_PHASE_Q")) {                    // tests: force fewer phases (1 or 2) where the plan allows them
@@ -963,6 +964,31 @@ hipError_t hamming_search_launch(const SearchParams &P0, hipStream_t s, uint32_t
     const uint64_t groups = (P.hay_len - P.needle_len + delta) / 4 + 1;
     set_last_kernel_name("hamming_search_kernel");
     hipLaunchKernelGGL(hamming_search_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, P, delta);
+    return hipGetLastError();
+}
+
+// A search's outcome into host-mapped pinned memory (one 256-thread block behind the search kernel on its stream): the hit count, the
+// NUL-byte flag and -- when they are few enough for the box -- the hit records themselves: the host has everything after ONE stream
+// synchronisation, no copy (a count brought back by hipMemcpyAsync into pageable memory + a device-side sort and copy of the hits cost
+// a hamming_search call 0.11 ms beyond its kernel).
+__global__ void search_report_copy_kernel(const unsigned long long *count, const uint32_t *nul_flag, const ta_match *hits, uint64_t cap, uint8_t *box) {
+    SearchReport *rep = (SearchReport *)box;
+    const unsigned long long c = *count;
+    const uint64_t have = c < cap ? c : cap;
+    const bool fits = have <= SEARCH_REPORT_SEL;
+    if (threadIdx.x == 0) {
+        rep->count = c;
+        rep->dense = nul_flag ? *nul_flag : 0u;        // (this report: a NUL byte in the haystack)
+        rep->sel_count = fits ? (uint32_t)have : 0u;
+        rep->sel_state = fits ? 1u : 2u;               // 1: the records follow this header; 2: too many, they are in the caller's device buffer
+    }
+    if (!fits) return;
+    uint64_t *dst = (uint64_t *)(box + sizeof(SearchReport));
+    const uint64_t *src = (const uint64_t *)hits;
+    for (uint64_t w = threadIdx.x; w < have * 3u; w += blockDim.x) dst[w] = src[w];
+}
+hipError_t search_report_copy_launch(const unsigned long long *count, const uint32_t *nul_flag, const ta_match *hits, uint64_t cap, uint8_t *box, hipStream_t s) {
+    hipLaunchKernelGGL(search_report_copy_kernel, dim3(1), dim3(256), 0, s, count, nul_flag, hits, cap, box);
     return hipGetLastError();
 }
 

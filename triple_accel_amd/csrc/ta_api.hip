@@ -1152,8 +1152,14 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
         const bool unit = costs->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || costs->transpose_cost == 1);
         const uint32_t u = lev_batch_unit_k(k, 1, 1, 0, max_len);
         if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len <= 0x7FFFFFF0ull && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
-            if ((rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
-            const uint32_t tile = lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
+            // Fixed-length batches: the distance pass IS the forward sweep -- the stride-8 kernel's CKPT instantiation stores the column
+            // state in front of every 16th column (rows = the shorter string: the views are swapped for it where a is the longer one; the
+            // distance is symmetric).  CSR batches (per-pair orientation) keep the trace kernel's own sweep.  TA_TRACE_OWN_SWEEP=1 pins that.
+            const bool fixed = !a->off && !b->off;
+            const LevBitsPlan bp8 = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 3);
+            const bool fold = fixed && bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE");
+            const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
+            if (!fold && (rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
             // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
             const uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
             Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
@@ -1162,9 +1168,24 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
             LevBitsTraceParams T;
             T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
             T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = runs_cap; T.n_runs = (uint32_t *)ss.dev;
+            if (fold) {
+                const bool sw = a->len > b->len;
+                LevParams P;
+                P.a = view_of(sw ? b : a); P.b = view_of(sw ? a : b);
+                P.subset = nullptr; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
+                P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
+                P.u = bp8.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp8.lds_per_wave; P.Tw = bp8.Tw; P.ch = bp8.ch;
+                P.ckpt = (uint32_t *)cs.dev; P.ckpt_tiles = tiles;
+                TA_HIP(lev_bits_launch(P, bp8, trans, max_len, st, nullptr, nullptr));
+                ta_launch_info l0 = {};
+                ta_lev_select sel;
+                ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
+                l0.cell_bits = sel.cell_bits; l0.transpose = trans;
+                g_last_launch = l0;
+            }
             ta_launch_info li = g_last_launch;                 // (the distance pass's: kernel 3)
             uint32_t grid = 0, lds = 0;
-            TA_HIP(lev_bits_trace_launch(T, trans, edits_dev, n_edits_dev, cap, st, &grid, &lds));
+            TA_HIP(lev_bits_trace_launch(T, trans, fold, edits_dev, n_edits_dev, cap, st, &grid, &lds));
             li.kernel = 8; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
             g_last_launch = li;
             return TA_OK;

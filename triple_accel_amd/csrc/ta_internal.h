@@ -105,7 +105,7 @@ hipError_t compact_none_launch(const uint32_t *out, const uint32_t *subset_in, u
 // batch tracebacks of the unit-cost families by checkpoints + recomputation (lev_bits_trace.hip; bands of up to 33 diagonals)
 uint32_t lev_bits_trace_ckpt_words(bool trans);
 uint32_t lev_bits_trace_tile();
-hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
+hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool have_ckpt, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
                                  uint32_t *grid_out, uint32_t *lds_out);
 hipError_t fill_u32_launch(uint32_t *p, uint32_t v, uint32_t n, hipStream_t st);   // p[0..n) = v, as a kernel (graph-safe)
 hipError_t compact_some_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
@@ -187,6 +187,7 @@ PinBox &search_report_box();
 hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
                                   SearchCtl *ctl, SearchSlot *slots /* SEARCH_SLOT_CAP of them; Best passes */, uint8_t *report_dev,
                                   hipStream_t s);
+hipError_t search_report_copy_launch(const unsigned long long *count, const uint32_t *nul_flag, const ta_match *hits, uint64_t cap, uint8_t *box, hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s, uint32_t *nul_flag = nullptr, bool *nul_done = nullptr);
 
 }  // namespace ta

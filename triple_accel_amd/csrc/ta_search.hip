@@ -275,38 +275,55 @@ int ta_levenshtein_search_best_dev(const uint8_t *needle_host, size_t needle_len
 
 }  // extern "C"
 
-// shared by the SIMD-contract entry (NUL bytes in the haystack are an error, src/hamming.rs:463) and the naive-contract one
+// shared by the SIMD-contract entry (NUL bytes in the haystack are an error, src/hamming.rs:463) and the naive-contract one.
+// host_hits (optional): the hits, unsorted, straight from the report box when they fit it (SEARCH_REPORT_SEL records; *in_box says so) --
+// the caller need not copy them from hits_dev then.
 static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len,
                                    const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
-                                   uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream, bool check_nul) {
+                                   uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream, bool check_nul,
+                                   std::vector<ta_match> *host_hits = nullptr, bool *in_box = nullptr) {
     if (!count_host || (!needle_host && needle_len) || (!haystack_dev && haystack_len)) return TA_ERR_ARG;
     if (!device_ready()) return TA_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     *count_host = 0;
+    if (in_box) *in_box = false;
     if (needle_len == 0 || needle_len > haystack_len) return TA_OK;                     // src/hamming.rs:455-461
     StreamGuard guard(st);
     Scratch &cnt = tls_scratch(2);
+    PinBox &box = search_report_box();
     int rc = cnt.ensure(16);
-    if (rc) return rc;
-    TA_HIP(hipMemsetAsync(cnt.dev, 0, 16, st));
+    if (rc || (rc = box.ensure())) return rc;
+    TA_HIP(fill_u32_launch((uint32_t *)cnt.dev, 0u, 4, st));
     SearchParams P;
     fill_params(P, needle_host, needle_len, haystack_dev, haystack_len, k, nullptr, 0, base, 0, hits_dev, cap,
                 (unsigned long long *)cnt.dev);
-    Scratch &nd = tls_scratch(7);
-    if ((rc = nd.ensure(needle_len + 16))) return rc;
-    TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
-    P.needle_dev = (const uint8_t *)nd.dev;
+    // needles of up to 64 bytes travel in the kernel arguments (SearchParams::needle): no upload
+    // (the round-1 SWAR kernel -- needles beyond 64 bytes the phased filter does not take, or TA_HAMMING_SEARCH_SWAR=1 -- reads the device copy)
+    P.needle_dev = nullptr;
+    if (needle_len > 64 || env_str("TA_HAMMING_SEARCH_SWAR")) {
+        Scratch &nd = tls_scratch(7);
+        if ((rc = nd.ensure(needle_len + 16))) return rc;
+        TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
+        P.needle_dev = (const uint8_t *)nd.dev;
+    }
     // the NUL-byte scan of the SIMD contract (:463) rides inside the search kernel where that kernel reads every byte anyway
     uint32_t *nul_flag = (uint32_t *)((uint8_t *)cnt.dev + 8);
     bool nul_done = false;
     TA_HIP(hamming_search_launch(P, st, check_nul ? nul_flag : nullptr, &nul_done));
     if (check_nul && !nul_done) TA_HIP(has_zero_byte_launch(haystack_dev, haystack_len, nul_flag, st));
-    unsigned long long c[2] = {0, 0};
-    TA_HIP(hipMemcpyAsync(c, cnt.dev, 16, hipMemcpyDeviceToHost, st));
+    // count, NUL flag and (few) hits into host-mapped memory: one synchronisation delivers them
+    TA_HIP(search_report_copy_launch((const unsigned long long *)cnt.dev, nul_flag, hits_dev, cap, box.dev, st));
     TA_HIP(hipStreamSynchronize(st));
-    if ((uint32_t)c[1]) return TA_ERR_NULL_BYTE;
-    *count_host = c[0];
-    return c[0] > cap ? TA_ERR_CAPACITY : TA_OK;
+    const SearchReport *rep = (const SearchReport *)box.host;
+    if (check_nul && rep->dense) return TA_ERR_NULL_BYTE;
+    *count_host = rep->count;
+    if (rep->count > cap) return TA_ERR_CAPACITY;
+    if (host_hits && rep->sel_state == 1) {
+        const ta_match *sel = (const ta_match *)(box.host + sizeof(SearchReport));
+        host_hits->assign(sel, sel + rep->sel_count);
+        if (in_box) *in_box = true;
+    }
+    return TA_OK;
 }
 
 extern "C" {
@@ -315,6 +332,31 @@ int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
                           const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
                           uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
     return hamming_search_dev_impl(needle_host, needle_len, haystack_dev, haystack_len, k, base, hits_dev, cap, count_host, stream, true);
+}
+
+/* ta_hamming_search_dev with the hits on the HOST, sorted by end (library-allocated: ta_free): the few hits of an ordinary search arrive
+ * through host-mapped memory with the call's one stream synchronisation; more than the report box holds are copied from hits_dev. */
+int ta_hamming_search_dev_sorted(const uint8_t *needle_host, size_t needle_len, const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                                 uint64_t base, ta_match *hits_dev, size_t cap, ta_match **out, size_t *n_out, void *stream) {
+    if (!out || !n_out) return TA_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    std::vector<ta_match> v;
+    bool in_box = false;
+    uint64_t count = 0;
+    int rc = hamming_search_dev_impl(needle_host, needle_len, haystack_dev, haystack_len, k, base, hits_dev, cap, &count, stream, true, &v, &in_box);
+    if (rc) return rc;
+    if (!in_box && count) {
+        v.resize(count);
+        TA_HIP(hipMemcpy(v.data(), hits_dev, count * sizeof(ta_match), hipMemcpyDeviceToHost));
+    }
+    sort_by_end(v);
+    *n_out = v.size();
+    if (!v.empty()) {
+        *out = (ta_match *)malloc(v.size() * sizeof(ta_match));
+        if (!*out) return TA_ERR_ARG;
+        memcpy(*out, v.data(), v.size() * sizeof(ta_match));
+    }
+    return TA_OK;
 }
 
 // The hits of a device-resident All-mode result that can survive the Best fold -- those with the smallest k -- sorted by end.
