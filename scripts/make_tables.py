@@ -52,7 +52,7 @@ def main():
     out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
             "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
     for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg4_mutated", "cfg3", "cfg3_mutated", "cfg3_mutated_host_rounds", "cfg5", "cfg5w_220", "cfg5w_231", "cfg5w_2213", "cfg5w_1101",
-               "cfg5w_231_nofilter", "cfg1", "cfg2w", "cfg2w_prefilter", "cfg2w_mutated", "cfg2w_mutated_prefilter", "cfg4w", "cfg4w_prefilter", "cfg2l", "cfg2s", "cfg2t", "cfg2t_dp",
+               "cfg5w_231_nofilter", "cfg1", "cfg2w", "cfg2w_prefilter", "cfg2w_mutated", "cfg2w_mutated_prefilter", "cfg4w", "cfg4w_prefilter", "cfg2l", "cfg2s", "cfg2t", "cfg2t_own_sweep", "cfg2t_dp",
                "cfg2_ragged", "cfg2_ragged_vline", "cfg2_dna",
                "cfg2_dna5", "cfg2_protein_table", "hsearch8", "hsearch16", "hsearch32", "hsearch32_r04", "hsearch64", "hsearch64_r04", "cfg2_early_out", "cfg2_2m"):
         b = J("bench_%s.json" % wl)
@@ -84,7 +84,7 @@ def main():
             "(cfg3_mutated: the levenshtein_exp rounds, device-driven; cfg3_mutated_host_rounds: TA_EXP_HOST_ROUNDS=1, an A/B row); cfg5w_<costs>: levenshtein_search of cfg5's "
             "geometry under EditCosts(2,2,0,None) / (2,3,1,None) / (2,2,1,Some(3)) / RDAMERAU_COSTS through the superset filter, cfg5w_231_nofilter: round 4's route "
             "(TA_SEARCH_NOWFILTER=1, an A/B row); cfgNw_prefilter / cfg2w_mutated_prefilter: ta_set_option(TA_OPT_UNIT_PREFILTER) -- same answers, data-dependent work, NOT a "
-            "headline figure; cfg2t: the checkpoint-and-recompute kernel (cfg2t_dp: the DP kernel's records, TA_TRACE_NO_BITS=1, an A/B row); hsearchN_r04: round 4's routing "
+            "headline figure; cfg2t: the checkpoint-and-recompute kernel, its forward sweep done by the distance pass (cfg2t_own_sweep: the trace kernel's own forward sweep, TA_TRACE_OWN_SWEEP=1; cfg2t_dp: the DP kernel's records, TA_TRACE_NO_BITS=1: A/B rows); hsearchN_r04: round 4's routing "
             "(TA_HAMMING_SEARCH_NO_PHASE=1, A/B rows).)", ""]
     e2e = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg5", "cfg1", "cfg2_ragged")]
     out += ["## Host buffers in, answers out (`end_to_end_ms`: pinned H2D of the batch + the pass + D2H; never the headline)", "",
@@ -108,7 +108,7 @@ def main():
                        ("cfg2_ragged", "lev_bits_"), ("cfg2_ragged", "len_hist"), ("cfg2_ragged", "len_scan"), ("cfg2_ragged", "len_scatter"),
                        ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8"), ("cfg2_dna5", "lev_bitsqw_kernel"), ("cfg2_protein_table", "lev_bitsqw_kernel"), ("cfg2_ragged_vline", "lev_bits_s8v"), ("cfg2_ragged_vline", "len_scatter"),
                        ("cfg2l", "lev_band_score"), ("cfg2s", "lev_bits_line"), ("cfg2s", "scale_results"), ("cfg2t", "lev_band_trace_kernel"), ("cfg2t", "lev_trace_walk"),
-                       ("cfg2t", "lev_bits_trace_kernel"), ("cfg2t", "lev_bits_s8_kernel"), ("cfg3_mutated", "lev_bits_"), ("cfg3_mutated", "lev_widebits_kernel"), ("cfg3_mutated", "compact_"),
+                       ("cfg2t", "lev_bits_trace_kernel"), ("cfg2t", "lev_bits_s8_ckpt_kernel"), ("cfg3_mutated", "lev_bits_"), ("cfg3_mutated", "lev_widebits_kernel"), ("cfg3_mutated", "compact_"),
                        ("cfg3_mutated", "bag_bound"), ("cfg4_mutated", "lev_bits2"), ("cfg5w_231", "lev_filter_kernel"), ("cfg5w_231", "lev_search_wave_kernel"),
                        ("cfg5w_2213", "lev_filter_kernel"), ("cfg5w_2213", "lev_search_wave_kernel"),
                        ("cfg2w_prefilter", "lev_bits_"), ("cfg2w_prefilter", "compact_some"), ("cfg2w_prefilter", "lev_band_score"),
