@@ -190,6 +190,12 @@ int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
  * call this for their first element and run the full search only when a second one is asked for. */
 int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
                                 uint32_t k, const ta_edit_costs *costs, int anchored, ta_match *out, int *found);
+/* The All-mode result for a caller that has just taken its first element with ta_levenshtein_search_first on THE SAME haystack (same pointer
+ * and length, bytes unchanged: the caller's promise -- the bindings' lazy iterators hold the haystack immutable): the bytes that call uploaded
+ * stay on the device, only the rest travels (src/levenshtein.rs:2282-2420: the reference's lazy iterator continues where it stopped).  After
+ * any other call of the thread it is ta_levenshtein_search_simd_with_opts(.., TA_SEARCH_ALL, ..). */
+int ta_levenshtein_search_resume(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                                 uint32_t k, const ta_edit_costs *costs, int anchored, ta_match **out, size_t *n_out);
 /* the same over a haystack shard resident in HBM (positions + base; the end == 0 match is the caller's, as with *_search_dev) */
 int ta_levenshtein_search_first_dev(const uint8_t *needle_host, size_t needle_len,
                                     const uint8_t *haystack_dev, size_t haystack_len,

@@ -52,6 +52,8 @@ mod ffi {
                                                     out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_levenshtein_search_first(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                            costs: *const TaEditCosts, anchored: c_int, out: *mut TaMatch, found: *mut c_int) -> c_int;
+        pub fn ta_levenshtein_search_resume(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
+                                            costs: *const TaEditCosts, anchored: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_hamming_search_simd_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
                                                 search_type: c_int, out: *mut *mut TaMatch, n_out: *mut usize) -> c_int;
         pub fn ta_hamming_search_naive_with_opts(needle: *const u8, n: usize, haystack: *const u8, h: usize, k: u32,
@@ -263,7 +265,8 @@ pub mod levenshtein {
 
     /// All-mode result over a long haystack, lazily (the reference's iterator is lazy too, src/levenshtein.rs:2282-2420): the
     /// first element comes from `ta_levenshtein_search_first`, which stops scanning (and uploading) at the first window that
-    /// holds a hit; the full search runs when a second element is asked for.  Element for element the eager sequence.
+    /// holds a hit; the full search runs when a second element is asked for -- on the device copy the first call started, only the
+    /// rest of the haystack is uploaded then (`ta_levenshtein_search_resume`).  Element for element the eager sequence.
     struct LazyAll<'a> { needle: &'a [u8], haystack: &'a [u8], k: u32, costs: EditCosts, anchored: bool, state: u8,
                          rest: std::vec::IntoIter<Match> }
     impl<'a> Iterator for LazyAll<'a> {
@@ -280,8 +283,10 @@ pub mod levenshtein {
             if self.state == 1 {
                 self.state = 2;
                 let (mut p, mut n, c) = (std::ptr::null_mut::<TaMatch>(), 0usize, self.costs.raw());
-                check(unsafe { ta_levenshtein_search_simd_with_opts(self.needle.as_ptr(), self.needle.len(), self.haystack.as_ptr(),
-                                                                    self.haystack.len(), self.k, 0, &c, self.anchored as c_int, &mut p, &mut n) });
+                // (the haystack is borrowed for 'a: the same pointer, the same bytes as in the first call -- only what that call did not
+                // upload travels now)
+                check(unsafe { ta_levenshtein_search_resume(self.needle.as_ptr(), self.needle.len(), self.haystack.as_ptr(),
+                                                            self.haystack.len(), self.k, &c, self.anchored as c_int, &mut p, &mut n) });
                 self.rest = unsafe { take_matches(p, n) }.into_iter();
                 self.rest.next();                              // the element already handed out
             }

@@ -552,3 +552,40 @@ def test_cfg5w_geometry_shard():
             want = O.levenshtein_search_naive_with_opts(needle, hay, 16, st, costs, False)
             got = [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, 16, st, T.EditCosts(*costs), False)]
             assert got == want and len(want) > 0, (costs, st)
+
+
+def test_lazy_iterator_resumes_on_the_resident_prefix(capfd, monkeypatch):
+    """The second element of the lazy All-mode iterator does not upload the haystack again: ta_levenshtein_search_resume keeps what
+    ta_levenshtein_search_first uploaded (the TA_DEBUG line says how many bytes), sends the rest, and returns the eager sequence -- hits in the
+    first window, beyond it, in the last bytes; a different haystack, another search in between or an exhausted first call make it the plain call."""
+    import triple_accel_amd as T
+    monkeypatch.setenv("TA_DEBUG", "1")
+    g = Dg.rng(777)
+    needle = Dg.rand_str(g, 20)
+    size = 3_000_000
+    for where in ([40_000, 2_000_000], [700_000, 700_300, 2_999_900], [2_999_970]):
+        hay = bytearray(g.integers(33, 127, size=size, dtype=np.uint8).tobytes())
+        for w in where:
+            hay[w:w + 20] = needle
+        hay = bytes(hay)
+        want = O.levenshtein_search_naive_with_opts(needle, hay, 2, O.ALL, (1, 1, 0, None), False)
+        assert len(want) >= len(where)
+        it = T.levenshtein_search_simd_with_opts(needle, hay, 2, T.SearchType.All, T.LEVENSHTEIN_COSTS, False)
+        first = next(it)
+        capfd.readouterr()
+        rest = list(it)
+        err = capfd.readouterr().err
+        assert [tuple(first)] + [tuple(m) for m in rest] == want
+        assert "search resume:" in err, err[-300:]
+        resident = int(err.split("search resume:")[1].split()[0])
+        assert 20 <= resident <= size and resident >= where[0], (resident, where)
+        assert resident < size or where[0] > 2_900_000
+    # another call in between: the plain call (nothing claimed resident), same sequence
+    hay2 = bytes(g.integers(33, 127, size=size, dtype=np.uint8).tobytes())
+    it = T.levenshtein_search_simd_with_opts(needle, hay, 2, T.SearchType.All, T.LEVENSHTEIN_COSTS, False)
+    first = next(it)
+    assert T.levenshtein_search_first(needle, hay2, 2) is None or True
+    capfd.readouterr()
+    rest = list(it)
+    assert "search resume:" not in capfd.readouterr().err
+    assert [tuple(first)] + [tuple(m) for m in rest] == want

@@ -260,8 +260,10 @@ class _LazyMatches:
             return first
         if self._state == 1:
             self._state = 2
-            self._rest = _matches(_n.lib().ta_levenshtein_search_simd_with_opts, needle, len(needle), haystack, len(haystack), k,
-                                  SearchType.All, _C.byref(costs._c()), int(bool(anchored)))
+            # (ta_levenshtein_search_resume: the bytes the first call uploaded stay on the device, only the rest of the haystack travels;
+            # `haystack` is an immutable bytes object held by this iterator: the same pointer, the same contents)
+            self._rest = _matches(_n.lib().ta_levenshtein_search_resume, needle, len(needle), haystack, len(haystack), k,
+                                  _C.byref(costs._c()), int(bool(anchored)))
             next(self._rest)                                  # the element already handed out
         return next(self._rest)
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_search_simd_with_opts", "ta_levenshtein_search", "ta_hamming_search_simd_with_opts",
     "ta_hamming_search", "ta_hamming_search_naive_with_opts", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
-    "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted",
+    "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted", "ta_levenshtein_search_resume",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
     sig("ta_levenshtein_exp_with_opts", i32, [u8p, sz, u8p, sz, i32, cp, u32p])
     sig("ta_levenshtein_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, cp, i32, mpp, szp])
     sig("ta_levenshtein_search", i32, [u8p, sz, u8p, sz, mpp, szp])
+    sig("ta_levenshtein_search_resume", i32, [u8p, sz, u8p, sz, u32, cp, i32, mpp, szp])
     sig("ta_levenshtein_search_first", i32, [u8p, sz, u8p, sz, u32, cp, i32, C.POINTER(MatchC), C.POINTER(C.c_int)])
     sig("ta_levenshtein_search_first_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, C.c_uint64, C.POINTER(MatchC), C.POINTER(C.c_int), C.c_void_p])
     sig("ta_hamming_search_simd_with_opts", i32, [u8p, sz, u8p, sz, u32, i32, mpp, szp])

@@ -464,6 +464,7 @@ void ta_thread_release(void) {
     for (int i = 0; i < TA_SCRATCH_SLOTS; i++) tls_scratch(i).release();
     call_ctx().release();
     search_report_box().release();
+    search_resident_reset();
     LastUse &u = last_use();                     // the event that orders this thread's calls across streams
     if (u.ev) (void)hipEventDestroy(u.ev);
     u = LastUse{};

@@ -33,7 +33,8 @@ struct Scratch {
     void release();
     ~Scratch();
 };
-constexpr int TA_SCRATCH_SLOTS = 17;
+constexpr int TA_SCRATCH_SLOTS = 18;
+constexpr int TA_SLOT_SEARCH_HAY = 17;        // the host search entries' haystack staging: nothing else writes it (ta_levenshtein_search_resume relies on that)
 Scratch &tls_scratch(int which);
 
 // Per-thread context of the single-call host API: its own non-blocking stream (concurrent callers never meet on the null
@@ -183,6 +184,7 @@ struct PinBox {
     void release();
 };
 PinBox &search_report_box();
+void search_resident_reset();        // forget what ta_levenshtein_search_first left in the haystack staging buffer (ta_search.hip)
 // one wavefront per flagged block (lev_search_wave_body.h), persistent grid reading n_list on the device; needles <= 64 bytes
 hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, const uint32_t *list, uint32_t cap_list,
                                   SearchCtl *ctl, SearchSlot *slots /* SEARCH_SLOT_CAP of them; Best passes */, uint8_t *report_dev,

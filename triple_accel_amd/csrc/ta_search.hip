@@ -1,6 +1,7 @@
 // ta_search.hip -- search entry points of the C ABI: special cases, haystack tiling, hit gathering,
 // and the order-dependent Best post-pass (host).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -412,8 +413,16 @@ static int give(std::vector<ta_match> &v, ta_match **out, size_t *n_out) {
 // stage a haystack into device scratch (with read slack) and collect the All-mode hits, sorted by end; everything runs on
 // the calling thread's own stream.  The hit buffer starts at min(haystack_len + 2, 4M) records; a denser result (All mode
 // over a big haystack, k >= needle_len) reports its true count, and the pass is repeated once with room for exactly that.
+// What ta_levenshtein_search_first left in this thread's haystack staging buffer (tls_scratch(TA_SLOT_SEARCH_HAY)): the first `upto` bytes of the caller's
+// haystack.  ta_levenshtein_search_resume -- "the rest of the All-mode result over THE SAME haystack" -- uploads only what is missing.
+struct ResidentHay { const uint8_t *host = nullptr; size_t len = 0; uint64_t upto = 0; const void *dev = nullptr; };
+static ResidentHay &resident_hay() { static thread_local ResidentHay r; return r; }
+namespace ta { void search_resident_reset() { resident_hay() = ResidentHay{}; } }     // (ta_thread_release: the staging buffer is gone)
+static thread_local uint64_t g_resume_upto = 0;      // set by ta_levenshtein_search_resume around its call of the full search
+
 template <class Launch>
-static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::vector<ta_match> &hits, Launch launch) {
+// resident_upto: bytes [0, resident_upto) of the haystack are already in that buffer (0: none)
+static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::vector<ta_match> &hits, Launch launch, uint64_t resident_upto = 0) {
     if (!device_ready()) return TA_ERR_HIP;
     CallCtx &cx = call_ctx();
     int rc = cx.ensure();
@@ -422,7 +431,7 @@ static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::ve
     // read it in place and write their hits next to it -- no staging copy in, no copy of the hits out.  Room for the haystack
     // and at least 64 hits; a denser result falls through to the general path below.
     const size_t hay_pad = (haystack_len + TA_BLOB_SLACK + 255) & ~(size_t)255;
-    if (hay_pad + 64 * sizeof(ta_match) <= CallCtx::RESULT_OFF) {
+    if (!resident_upto && hay_pad + 64 * sizeof(ta_match) <= CallCtx::RESULT_OFF) {
         const size_t pcap = (CallCtx::RESULT_OFF - hay_pad) / sizeof(ta_match);
         if (haystack_len) memcpy(cx.pin, haystack, haystack_len);
         memset(cx.pin + haystack_len, 0, TA_BLOB_SLACK);
@@ -438,12 +447,17 @@ static int run_search_host(const uint8_t *haystack, size_t haystack_len, std::ve
         }
         if (rc != TA_ERR_CAPACITY) return rc;
     }
-    Scratch &hs = tls_scratch(0), &ob = tls_scratch(1);
+    Scratch &hs = tls_scratch(TA_SLOT_SEARCH_HAY), &ob = tls_scratch(1);
+    if (hs.cap < haystack_len + TA_BLOB_SLACK + 64) resident_upto = 0;                          // (the buffer is about to be re-allocated)
     if ((rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64))) return rc;
     size_t cap = haystack_len + 2;
     if (cap > (1u << 22)) cap = (1u << 22);
     if ((rc = ob.ensure(cap * sizeof(ta_match)))) return rc;
-    if (haystack_len) TA_HIP(hipMemcpyAsync(hs.dev, haystack, haystack_len, hipMemcpyHostToDevice, cx.st));
+    if (resident_upto > haystack_len || resident_hay().dev != hs.dev) resident_upto = 0;       // (the buffer was re-allocated: nothing is resident)
+    if (resident_upto && env_int("TA_DEBUG")) fprintf(stderr, "[triple_accel_amd] search resume: %llu of %zu haystack bytes already resident\n", (unsigned long long)resident_upto, haystack_len);
+    if (haystack_len > resident_upto)
+        TA_HIP(hipMemcpyAsync((uint8_t *)hs.dev + resident_upto, haystack + resident_upto, haystack_len - resident_upto, hipMemcpyHostToDevice, cx.st));
+    resident_hay() = ResidentHay{};                                // (whatever runs next starts from scratch)
     uint64_t count = 0;
     rc = launch((const uint8_t *)hs.dev, (ta_match *)ob.dev, cap, &count, cx.st);
     if (rc == TA_ERR_CAPACITY && count > cap && count <= (uint64_t)haystack_len + 2) {
@@ -491,7 +505,7 @@ int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_le
     int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         if (haystack_len == 0) { *cnt = 0; return (int)TA_OK; }
         return ta_levenshtein_search_dev(needle, needle_len, hd, haystack_len, k, costs, anchored, 0, 0, od, cap, cnt, st);
-    });
+    }, g_resume_upto);
     if (rc) return rc;
     // the match that ends before the first haystack byte (:1693-1706, SIMD :2394-2399)
     const uint32_t whole_gap = (uint32_t)needle_len * costs->gap_cost + costs->start_gap_cost;
@@ -564,6 +578,7 @@ int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const 
                                 uint32_t k, const ta_edit_costs *costs, int anchored, ta_match *out, int *found) {
     if (!out || !found || (!needle && needle_len) || (!haystack && haystack_len)) return TA_ERR_ARG;
     *found = 0;
+    resident_hay() = ResidentHay{};                                            // (set again below if this call uploads a prefix)
     if (!search_costs_ok(costs)) return TA_ERR_BAD_COSTS;
     if (needle_len == 0) {                                                      // src/levenshtein.rs:1919-1963
         if (anchored) { *out = ta_match{0, 0, 0, 0}; *found = 1; }
@@ -588,14 +603,33 @@ int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const 
     CallCtx &cx = call_ctx();
     int rc = cx.ensure();
     if (rc) return rc;
-    Scratch &hs = tls_scratch(0);
+    Scratch &hs = tls_scratch(TA_SLOT_SEARCH_HAY);
     if ((rc = hs.ensure(haystack_len + TA_BLOB_SLACK + 64))) return rc;
     uint8_t *hd = (uint8_t *)hs.dev;
     hipStream_t st = cx.st;
-    return first_hit_windows(needle, needle_len, hd, haystack_len, k, costs, 0, out, found, st, [&](uint64_t from, uint64_t to) -> int {
+    uint64_t upto = 0;
+    rc = first_hit_windows(needle, needle_len, hd, haystack_len, k, costs, 0, out, found, st, [&](uint64_t from, uint64_t to) -> int {
         TA_HIP(hipMemcpyAsync(hd + from, haystack + from, (size_t)(to - from), hipMemcpyHostToDevice, st));   // only as far as the scan gets
+        if (from == upto) upto = to;                               // (the windows' uploads are consecutive)
         return (int)TA_OK;
     });
+    resident_hay() = rc == TA_OK ? ResidentHay{haystack, haystack_len, upto, hs.dev} : ResidentHay{};
+    return rc;
+}
+
+/* The All-mode result of ta_levenshtein_search_simd_with_opts for a caller that has just taken its first element with
+ * ta_levenshtein_search_first ON THE SAME HAYSTACK (same pointer, same length, unchanged bytes -- the caller's promise; the bindings' lazy
+ * iterators hold the haystack borrowed / immutable): the bytes that call uploaded stay where they are, only the rest of the haystack
+ * travels, then the whole search runs on the resident copy.  Anything else in between on this thread, a different haystack or a
+ * re-allocated staging buffer make it the plain call.  (src/levenshtein.rs:2282-2420: the reference's iterator continues where it stopped.) */
+int ta_levenshtein_search_resume(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
+                                 uint32_t k, const ta_edit_costs *costs, int anchored, ta_match **out, size_t *n_out) {
+    const ResidentHay r = resident_hay();
+    const uint64_t upto = (r.host == haystack && r.len == haystack_len && haystack_len) ? r.upto : 0;
+    g_resume_upto = upto;
+    const int rc = ta_levenshtein_search_simd_with_opts(needle, needle_len, haystack, haystack_len, k, TA_SEARCH_ALL, costs, anchored, out, n_out);
+    g_resume_upto = 0;
+    return rc;
 }
 
 int ta_levenshtein_search(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
