@@ -125,7 +125,7 @@ static void filter_n(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint
 
 extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *hay, uint64_t h, uint32_t k, int has_t,
                               uint64_t tile, uint64_t halo, int force_words, uint64_t *blocks_out, uint64_t cap, uint64_t *count) {
-    if (n == 0 || n > 256 || tile == 0 || tile % FILTER_BLOCK) return 1;
+    if (n == 0 || n > 512 || tile == 0 || tile % FILTER_BLOCK) return 1;
     std::vector<uint64_t> blocks;
     uint32_t nwf = (n + 31) / 32;
     const bool lower_bound = force_words == -1;       // lev_filter_tile_lb: the score settled per 32 columns (needles <= 32 bytes)
@@ -152,6 +152,8 @@ extern "C" int emu_lev_filter(const uint8_t *needle, uint32_t n, const uint8_t *
             case 6: filter_n<6>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
             case 7: filter_n<7>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
             case 8: filter_n<8>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 9: case 10: case 11: case 12: filter_n<12>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
+            case 13: case 14: case 15: case 16: filter_n<16>(needle, n, hay, h, k, has_t, tile, halo, blocks); break;
             default: return 2;
         }
     }

@@ -42,10 +42,11 @@ def test_filter_small_alphabet_and_nulls():
 
 @pytest.mark.parametrize("trans", [False, True])
 def test_filter_long_needles(trans):
-    """Needles of 33..256 bytes: the multi-dword form of the scan (and a short needle forced onto 2 and 3 dwords)."""
+    """Needles of 33..512 bytes: the multi-dword form of the scan (and a short needle forced onto 2 and 3 dwords; beyond 256 bytes the
+    vectors are 12 or 16 dwords whatever the needle's own count: round 5)."""
     g = Dg.rng(43)
     costs = RDAM if trans else LEV
-    for n in (33, 64, 65, 100, 200, 256):
+    for n in (33, 64, 65, 100, 200, 256, 257, 300, 384, 385, 500, 512):
         needle = Dg.rand_str(g, n)
         hay = Dg.planted_haystack(200 + n, needle, 8000, 900 + n, max(1, n // 5))
         for k in (0, n // 6, n // 3):

@@ -200,11 +200,11 @@ def test_filter_falls_back_when_matches_are_dense():
 
 @pytest.mark.parametrize("costs", [(1, 1, 0, None), (1, 1, 0, 1)])
 def test_long_needles_through_the_filter(costs, monkeypatch):
-    """Needles of 33..256 bytes: multi-dword candidate filter + the memory-backed exact kernel on the flagged blocks,
-    against the oracle (All and Best) and against the exact kernel over everything."""
+    """Needles of 33..512 bytes: multi-dword candidate filter + the memory-backed exact kernel on the flagged blocks,
+    against the oracle (All and Best) and against the exact kernel over everything (beyond 256 bytes: 12- / 16-dword vectors, round 5)."""
     from triple_accel_amd import batch as B
     g = Dg.rng(0x10F6)
-    for n in (33, 64, 100, 256):
+    for n in (33, 64, 100, 256, 257, 300, 420, 512):
         needle = Dg.rand_str(g, n)
         hay = Dg.planted_haystack(int(g.integers(1 << 30)), needle, 150_000, 9000 + n, max(1, n // 6))
         for k in (n // 8, n // 3):

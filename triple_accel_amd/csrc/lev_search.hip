@@ -193,7 +193,7 @@ __global__ __launch_bounds__(REPL ? 512 : 256) void lev_filter_kernel(SearchPara
     }
 }
 
-// needles of 33..256 bytes: NWF-dword vectors, match table (256 x NWF dwords) in LDS built from the device copy of the needle
+// needles of 33..512 bytes: NWF-dword vectors, match table (256 x NWF dwords) in LDS built from the device copy of the needle
 template <int NWF, bool TRANS>
 __global__ __launch_bounds__(256) void lev_filter_kernel_n(SearchParams P, uint32_t *list, uint32_t list_cap, unsigned int *list_count) {
     __shared__ uint32_t peq[256 * NWF];
@@ -287,6 +287,8 @@ hipError_t lev_filter_launch(const SearchParams &P, bool trans, uint32_t *list, 
         case 6: return launch_filter_n<6>(P, trans, grid, list, list_cap, list_count, s);
         case 7: return launch_filter_n<7>(P, trans, grid, list, list_cap, list_count, s);
         case 8: return launch_filter_n<8>(P, trans, grid, list, list_cap, list_count, s);
+        case 9: case 10: case 11: case 12: return launch_filter_n<12>(P, trans, grid, list, list_cap, list_count, s);     // needles of up to 384 bytes
+        case 13: case 14: case 15: case 16: return launch_filter_n<16>(P, trans, grid, list, list_cap, list_count, s);    // up to 512 (round 5; the table: 16 KB of LDS)
         default: return hipErrorInvalidValue;
     }
 }

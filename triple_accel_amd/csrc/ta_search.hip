@@ -156,7 +156,7 @@ static int search_dev_core(const uint8_t *needle_host, size_t needle_len, const 
     // filter -- every alignment of weighted cost <= k has at most k' unit edits -- in front of the exact kernel, which knows the
     // real costs.  With k' >= needle_len every position matches: no filter.  (TA_SEARCH_NOWFILTER=1: unit costs only, round 4's rule.)
     const uint32_t kf = unit ? k : srch_filter_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, trans, costs->transpose_cost);
-    const bool filter_ok = (unit || !env_str("TA_SEARCH_NOWFILTER")) && !anchored && needle_len <= 256 && kf < needle_len && h >= 4096 &&
+    const bool filter_ok = (unit || !env_str("TA_SEARCH_NOWFILTER")) && !anchored && needle_len <= 512 && kf < needle_len && h >= 4096 &&
                            !env_str("TA_SEARCH_NOFILTER");
     bool searched = false;
     unsigned long long c = 0;
