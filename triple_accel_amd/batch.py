@@ -171,16 +171,19 @@ def _hits_to_numpy(hits_t, count):
     return out
 
 
-_hit_bufs = {}
+import threading as _threading
+
+_hit_bufs = _threading.local()
 
 
 def _hit_buffer(device, cap):
-    """Reused device buffer for hit records (24 B each)."""
+    """Reused device buffer for hit records (24 B each), one per calling thread (concurrent callers' kernels write their hits into it)."""
     key = (str(device), cap)
-    if key not in _hit_bufs:
-        _hit_bufs.clear()
-        _hit_bufs[key] = torch.empty(cap * 3, dtype=torch.int64, device=device)
-    return _hit_bufs[key]
+    bufs = _hit_bufs.__dict__.setdefault("bufs", {})
+    if key not in bufs:
+        bufs.clear()
+        bufs[key] = torch.empty(cap * 3, dtype=torch.int64, device=device)
+    return bufs[key]
 
 
 def levenshtein_search_dev(needle, haystack, k, costs=LEVENSHTEIN_COSTS, anchored=False, base=0, emit_from=0, cap=None):
