@@ -216,6 +216,7 @@ struct LevBitsTrace {
             run_tile(t, std::true_type());
             W::lds_wave_sync();
             Bool act = some & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u);
+            if (P.runs_cap == 0u) act = W::bfalse();            // (a timing probe, TA_TRACE_SKIP_WALK=1: the recomputation without the walk -- no scripts)
             while (W::any(act)) {
                 // MATCHES FIRST: where x[i-1] == y[j-1] the scalar routine takes the diagonal whatever the neighbours hold (sub = diag is
                 // never above a_gap or b_gap -- adjacent cells differ by at most one -- and a transposition of four equal characters

@@ -1162,13 +1162,13 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
             const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
             if (!fold && (rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
             // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
-            const uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
+            uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
             Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
             if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (rc = ps.ensure((size_t)n * runs_cap * 4u)) ||
                 (rc = ss.ensure((size_t)n * 4u))) return rc;
             LevBitsTraceParams T;
             T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
-            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = runs_cap; T.n_runs = (uint32_t *)ss.dev;
+            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = env_int("TA_TRACE_SKIP_WALK") ? 0u : runs_cap; T.n_runs = (uint32_t *)ss.dev;
             if (fold) {
                 const bool sw = a->len > b->len;
                 LevParams P;
