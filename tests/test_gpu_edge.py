@@ -195,3 +195,53 @@ def test_many_helpers_and_failed_flush():
     q.push(big, near)
     assert q.flush() == [O.levenshtein_simd_k_with_opts(big, y, 12, False, (2, 3, 1, None))[0] for y in (big[::-1], near)]
     q.close()
+
+
+def test_round5_paths_on_degenerate_batches():
+    """This round's batch paths on degenerate shapes: empty strings (all of them, one side only), one-byte strings, k = 0, batches of 1 / 63 /
+    65 / 1,024 / 1,025 pairs -- device-driven levenshtein_exp rounds, the unit-cost pre-pass, checkpoint tracebacks (CSR and fixed-length),
+    hamming_search with needle = haystack and with no hit at all."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    g = Dg.rng(0xED6E)
+    shapes = []
+    shapes.append(([b""] * 1500, [b""] * 1500))
+    shapes.append(([b""] * 1100, [Dg.rand_str(g, int(g.integers(0, 9))) for _ in range(1100)]))
+    shapes.append(([Dg.rand_str(g, 1) for _ in range(1025)], [Dg.rand_str(g, 1) for _ in range(1025)]))
+    for n in (1, 63, 65, 1024, 1025):
+        a = [Dg.rand_str(g, int(g.integers(0, 70))) for _ in range(n)]
+        shapes.append((a, [Dg.mutate(g, x, int(g.integers(0, 6)), True) if i % 3 else Dg.rand_str(g, int(g.integers(0, 70))) for i, x in enumerate(a)]))
+    for a, b in shapes:
+        sa, sb, ca, cb = B.Strings.from_list(a), B.Strings.from_list(b), O.csr_from_list(a), O.csr_from_list(b)
+        for costs in ((1, 1, 0, None), (1, 1, 0, 1), (2, 3, 1, None)):
+            got = B.levenshtein_exp_batch(sa, sb, costs).cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, O.levenshtein_exp_batch(ca, cb, costs)), (len(a), costs)
+        try:
+            T.set_option(T.OPT_UNIT_PREFILTER, True)
+            for k in (0, 3, 40):
+                got = B.levenshtein_k_batch(sa, sb, k, (2, 3, 1, None)).cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, O.levenshtein_k_batch(ca, cb, k, (2, 3, 1, None))), (len(a), k)
+        finally:
+            T.set_option(T.OPT_UNIT_PREFILTER, False)
+        for costs in ((1, 1, 0, None), (1, 1, 0, 1)):
+            for k in (0, 2, 30):
+                out, ed, ne = B.levenshtein_trace_batch(sa, sb, k, costs)
+                d, scripts = out.cpu().numpy().view(np.uint32), B.edits_to_lists(ed, ne)
+                for i in range(0, len(a), max(1, len(a) // 60)):
+                    wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+                    assert (d[i] == wd and scripts[i] == we) if wd is not None else (d[i] == 0xFFFFFFFF and scripts[i] == []), (len(a), i, k, costs)
+    # fixed-length batches of one-byte and of 16-byte strings through the folded forward sweep
+    for L, n in ((1, 70), (16, 1030), (17, 64)):
+        am, bm = Dg.pairs_mutated_fixed(0xED70 + L, n, L, 1)
+        out, ed, ne = B.levenshtein_trace_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), 4)
+        d, scripts = out.cpu().numpy().view(np.uint32), B.edits_to_lists(ed, ne)
+        for i in range(n):
+            wd, we = O.levenshtein_simd_k_with_opts(am[i].tobytes(), bm[i].tobytes(), 4, True)
+            assert (d[i] == wd and scripts[i] == we) if wd is not None else (d[i] == 0xFFFFFFFF and scripts[i] == []), (L, i)
+    # hamming_search: the haystack IS the needle; no hit anywhere; a needle longer than the haystack
+    for nl in (8, 24, 33, 64, 200):
+        needle = bytes(int(c) or 1 for c in Dg.random_bytes(g, nl))
+        assert [tuple(int(v) for v in r) for r in B.hamming_search_dev(needle, B.haystack_tensor(needle), 0)] == [(0, nl, 0)]
+        hay = bytes([7]) * 5000
+        assert len(B.hamming_search_dev(bytes([9]) * nl, B.haystack_tensor(hay), nl // 4)) == 0
+        assert len(B.hamming_search_dev(needle, B.haystack_tensor(needle[:-1]), 1)) == 0
