@@ -491,7 +491,10 @@ int ta_levenshtein_k_batch(const ta_strings *a, const ta_strings *b, size_t n, u
     bool exact_columns = false;
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
         const uint32_t u = lev_batch_unit_k(k, costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, max_len);
-        // the key counts what the kernel of this pass iterates over: columns (bit-parallel kernels) or anti-diagonal steps (DP band kernel)
+        // the key counts what the kernel of this pass iterates over: columns (bit-parallel kernels) or anti-diagonal steps (DP band kernel).
+        // (the kernels whose time follows max(len_a, len_b) or len_a -- two pairs per lane, the single-pair kernel, the row-blocked
+        // one -- never see a length-ordered CSR wavefront of many pairs: the first takes fixed-length batches only, the other two run ONE pair
+        // per wavefront, where the order only shapes the launch's tail; len_b is the right key for everything that is ordered by columns.)
         const bool unit = (costs->mismatch_cost == 1 && costs->gap_cost == 1 && costs->start_gap_cost == 0 && (!costs->has_transpose || costs->transpose_cost == 1)) ||
                           lev_unit_scale(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose != 0, costs->transpose_cost);
         const bool by_steps = !unit || env_int("TA_NO_BITS") || env_int("TA_FORCE_D") || env_int("TA_FORCE_L");
