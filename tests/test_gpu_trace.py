@@ -221,3 +221,26 @@ def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
         for i in range(0, 3000, 41):
             wd, we = O.levenshtein_simd_k_with_opts(xa[i].tobytes(), xb[i].tobytes(), k, True, costs)
             assert (d2[i] == wd and l2[i] == we) if wd is not None else (d2[i] == 0xFFFFFFFF and l2[i] == []), i
+
+
+def test_trace_batch_in_a_captured_graph():
+    """ta_levenshtein_trace_batch synchronises nothing and fills nothing with memset nodes: the call (distance pass with checkpoints + the
+    trace kernel; the DP route's two kernels for weighted costs) can be captured into a graph and replayed -- same scripts."""
+    import torch
+    from triple_accel_amd import batch as B
+    am, bm = Dg.pairs_mutated_fixed(0x6A0, 5000, 180, 14, swaps=True)
+    sa, sb = B.Strings.from_fixed(am), B.Strings.from_fixed(bm)
+    for costs, k in (((1, 1, 0, 1), 30), ((2, 3, 1, None), 40)):
+        out, ed, ne = B.levenshtein_trace_batch(sa, sb, k, costs)                      # (sizes the library's scratch)
+        want_d, want_s = out.cpu().numpy().copy(), B.edits_to_lists(ed, ne)
+        torch.cuda.synchronize()
+        st, gr = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(gr, stream=st):
+                B.levenshtein_trace_batch(sa, sb, k, costs, out=out, edits=ed, n_edits=ne)
+        out.fill_(7); ne.fill_(0); ed.fill_(0)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want_d) and B.edits_to_lists(ed, ne) == want_s, costs
+    wd, we = O.levenshtein_simd_k_with_opts(am[5].tobytes(), bm[5].tobytes(), 40, True, (2, 3, 1, None))
+    assert (want_s[5] == we) if wd is not None else (want_s[5] == [])

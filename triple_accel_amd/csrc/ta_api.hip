@@ -1210,15 +1210,18 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
     const uint64_t wave_words = taus * 2 * 64 * tw;
     // the records of one chunk: at most ~4 GiB and at most a quarter of the device memory that is free right now (or one wavefront's, if
     // that is more)
-    uint64_t rec_budget = 4ull << 30;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < rec_budget) rec_budget = free_b / 4;
-    }
-    uint64_t waves_per_chunk = (rec_budget / 4) / wave_words;
-    if (waves_per_chunk == 0) waves_per_chunk = 1;
     const uint64_t waves_all = (n + pl.PW - 1) / pl.PW;
+    uint64_t waves_per_chunk = ((4ull << 30) / 4) / wave_words;
+    if (waves_per_chunk == 0) waves_per_chunk = 1;
     if (waves_per_chunk > waves_all) waves_per_chunk = waves_all;
+    if (wave_words * waves_per_chunk * 4 > tls_scratch(6).cap) {      // the scratch has to grow: not beyond a quarter of what is free right now
+        size_t free_b = 0, total_b = 0;                                // (asked only then: a captured call must not query the device)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t budget = ((uint64_t)free_b + tls_scratch(6).cap) / 4;
+            if (wave_words * waves_per_chunk * 4 > budget) waves_per_chunk = (budget / 4) / wave_words;
+            if (waves_per_chunk == 0) waves_per_chunk = 1;
+        }
+    }
     if (wave_words * waves_per_chunk * 4 > (48ull << 30)) { set_last_error_msg("batch traceback: more than 48 GB of records for one wavefront"); return TA_ERR_UNSUPPORTED; }
     Scratch &ts = tls_scratch(6), &ps = tls_scratch(9);
     const uint32_t path_words = (uint32_t)((2 * max_len) / 16 + 2);                  // 2-bit codes of a pair's path, sixteen per word
