@@ -107,6 +107,8 @@ struct EmuWave {
     }
     static U32 bfe(const U32 &x, uint32_t off, uint32_t width) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (x.v[i] >> off) & ((1u << width) - 1u); return r; }
     static U32 lshl_add(const U32 &a, uint32_t s, const U32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] << s) + b.v[i]; return r; }
+    static U32 alignbyte_v(const U32 &hi, const U32 &lo, const U32 &s) {
+        V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)(((((uint64_t)hi.v[i]) << 32) | lo.v[i]) >> (8 * (s.v[i] & 3u))); return r; }
     static U32 clz(const U32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (uint32_t)__builtin_clz(x.v[i]) : 32u; return r; }
     static U32 shlv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] << (s.v[i] & 31); return r; }
     static U32 shrv(const U32 &x, const U32 &s) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] >> (s.v[i] & 31); return r; }

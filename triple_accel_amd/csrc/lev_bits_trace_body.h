@@ -45,8 +45,8 @@ struct LevBitsTrace {
     static constexpr uint32_t T0 = 64;                                   // iteration of column 1 (a multiple of 8, >= the 32 warm-up iterations)
     static constexpr uint32_t CK_WORDS = TRANS ? 5 : 2;                  // VP, VN (, PM', bottom PM', D0')
     // per-lane string slot: a = PA pieces covering a-indices [a_lo, a_lo + 16 PA) -- the tile's bytes, the 32 before them (the window is
-    // rebuilt from those) and 8 more (the walk compares the eight characters up to a[i - 1] at once); b = PB pieces from 16 bytes before the tile
-    static constexpr uint32_t PA = (40 + STILE + 15 + 15) / 16, PB = 1 + STILE / 16, RT = STILE / TILE;
+    // rebuilt from those) and 12 more (the walk reads the twelve characters up to a[i - 1] at once); b = PB pieces from 16 bytes before the tile
+    static constexpr uint32_t PA = (44 + STILE + 15 + 15) / 16, PB = 1 + STILE / 16, RT = STILE / TILE;
     static constexpr uint32_t SLOT = 16 * (PA + PB) + 4;                 // bytes per lane (an odd number of dwords)
     // records, [word][lane]: pre-column VP / VN of columns 0 .. TILE (TILE = the column behind the tile), D0 of columns 0 .. TILE - 1,
     // one word of bottom-diagonal D0 bits (bit c = column c), and for the transposition test the D0 of the column in front of the tile
@@ -89,27 +89,41 @@ struct LevBitsTrace {
         // tp - T0 + 1 with b[tp - T0]): pieces on the strings' own 16-byte grids, zeros outside the strings
         U32 a_lo = W::splat(0);                                            // a-index of the slot's first byte (may be "negative": two's complement)
         uint32_t b_lo = 0, loaded = 0xFFFFFFFFu;                           // b-index of the b slot's first byte; the string tile the slots hold
-        auto load_strings = [&](uint32_t T) {
-            if (T == loaded) return;
-            loaded = T;
-            const Bool all = (lane == lane);
-            const U32 first = (W::splat((uint32_t)STILE * T) + nlo) - 40u; // a-index the string tile needs first (mod 2^32)
-            a_lo = first & ~15u;
+        // fetch: the pieces of string tile T into registers (in flight until commit needs them -- phase B asks for tile T - 1 as soon as tile T
+        // sits in the slots: its latency hides behind RT tiles of work); commit: into the slots
+        Q sa[PA], sb[PB];
+        uint32_t fetched = 0xFFFFFFFFu;
+        auto fetch_strings = [&](uint32_t T) {
+            fetched = T;
+            const U32 lo = ((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u;   // a-index the string tile needs first (mod 2^32), on the 16-byte grid
 #pragma unroll
             for (uint32_t p = 0; p < PA; p++) {
-                const U32 q0 = a_lo + 16u * p;                             // a-index of the piece ("negative" in front of the string: huge, not below n)
+                const U32 q0 = lo + 16u * p;                               // a-index of the piece ("negative" in front of the string: huge, not below n)
                 const Bool ok = some & (q0 < n);
-                W::lds_store16(lds, slot + 16u * p, W::gload16(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))), ok), all);
+                sa[p] = W::gload16(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))), ok);
             }
-            b_lo = (uint32_t)STILE * T - 16u;
+            const uint32_t blo = (uint32_t)STILE * T - 16u;
 #pragma unroll
             for (uint32_t p = 0; p < PB; p++) {
                 const bool front = T == 0u && p == 0u;                     // the piece in front of the string: zeros
-                const uint32_t q0 = front ? 0u : b_lo + 16u * p;
+                const uint32_t q0 = front ? 0u : blo + 16u * p;
                 const Bool ok = front ? W::bfalse() : (some & (W::splat(q0) < m));
-                W::lds_store16(lds, slot + 16u * (PA + p), W::gload16(W::ptr_add(yp, W::splat(q0)), ok), all);
+                sb[p] = W::gload16(W::ptr_add(yp, W::splat(q0)), ok);
             }
+        };
+        auto load_strings = [&](uint32_t T, bool ahead) {
+            if (T == loaded) return;
+            if (fetched != T) fetch_strings(T);
+            loaded = T;
+            const Bool all = (lane == lane);
+            a_lo = ((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u;
+            b_lo = (uint32_t)STILE * T - 16u;
+#pragma unroll
+            for (uint32_t p = 0; p < PA; p++) W::lds_store16(lds, slot + 16u * p, sa[p], all);
+#pragma unroll
+            for (uint32_t p = 0; p < PB; p++) W::lds_store16(lds, slot + 16u * (PA + p), sb[p], all);
             W::lds_wave_sync();
+            if (ahead && T > 0u) fetch_strings(T - 1u);
         };
         // LDS addresses of the bytes of iteration tp (a) / of b[tp - T0]
         auto a_addr = [&](uint32_t tp) { return slot + (((W::splat(tp - T0) + nlo) - a_lo)); };
@@ -169,23 +183,26 @@ struct LevBitsTrace {
                 W::store_u32(c + 256, lane, st.D0p[0], lane == lane);
             }
         };
-        auto load_ckpt = [&](uint32_t t) {
+        // the checkpoint in front of tile t: asked for one tile ahead (phase B), taken into the state when the tile starts
+        U32 ckv[CK_WORDS];
+        auto fetch_ckpt = [&](uint32_t t) {
             const uint32_t *c = ck + (uint64_t)t * (CK_WORDS * 64u);
-            st.VP[0] = W::load_u32(c, lane, lane == lane, 0u); st.VN[0] = W::load_u32(c + 64, lane, lane == lane, 0u);
-            if (TRANS) {
-                st.PMp[0] = W::load_u32(c + 128, lane, lane == lane, 0u); st.PMp[1] = W::load_u32(c + 192, lane, lane == lane, 0u);
-                st.D0p[0] = W::load_u32(c + 256, lane, lane == lane, 0u);
-            }
+#pragma unroll
+            for (uint32_t w = 0; w < CK_WORDS; w++) ckv[w] = W::load_u32(c + 64u * w, lane, lane == lane, 0u);
+        };
+        auto take_ckpt = [&]() {
+            st.VP[0] = ckv[0]; st.VN[0] = ckv[1];
+            if (TRANS) { st.PMp[0] = ckv[2]; st.PMp[1] = ckv[3]; st.D0p[0] = ckv[4]; }
         };
 
         // ---- F: forwards, a checkpoint in front of every tile (HAVE_CKPT: the distance pass did it; the state behind the last tile is its
         // last checkpoint)
         init_state();
         if (HAVE_CKPT) {
-            load_ckpt(tiles);
+            fetch_ckpt(tiles); take_ckpt();
         } else {
             for (uint32_t t = 0; t < tiles; t++) {
-                load_strings(t / RT);
+                load_strings(t / RT, false);
                 if (t == 0) rebuild_window(T0);
                 save_ckpt(t);
                 run_tile(t, std::false_type());
@@ -205,10 +222,12 @@ struct LevBitsTrace {
             cur = W::sel(on, e, cur);
         };
         U32 nxt_vp = st.VP[0], nxt_vn = st.VN[0];                          // the pre-state of the column behind the last tile
+        if (tiles > 0u) fetch_ckpt(tiles - 1u);
         for (uint32_t t = tiles; t-- > 0u;) {
             const uint32_t tb = T0 + (uint32_t)TILE * t, j_lo = (uint32_t)TILE * t;      // the tile's columns: j_lo + 1 .. j_lo + TILE
-            load_strings(t / RT);
-            load_ckpt(t);
+            load_strings(t / RT, true);
+            take_ckpt();
+            if (t > 0u) fetch_ckpt(t - 1u);
             rebuild_window(tb);
             W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
             W::lds_write32(rec, raddr(R_VP + TILE), nxt_vp); W::lds_write32(rec, raddr(R_VN + TILE), nxt_vn);
@@ -218,34 +237,28 @@ struct LevBitsTrace {
             Bool act = some & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u);
             if (P.runs_cap == 0u) act = W::bfalse();            // (a timing probe, TA_TRACE_SKIP_WALK=1: the recomputation without the walk -- no scripts)
             while (W::any(act)) {
-                // MATCHES FIRST: where x[i-1] == y[j-1] the scalar routine takes the diagonal whatever the neighbours hold (sub = diag is
-                // never above a_gap or b_gap -- adjacent cells differ by at most one -- and a transposition of four equal characters
-                // costs one more), so a run of equal characters is a run of code 0: up to eight steps per iteration, no records read
-                {
-                    const U32 xo = W::sel(act, (i - 1u) - a_lo, W::splat(8)), yo = W::sel(act, (j - 1u) - b_lo, W::splat(8));
-                    const U32 xh = W::lds_read32u(lds, slot + (xo - 3u)), yh = W::lds_read32u(lds, slot + 16u * PA + (yo - 3u));
-                    const U32 xl = W::lds_read32u(lds, slot + (xo - 7u)), yl = W::lds_read32u(lds, slot + 16u * PA + (yo - 7u));
-                    const U32 dh = xh ^ yh, dl = xl ^ yl;
-                    U32 r = W::sel(dh == 0u, W::splat(4) + (W::clz(dl) >> 3), W::clz(dh) >> 3);      // equal bytes from x[i-1] / y[j-1] downwards
-                    r = W::umin(r, W::umin(i, j - j_lo));
-                    const Bool fast = act & (r > 0u);
-                    note(W::splat(0), r, fast);                                // r Matches
-                    i = W::sel(fast, i - r, i); j = W::sel(fast, j - r, j);
-                    act = act & (j > j_lo) & (i > 0u);
-                    if (!W::any(act)) break;
-                }
+                // One iteration = ONE general step at (i, j) and the run of matches behind it, on ONE round trip to LDS: the cell's records and
+                // the twelve characters of each string up to x[i-1] / y[j-1] are requested together.  (Where x[i-1] == y[j-1] the scalar routine
+                // takes the diagonal whatever the neighbours hold -- sub = diag is never above a_gap or b_gap: adjacent cells differ by at most
+                // one -- and a transposition of four equal characters costs one more: a run of equal characters is a run of diagonal steps, up
+                // to eight of them per iteration without a look at a record.)
                 // (lanes that are not walking read the tile's first record and the slot's first bytes: every address stays inside the block)
                 const U32 c = W::sel(act, (j - j_lo) - 1u, W::splat(0));   // column within the tile
                 const U32 bi = W::sel(act, (i + dhi) - j, W::splat(1));    // window bit of row i at column j: 0 .. 32
+                const U32 xo = slot + W::sel(act, (i - 1u) - a_lo, W::splat(12)), yo = slot + 16u * PA + W::sel(act, (j - 1u) - b_lo, W::splat(12));
+                const U32 X2 = W::lds_read32u(lds, xo - 3u), X1 = W::lds_read32u(lds, xo - 7u), X0 = W::lds_read32u(lds, xo - 11u);    // x[i-4..i-1], x[i-8..i-5], x[i-12..i-9]
+                const U32 Y2 = W::lds_read32u(lds, yo - 3u), Y1 = W::lds_read32u(lds, yo - 7u), Y0 = W::lds_read32u(lds, yo - 11u);
                 const U32 d0w = W::lds_read32(rec, raddr_v(c + R_D0)), botw = W::lds_read32(rec, raddr(R_BOT));
+                const U32 vp1 = W::lds_read32(rec, raddr_v(c + (R_VP + 1u))), vn1 = W::lds_read32(rec, raddr_v(c + (R_VN + 1u)));
+                const U32 vp0 = W::lds_read32(rec, raddr_v(c + R_VP)), vn0 = W::lds_read32(rec, raddr_v(c + R_VN));
+                const Bool first_col = c == 0u;
+                const U32 d0m = TRANS ? W::lds_read32(rec, raddr_v(W::sel(first_col, W::splat(R_D0P), c + (R_D0 - 1u)))) : W::splat(0);
                 const U32 d0 = W::sel(bi >= 32u, W::shrv(botw, c), W::shrv(d0w, bi)) & 1u;
                 // v(i, j): the pre-state of column j + 1 at bit bi - 1 (bi = 0: the row above is outside the window)
-                const U32 vp1 = W::lds_read32(rec, raddr_v(c + (R_VP + 1u))), vn1 = W::lds_read32(rec, raddr_v(c + (R_VN + 1u)));
                 const Bool up_ok = bi >= 1u;
                 const U32 sh1 = W::sel(up_ok, bi - 1u, W::splat(0));
                 const U32 v_ij = (W::shrv(vp1, sh1) & 1u) - (W::shrv(vn1, sh1) & 1u);
                 // v(i, j - 1): the pre-state of column j at bit bi (bi = 32: the bottom diagonal has no left neighbour)
-                const U32 vp0 = W::lds_read32(rec, raddr_v(c + R_VP)), vn0 = W::lds_read32(rec, raddr_v(c + R_VN));
                 const Bool left_ok = bi <= 31u;
                 const U32 sh0 = W::sel(left_ok, bi, W::splat(0));
                 const U32 v_l = (W::shrv(vp0, sh0) & 1u) - (W::shrv(vn0, sh0) & 1u);
@@ -254,18 +267,14 @@ struct LevBitsTrace {
                 const U32 diag = W::splat(BIAS) - (d0 ^ 1u);
                 const U32 up = W::sel(up_ok, W::splat(BIAS) - v_ij, W::splat(INF));
                 const U32 left = W::sel(left_ok, diag + v_l, W::splat(INF));
-                // the characters: x[i - 1], x[i - 2] (a-index - a_lo), y[j - 1], y[j - 2]
-                const U32 xa = slot + W::sel(act, (i - 1u) - a_lo, W::splat(4)), ya = slot + 16u * PA + W::sel(act, (j - 1u) - b_lo, W::splat(4));
-                const U32 x1 = W::lds_u8(lds, xa), y1 = W::lds_u8(lds, ya);
+                const U32 x1 = X2 >> 24, y1 = Y2 >> 24;                     // x[i - 1], y[j - 1]
                 const U32 sub = diag + W::sel(x1 == y1, W::splat(0), W::splat(1)), ag = left + 1u, bg = up + 1u;
                 const U32 m1 = W::umin(sub, ag);
                 U32 code = W::sel(bg < m1, W::splat(2), W::sel(ag < sub, W::splat(1), W::splat(0)));      // :493-515
                 if (TRANS) {
-                    const U32 x2 = W::lds_u8(lds, xa - 1u), y2 = W::lds_u8(lds, ya - 1u);
+                    const U32 x2 = (X2 >> 16) & 255u, y2 = (Y2 >> 16) & 255u;                               // x[i - 2], y[j - 2]
                     const Bool tt = (i > 1u) & (j > 1u) & (x1 == y2) & (x2 == y1);                           // :517-532
                     // D[i-2][j-2] = D0(i-1, j-1) ? diag : diag - 1; (i-1, j-1) is window bit bi of column j - 1
-                    const Bool first_col = c == 0u;
-                    const U32 d0m = W::lds_read32(rec, raddr_v(W::sel(first_col, W::splat(R_D0P), c + (R_D0 - 1u))));
                     const U32 botm = W::sel(first_col, W::splat(0), W::shrv(botw, W::sel(first_col, W::splat(0), c - 1u)));
                     const U32 d0p = W::sel(bi >= 32u, botm, W::shrv(d0m, sh0)) & 1u;
                     const Bool dd_ok = (bi <= 31u) | !first_col;          // (the bottom bit of the column in front of the tile is not kept: a band-edge cell)
@@ -274,8 +283,19 @@ struct LevBitsTrace {
                     code = W::sel(tt & (tval <= nv), W::splat(3), code);
                 }
                 note(W::sel(code == 0u, W::sel(x1 == y1, W::splat(0), W::splat(1)), W::sel(code == 1u, e_left, W::sel(code == 2u, e_up, W::splat(4)))), W::splat(1), act);
-                i = W::sel(act & (code != 1u), i - W::sel(code == 3u, W::splat(2), W::splat(1)), i);
-                j = W::sel(act & (code != 2u), j - W::sel(code == 3u, W::splat(2), W::splat(1)), j);
+                const U32 two = W::sel(code == 3u, W::splat(2), W::splat(1));
+                const U32 di = W::sel(code != 1u, two, W::splat(0)), dj = W::sel(code != 2u, two, W::splat(0));
+                const U32 i1 = i - di, j1 = j - dj;
+                // the run of matches behind the step: the strings' last eight characters in front of (i1, j1), out of the twelve that were read
+                const U32 xh = W::sel(di == 0u, X2, W::alignbyte_v(X2, X1, W::splat(4) - di)), xl = W::sel(di == 0u, X1, W::alignbyte_v(X1, X0, W::splat(4) - di));
+                const U32 yh = W::sel(dj == 0u, Y2, W::alignbyte_v(Y2, Y1, W::splat(4) - dj)), yl = W::sel(dj == 0u, Y1, W::alignbyte_v(Y1, Y0, W::splat(4) - dj));
+                const U32 dh = xh ^ yh, dl = xl ^ yl;
+                U32 r = W::sel(dh == 0u, W::splat(4) + (W::clz(dl) >> 3), W::clz(dh) >> 3);      // equal characters from x[i1-1] / y[j1-1] downwards
+                r = W::umin(r, W::sel(j1 > j_lo, W::umin(i1, j1 - j_lo), W::splat(0)));
+                const Bool fast = act & (r > 0u);
+                note(W::splat(0), r, fast);                                    // r Matches
+                i = W::sel(act, i1 - W::sel(fast, r, W::splat(0)), i);
+                j = W::sel(act, j1 - W::sel(fast, r, W::splat(0)), j);
                 act = act & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u) & (i <= n);
             }
         }

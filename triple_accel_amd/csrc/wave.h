@@ -91,6 +91,8 @@ struct DevWave {
     // (a << s) + b -> v_lshl_add_u32
     static __device__ __forceinline__ U32 lshl_add(U32 a, uint32_t s, U32 b) { return (a << s) + b; }
     // per-lane shift amounts (< 32)
+    // ({hi, lo} >> 8 (s & 3)) [31:0] with the byte count in a register (v_alignbyte_b32)
+    static __device__ __forceinline__ U32 alignbyte_v(U32 hi, U32 lo, U32 s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
     static __device__ __forceinline__ U32 clz(U32 x) { return (U32)__clz((int)x); }        // leading zero bits, 32 for 0
     static __device__ __forceinline__ U32 shlv(U32 x, U32 s) { return x << s; }
     static __device__ __forceinline__ U32 shrv(U32 x, U32 s) { return x >> s; }
