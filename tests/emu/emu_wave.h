@@ -164,6 +164,8 @@ struct EmuWave {
         return q;
     }
     static Q128V gload16_nt(const Ptr &p, const Bool &pred) { return gload16(p, pred); }
+    static Q128V gload16_all(const Ptr &p) { Bool all; for (int l = 0; l < 64; l++) all.v[l] = true; return gload16(p, all); }
+    static Q128V qkeep(Q128V q, const Bool &keep) { for (int l = 0; l < 64; l++) if (!keep.v[l]) q.v[l] = Q128{0u, 0u, 0u, 0u}; return q; }
     // ---- VLINE fetch form: whole 128-byte lines are read, also the bytes of a line that lie outside the string (on the device: the
     // same line, mapped memory).  The drivers register the blobs; a byte outside every registered range reads as 0xA5.
     struct Range { const uint8_t *lo, *hi; };

@@ -49,7 +49,7 @@ hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool h
     if (waves == 0) return hipSuccess;
     if (have_ckpt) {
         set_last_kernel_name("lev_bits_trace_kernel<%s, 16, %u, true>", trans ? "true" : "false", stile);
-#define TA_BTC(T_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, 16, SL_, true>::LDS_PER_WAVE; if (lds_out) *lds_out = lds; \
+#define TA_BTC(T_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, 16, SL_, true>::LDS_PER_WAVE + 1024u * (uint32_t)env_int("TA_TRACE_LDS_PAD_KB"); if (lds_out) *lds_out = lds; \
         hipLaunchKernelGGL((lev_bits_trace_kernel<T_, 16, SL_, true>), dim3(waves), dim3(64), lds, s, P, edits, n_edits, cap); } while (0)
         if (stile == 64u) { if (trans) TA_BTC(true, 64); else TA_BTC(false, 64); }
         else { if (trans) TA_BTC(true, 32); else TA_BTC(false, 32); }

@@ -90,40 +90,56 @@ struct LevBitsTrace {
         U32 a_lo = W::splat(0);                                            // a-index of the slot's first byte (may be "negative": two's complement)
         uint32_t b_lo = 0, loaded = 0xFFFFFFFFu;                           // b-index of the b slot's first byte; the string tile the slots hold
         // fetch: the pieces of string tile T into registers (in flight until commit needs them -- phase B asks for tile T - 1 as soon as tile T
-        // sits in the slots: its latency hides behind RT tiles of work); commit: into the slots
-        Q sa[PA], sb[PB];
-        uint32_t fetched = 0xFFFFFFFFu;
-        auto fetch_strings = [&](uint32_t T) {
-            fetched = T;
-            const U32 lo = ((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u;   // a-index the string tile needs first (mod 2^32), on the 16-byte grid
+        // sits in the slots: its latency hides behind RT tiles of work); commit: into the slots.  A piece outside its string is fetched from
+        // the string's first bytes instead (readable: TA_BLOB_SLACK) and zeroed on its way into the slot -- no branch around the loads, so
+        // they write the registers that wait for the commit.
+        auto a_piece = [&](uint32_t T, uint32_t p, U32 &q0) {             // a-index of piece p ("negative" in front of the string: huge, not below n)
+            q0 = (((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u) + 16u * p;
+            return some & (q0 < n);
+        };
+        auto b_piece = [&](uint32_t T, uint32_t p, uint32_t &q0) {        // (the piece in front of the string: zeros)
+            const bool front = T == 0u && p == 0u;
+            q0 = front ? 0u : (uint32_t)STILE * T - 16u + 16u * p;
+            return front ? W::bfalse() : (some & (W::splat(q0) < m));
+        };
+        auto fetch_strings = [&](uint32_t T, Q (&sa)[PA], Q (&sb)[PB]) {
 #pragma unroll
             for (uint32_t p = 0; p < PA; p++) {
-                const U32 q0 = lo + 16u * p;                               // a-index of the piece ("negative" in front of the string: huge, not below n)
-                const Bool ok = some & (q0 < n);
-                sa[p] = W::gload16(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))), ok);
+                U32 q0;
+                const Bool ok = a_piece(T, p, q0);
+                sa[p] = W::gload16_all(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))));
             }
-            const uint32_t blo = (uint32_t)STILE * T - 16u;
 #pragma unroll
             for (uint32_t p = 0; p < PB; p++) {
-                const bool front = T == 0u && p == 0u;                     // the piece in front of the string: zeros
-                const uint32_t q0 = front ? 0u : blo + 16u * p;
-                const Bool ok = front ? W::bfalse() : (some & (W::splat(q0) < m));
-                sb[p] = W::gload16(W::ptr_add(yp, W::splat(q0)), ok);
+                uint32_t q0;
+                const Bool ok = b_piece(T, p, q0);
+                sb[p] = W::gload16_all(W::ptr_add(yp, W::sel(ok, W::splat(q0), W::splat(0))));
             }
         };
-        auto load_strings = [&](uint32_t T, bool ahead) {
-            if (T == loaded) return;
-            if (fetched != T) fetch_strings(T);
+        auto commit_strings = [&](uint32_t T, const Q (&sa)[PA], const Q (&sb)[PB]) {
             loaded = T;
             const Bool all = (lane == lane);
             a_lo = ((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u;
             b_lo = (uint32_t)STILE * T - 16u;
 #pragma unroll
-            for (uint32_t p = 0; p < PA; p++) W::lds_store16(lds, slot + 16u * p, sa[p], all);
+            for (uint32_t p = 0; p < PA; p++) {
+                U32 q0;
+                const Bool ok = a_piece(T, p, q0);
+                W::lds_store16(lds, slot + 16u * p, W::qkeep(sa[p], ok), all);
+            }
 #pragma unroll
-            for (uint32_t p = 0; p < PB; p++) W::lds_store16(lds, slot + 16u * (PA + p), sb[p], all);
+            for (uint32_t p = 0; p < PB; p++) {
+                uint32_t q0;
+                const Bool ok = b_piece(T, p, q0);
+                W::lds_store16(lds, slot + 16u * (PA + p), W::qkeep(sb[p], ok), all);
+            }
             W::lds_wave_sync();
-            if (ahead && T > 0u) fetch_strings(T - 1u);
+        };
+        auto load_strings = [&](uint32_t T) {                               // (phase F: fetch and commit on the spot)
+            if (T == loaded) return;
+            Q fa[PA], fb[PB];
+            fetch_strings(T, fa, fb);
+            commit_strings(T, fa, fb);
         };
         // LDS addresses of the bytes of iteration tp (a) / of b[tp - T0]
         auto a_addr = [&](uint32_t tp) { return slot + (((W::splat(tp - T0) + nlo) - a_lo)); };
@@ -202,7 +218,7 @@ struct LevBitsTrace {
             fetch_ckpt(tiles); take_ckpt();
         } else {
             for (uint32_t t = 0; t < tiles; t++) {
-                load_strings(t / RT, false);
+                load_strings(t / RT);
                 if (t == 0) rebuild_window(T0);
                 save_ckpt(t);
                 run_tile(t, std::false_type());
@@ -222,11 +238,17 @@ struct LevBitsTrace {
             cur = W::sel(on, e, cur);
         };
         U32 nxt_vp = st.VP[0], nxt_vn = st.VN[0];                          // the pre-state of the column behind the last tile
-        if (tiles > 0u) fetch_ckpt(tiles - 1u);
-        for (uint32_t t = tiles; t-- > 0u;) {
+        // string tiles from the last one down; the tile in front is in flight (registers) while this one's RT tiles are worked on.  It is
+        // asked for unconditionally (tile 0 asks for itself again), so that the loads write the registers the next commit reads, and inside
+        // the string tile's FIRST tile, behind the wait for that tile's checkpoint and in front of the request for the next one: every
+        // later wait finds loads that have had a whole tile's work to arrive.
+        Q sa[PA], sb[PB];
+        uint32_t T = tiles > 0u ? (tiles - 1u) / RT : 0u, t = tiles;
+        auto do_tile = [&](auto ahead_tag) {
+            t--;
             const uint32_t tb = T0 + (uint32_t)TILE * t, j_lo = (uint32_t)TILE * t;      // the tile's columns: j_lo + 1 .. j_lo + TILE
-            load_strings(t / RT, true);
             take_ckpt();
+            if (decltype(ahead_tag)::value) fetch_strings(T > 0u ? T - 1u : 0u, sa, sb);
             if (t > 0u) fetch_ckpt(t - 1u);
             rebuild_window(tb);
             W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
@@ -298,6 +320,14 @@ struct LevBitsTrace {
                 j = W::sel(act, j1 - W::sel(fast, r, W::splat(0)), j);
                 act = act & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u) & (i <= n);
             }
+        };
+        if (tiles > 0u) { fetch_ckpt(tiles - 1u); fetch_strings(T, sa, sb); }
+        while (t > 0u) {
+            commit_strings(T, sa, sb);
+            const uint32_t t_lo = T * RT;
+            do_tile(std::true_type());
+            while (t > t_lo) do_tile(std::false_type());
+            T = T > 0u ? T - 1u : 0u;
         }
         // the borders: row 0 (j steps left) and column 0 (i steps up), each one run
         note(e_left, j, some & (i == 0u) & (j > 0u) & (j <= m));

@@ -305,6 +305,15 @@ struct DevWave {
         }
         return q;
     }
+    // 16 bytes from an arbitrarily aligned global address, EVERY lane (all addresses readable): no branch and no zero-fill, so the load's
+    // destination can be a register that lives across iterations -- a prefetch stays in flight until the value is read
+    static __device__ __forceinline__ Q128 gload16_all(Ptr p) {
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+        const u32x4u v = *(const u32x4u *)p;
+        Q128 q = {v.x, v.y, v.z, v.w};
+        return q;
+    }
+    static __device__ __forceinline__ Q128 qkeep(Q128 q, Bool keep) { Q128 r = {keep ? q.x : 0u, keep ? q.y : 0u, keep ? q.z : 0u, keep ? q.w : 0u}; return r; }
     // same, streamed: the line is consumed whole by this one load, do not keep it in L2 (nt)
     static __device__ __forceinline__ Q128 gload16_nt(Ptr p, Bool pred) {
         Q128 q = {0u, 0u, 0u, 0u};
