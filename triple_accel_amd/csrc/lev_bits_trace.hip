@@ -23,9 +23,16 @@ __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P
     const uint32_t have = nr < P.runs_cap ? nr : P.runs_cap;
     const uint32_t *mine = P.runs + (uint64_t)pair * P.runs_cap;
     ta_edit *slot = edits + (uint64_t)pair * cap;
-    for (uint32_t t = 0; t < have && t < cap; t++) {
-        const uint32_t w = mine[have - 1u - t];
-        slot[t] = ta_edit{w >> 29, 0u, (uint64_t)(w & 0x1FFFFFFFu)};
+    // eight runs per round trip: loads and stores share one counter here, so a load waited for alone also waits for the stores in front of it
+    // (one run per iteration: a memory round trip per run, 45 in a row for the longest list of a wavefront -- a quarter of its life)
+    const uint32_t lim = (uint64_t)have < cap ? have : (uint32_t)cap;
+    for (uint32_t t0 = 0; t0 < lim; t0 += 8u) {
+        uint32_t w[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) w[u] = mine[t0 + u < lim ? have - 1u - (t0 + u) : 0u];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++)
+            if (t0 + u < lim) slot[t0 + u] = ta_edit{w[u] >> 29, 0u, (uint64_t)(w[u] & 0x1FFFFFFFu)};
     }
 }
 

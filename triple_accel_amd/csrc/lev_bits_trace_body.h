@@ -9,13 +9,16 @@
 // 33 diagonals) does, in ONE kernel:
 //   F. a forward sweep over the columns that keeps the column state (VP, VN; with the transposition term PM', D0') at every TILE-th
 //      column: 8 bytes per pair and checkpoint, in scratch memory;
-//   B. tile by tile from the last one down: restore the tile's checkpoint, run its TILE columns again -- the same step8 -- and keep what
-//      the walk needs of EVERY column of the tile in LDS (3 words per column and lane); then every lane walks its path through the tile,
-//      from where it entered it to the tile's first column, and counts the RUNS of the script as it goes -- the characters are in LDS, so a
-//      diagonal step is a Match or a Mismatch on the spot -- storing a run (edit type, count: one word) when it closes: last run first.
-// The strings go straight from memory into a per-lane LDS slot, a tile's bytes at a time (a lane's 16-byte loads; every line of a string
-// is touched a few times -- forwards, backwards -- instead of the records' 16 x).  A last step turns the pair's runs round and writes them as
-// ta_edit records (lev_bits_trace.hip).
+//   B. tile by tile from the last one down: restore the tile's checkpoint (asked for one tile ahead), run its TILE columns again -- the
+//      same step8 -- and keep what the walk needs of EVERY column of the tile in LDS (3 words per column and lane); then every lane walks
+//      its path through the tile, from where it entered it to the tile's first column, and counts the RUNS of the script as it goes -- the
+//      tile's characters are in LDS too, so a diagonal step is a Match or a Mismatch on the spot and a run of equal characters is taken
+//      eight at a time -- storing a run (edit type, count: one word) when it closes: last run first.
+// The strings of STILE columns sit in REGISTERS (a lane's 16-byte loads on the string's own grid, through LDS once to land on the lane's
+// window offset; every line of a string is touched a few times -- forwards, backwards -- instead of the records' 16 x): the recomputation
+// reads them at compile-time register indices, and LDS holds per lane only the records and ONE tile's characters for the walk -- 19.3 KB per
+// wavefront, 8 wavefronts per CU (with the string tile itself in LDS: 27.3 KB, 6; the kernel's time follows the residency one to one).
+// A last step turns the pair's runs round and writes them as ta_edit records (lev_bits_trace.hip).
 //
 // The distances come from the distance kernel (the caller runs it first): a pair it answered None has no script, and the walk needs no
 // absolute value.  Rows = the SHORTER string (the reference swaps, :386-390: the tie order depends on it); swap is per lane.
@@ -26,8 +29,8 @@ namespace ta {
 
 // (LevBitsTraceParams: lev_band_body.h, next to LevParams)
 
-// TILE: columns per checkpoint / per set of records in LDS; STILE: columns whose characters one fill of the string slots covers (a multiple
-// of TILE: every 128-byte line of a string is then touched STILE / 16 times less often -- with one fill per TILE columns the kernel read
+// TILE: columns per checkpoint / per set of records in LDS; STILE: columns whose characters one fetch of the strings covers (a multiple
+// of TILE: every 128-byte line of a string is then touched STILE / 16 times less often -- with one fetch per TILE columns the kernel read
 // 90 lines per 256-byte pair, 11.5 GB per million pairs at the L2's fabric side, and waited for them)
 // HAVE_CKPT: the forward sweep was the distance pass's (LevBits<.., CKPT>: fixed-length batches; it left the checkpoints of tiles of 16
 // columns and the state behind the last column in P.ckpt) -- phase F is skipped.
@@ -44,14 +47,34 @@ struct LevBitsTrace {
     using Q = typename W::Q;
     static constexpr uint32_t T0 = 64;                                   // iteration of column 1 (a multiple of 8, >= the 32 warm-up iterations)
     static constexpr uint32_t CK_WORDS = TRANS ? 5 : 2;                  // VP, VN (, PM', bottom PM', D0')
-    // per-lane string slot: a = PA pieces covering a-indices [a_lo, a_lo + 16 PA) -- the tile's bytes, the 32 before them (the window is
-    // rebuilt from those) and 12 more (the walk reads the twelve characters up to a[i - 1] at once); b = PB pieces from 16 bytes before the tile
+    // The strings of a string tile (STILE columns) live in REGISTERS: AD dwords of a -- a-indices [first, first + STILE + 48), first =
+    // STILE T + nlo - 44: the tile's bytes, the 32 in front of them (the window is rebuilt from those) and 12 more (the walk reads the twelve
+    // characters up to a[i - 1] at once) -- and PB pieces of b from 16 bytes in front of the tile.  Every column's bytes then sit at a
+    // compile-time register index (the tile's number q inside the string tile is a template constant).  a's pieces are fetched on the
+    // string's own 16-byte grid and pass through LDS once (BOUNCE bytes per lane, in the records' space) to land on `first`, which is per lane.
     static constexpr uint32_t PA = (44 + STILE + 15 + 15) / 16, PB = 1 + STILE / 16, RT = STILE / TILE;
-    static constexpr uint32_t SLOT = 16 * (PA + PB) + 4;                 // bytes per lane (an odd number of dwords)
+    static constexpr uint32_t AD = (STILE + 48) / 4, BD = 4 * PB, BOUNCE = 16 * PA + 4;
+    static_assert(15 + 4 * AD <= 16 * PA, "the pieces cover the registers' bytes");
+    // the walk's characters of ONE tile, per lane in LDS: XW dwords of a from first + TILE q, YW dwords of b from STILE T - 16 + TILE q
+    static constexpr uint32_t XW = (TILE + 48) / 4, YW = (TILE + 16) / 4;
+    static constexpr uint32_t WSLOT = 4 * (XW + YW) + (((XW + YW) % 2u) == 0u ? 4u : 0u);   // bytes per lane (an odd number of dwords)
     // records, [word][lane]: pre-column VP / VN of columns 0 .. TILE (TILE = the column behind the tile), D0 of columns 0 .. TILE - 1,
     // one word of bottom-diagonal D0 bits (bit c = column c), and for the transposition test the D0 of the column in front of the tile
     static constexpr uint32_t R_VP = 0, R_VN = TILE + 1, R_D0 = 2 * (TILE + 1), R_BOT = R_D0 + TILE, R_D0P = R_BOT + 1, R_WORDS = R_D0P + 1;
-    static constexpr uint32_t LDS_PER_WAVE = 64 * SLOT + 64 * 4 * R_WORDS;
+    static constexpr uint32_t REC_BYTES = 64 * 4 * R_WORDS > 64 * BOUNCE ? 64 * 4 * R_WORDS : 64 * BOUNCE;
+    static constexpr uint32_t LDS_PER_WAVE = 64 * WSLOT + REC_BYTES;
+    template <uint32_t N> using IC = std::integral_constant<uint32_t, N>;
+    // f(IC<q>) for the run-time q < RT: the tile bodies exist once per q
+    template <class F> static TA_HD inline void for_q(uint32_t q, F &&f) {
+        if (RT > 7u && q == 7u) f(IC<(RT > 7u ? 7u : 0u)>());
+        else if (RT > 6u && q == 6u) f(IC<(RT > 6u ? 6u : 0u)>());
+        else if (RT > 5u && q == 5u) f(IC<(RT > 5u ? 5u : 0u)>());
+        else if (RT > 4u && q == 4u) f(IC<(RT > 4u ? 4u : 0u)>());
+        else if (RT > 3u && q == 3u) f(IC<(RT > 3u ? 3u : 0u)>());
+        else if (RT > 2u && q == 2u) f(IC<(RT > 2u ? 2u : 0u)>());
+        else if (RT > 1u && q == 1u) f(IC<(RT > 1u ? 1u : 0u)>());
+        else f(IC<0u>());
+    }
 
     static TA_HD inline void run(const LevBitsTraceParams &P, uint32_t wave_index, uint8_t *lds) {
         const U32 lane = W::lane();
@@ -79,71 +102,42 @@ struct LevBitsTrace {
         const U32 dhi = W::splat(32u) - nlo;
         const uint32_t cols = W::wave_max(W::sel(some, m, W::splat(0)));
         const uint32_t tiles = (cols + (uint32_t)TILE - 1u) / (uint32_t)TILE;
-        uint8_t *rec = lds + 64u * SLOT;
-        const U32 slot = lane * SLOT, rlane = lane * 4u;
+        uint8_t *rec = lds + 64u * WSLOT;
+        const U32 wlane = lane * WSLOT, rlane = lane * 4u;
         auto raddr = [&](uint32_t w) { return rlane + w * 256u; };                       // a wave-uniform record word
         auto raddr_v = [&](const U32 &w) { return rlane + (w << 8); };                   // a per-lane one
         uint32_t *ck = P.ckpt + (uint64_t)wave_index * P.ckpt_tiles * (CK_WORDS * 64u);
 
         // ---- the strings of tile t (iterations [tb, tb + TILE), tb = T0 + TILE t; iteration tp slides a[tp - T0 + nlo] in and runs column
-        // tp - T0 + 1 with b[tp - T0]): pieces on the strings' own 16-byte grids, zeros outside the strings
-        U32 a_lo = W::splat(0);                                            // a-index of the slot's first byte (may be "negative": two's complement)
-        uint32_t b_lo = 0, loaded = 0xFFFFFFFFu;                           // b-index of the b slot's first byte; the string tile the slots hold
-        // fetch: the pieces of string tile T into registers (in flight until commit needs them -- phase B asks for tile T - 1 as soon as tile T
-        // sits in the slots: its latency hides behind RT tiles of work); commit: into the slots.  A piece outside its string is fetched from
-        // the string's first bytes instead (readable: TA_BLOB_SLACK) and zeroed on its way into the slot -- no branch around the loads, so
-        // they write the registers that wait for the commit.
-        auto a_piece = [&](uint32_t T, uint32_t p, U32 &q0) {             // a-index of piece p ("negative" in front of the string: huge, not below n)
-            q0 = (((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u) + 16u * p;
-            return some & (q0 < n);
-        };
-        auto b_piece = [&](uint32_t T, uint32_t p, uint32_t &q0) {        // (the piece in front of the string: zeros)
-            const bool front = T == 0u && p == 0u;
-            q0 = front ? 0u : (uint32_t)STILE * T - 16u + 16u * p;
-            return front ? W::bfalse() : (some & (W::splat(q0) < m));
-        };
-        auto fetch_strings = [&](uint32_t T, Q (&sa)[PA], Q (&sb)[PB]) {
-#pragma unroll
-            for (uint32_t p = 0; p < PA; p++) {
-                U32 q0;
-                const Bool ok = a_piece(T, p, q0);
-                sa[p] = W::gload16_all(W::ptr_add(xp, W::sel(ok, q0, W::splat(0))));
-            }
-#pragma unroll
-            for (uint32_t p = 0; p < PB; p++) {
-                uint32_t q0;
-                const Bool ok = b_piece(T, p, q0);
-                sb[p] = W::gload16_all(W::ptr_add(yp, W::sel(ok, W::splat(q0), W::splat(0))));
-            }
-        };
-        auto commit_strings = [&](uint32_t T, const Q (&sa)[PA], const Q (&sb)[PB]) {
-            loaded = T;
+        // tp - T0 + 1 with b[tp - T0]): zeros outside the strings.  A piece outside its string is fetched from the string's first bytes
+        // instead (readable: TA_BLOB_SLACK) and zeroed afterwards -- no branch around the loads.
+        U32 A[AD];                                                         // a-indices first + 4 d ..
+        U32 Bw[BD];                                                        // b-indices STILE T - 16 + 4 d ..
+        U32 first = W::splat(0);                                           // (may be "negative": two's complement)
+        auto load_strings = [&](uint32_t T) {
             const Bool all = (lane == lane);
-            a_lo = ((W::splat((uint32_t)STILE * T) + nlo) - 44u) & ~15u;
-            b_lo = (uint32_t)STILE * T - 16u;
+            first = (W::splat((uint32_t)STILE * T) + nlo) - 44u;
+            const U32 a_lo = first & ~15u, bounce = lane * BOUNCE;
 #pragma unroll
             for (uint32_t p = 0; p < PA; p++) {
-                U32 q0;
-                const Bool ok = a_piece(T, p, q0);
-                W::lds_store16(lds, slot + 16u * p, W::qkeep(sa[p], ok), all);
+                const U32 q0 = a_lo + 16u * p;                             // a-index of the piece ("negative" in front of the string: huge, not below n)
+                const Bool ok = some & (q0 < n);
+                W::lds_store16(rec, bounce + 16u * p, W::qkeep(W::gload16_all(W::ptr_add(xp, W::sel(ok, q0, W::splat(0)))), ok), all);
             }
 #pragma unroll
             for (uint32_t p = 0; p < PB; p++) {
-                uint32_t q0;
-                const Bool ok = b_piece(T, p, q0);
-                W::lds_store16(lds, slot + 16u * (PA + p), W::qkeep(sb[p], ok), all);
+                const bool front = T == 0u && p == 0u;                     // the piece in front of the string: zeros
+                const uint32_t q0 = front ? 0u : (uint32_t)STILE * T - 16u + 16u * p;
+                const Bool ok = front ? W::bfalse() : (some & (W::splat(q0) < m));
+                const Q piece = W::qkeep(W::gload16_all(W::ptr_add(yp, W::sel(ok, W::splat(q0), W::splat(0)))), ok);
+                Bw[4u * p] = W::qword(piece, 0); Bw[4u * p + 1u] = W::qword(piece, 1); Bw[4u * p + 2u] = W::qword(piece, 2); Bw[4u * p + 3u] = W::qword(piece, 3);
             }
             W::lds_wave_sync();
+            const U32 src = bounce + (first & 15u);
+#pragma unroll
+            for (uint32_t d = 0; d < AD; d++) A[d] = W::lds_read32u(rec, src + 4u * d);
+            W::lds_wave_sync();
         };
-        auto load_strings = [&](uint32_t T) {                               // (phase F: fetch and commit on the spot)
-            if (T == loaded) return;
-            Q fa[PA], fb[PB];
-            fetch_strings(T, fa, fb);
-            commit_strings(T, fa, fb);
-        };
-        // LDS addresses of the bytes of iteration tp (a) / of b[tp - T0]
-        auto a_addr = [&](uint32_t tp) { return slot + (((W::splat(tp - T0) + nlo) - a_lo)); };
-        auto b_addr = [&](uint32_t tp) { return slot + 16u * PA + ((tp - T0) - b_lo); };
 
         State st;
         auto init_state = [&]() {
@@ -155,41 +149,54 @@ struct LevBitsTrace {
             st.D0p[0] = W::splat(0xFFFFFFFFu); st.D0p[1] = W::splat(1);
             st.acc = W::splat(0);
         };
-        // the window's bytes in front of iteration tb: the 32 iterations before it slide in (the slot holds them)
-        auto rebuild_window = [&](uint32_t tb) {
+        // the window's bytes in front of tile q's first iteration: the 32 iterations before it slide in
+        auto rebuild_window = [&](auto qc) {
+            constexpr uint32_t q = decltype(qc)::value;
             const Bool all = (lane == lane);
 #pragma unroll
             for (int r = 0; r < 8; r++) st.AW[r] = W::splat(0);
-            for (uint32_t tp = tb - 32u; tp < tb; tp += 8u) {
-                const U32 pa = a_addr(tp);
-                const U32 x0 = W::lds_read32u(lds, pa) ^ 0x0C0C0C0Cu, x1 = W::lds_read32u(lds, pa + 4u) ^ 0x0C0C0C0Cu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {                            // a-bytes at first + 12 + TILE q + 8 k
+                // (opaque: what is computed from the registers must not be hoisted out of the tile loop, tile by tile for every q -- it was, at 450 live values)
+                const U32 x0 = W::opaque(A[3u + (uint32_t)TILE * q / 4u + 2u * k]) ^ 0x0C0C0C0Cu, x1 = W::opaque(A[4u + (uint32_t)TILE * q / 4u + 2u * k]) ^ 0x0C0C0C0Cu;
                 K::template step8<false, 0, false>(st, x0, x0, x0, all); K::template step8<false, 1, false>(st, x0, x0, x0, all);
                 K::template step8<false, 2, false>(st, x0, x0, x0, all); K::template step8<false, 3, false>(st, x0, x0, x0, all);
                 K::template step8<false, 4, false>(st, x1, x1, x1, all); K::template step8<false, 5, false>(st, x1, x1, x1, all);
                 K::template step8<false, 6, false>(st, x1, x1, x1, all); K::template step8<false, 7, false>(st, x1, x1, x1, all);
             }
         };
-        // the TILE columns of tile t; REC: every column's pre-state and D0 into the records
-        auto run_tile = [&](uint32_t t, auto rec_tag) {
+        // the TILE columns of tile q of the string tile; REC: every column's pre-state and D0 into the records
+        auto run_tile = [&](auto qc, auto rec_tag) {
+            constexpr uint32_t q = decltype(qc)::value;
             constexpr bool REC = decltype(rec_tag)::value;
             const Bool all = (lane == lane);
-            const uint32_t tb = T0 + (uint32_t)TILE * t;
             U32 bot = W::splat(0);
-            for (uint32_t c = 0; c < (uint32_t)TILE; c += 8u) {
-                const uint32_t tp = tb + c;
-                const U32 pa = a_addr(tp), pb = W::splat(0) + b_addr(tp);
-                const U32 r0 = W::lds_read32u(lds, pa), r1 = W::lds_read32u(lds, pa + 4u);
-                const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;
-                const U32 b0 = W::lds_read32u(lds, pb), b1 = W::lds_read32u(lds, pb + 4u);
 #define TA_TR_STEP(C_, bw, rw, xw)                                                                              \
                 if (REC) { W::lds_write32(rec, raddr(R_VP + c + C_), st.VP[0]); W::lds_write32(rec, raddr(R_VN + c + C_), st.VN[0]); } \
                 K::template step8<false, C_, true, REC>(st, bw, rw, xw, all);                                         \
                 if (REC) { W::lds_write32(rec, raddr(R_D0 + c + C_), st.rD0); bot = bot | W::shlv(st.rBot & 1u, W::splat(c + C_)); }
-                TA_TR_STEP(0, b0, r0, x0) TA_TR_STEP(1, b0, r0, x0) TA_TR_STEP(2, b0, r0, x0) TA_TR_STEP(3, b0, r0, x0)
-                TA_TR_STEP(4, b1, r1, x1) TA_TR_STEP(5, b1, r1, x1) TA_TR_STEP(6, b1, r1, x1) TA_TR_STEP(7, b1, r1, x1)
-#undef TA_TR_STEP
+#define TA_TR_BLOCK(CB_)                                                                                         \
+            if ((uint32_t)TILE > CB_) {                                                                          \
+                constexpr uint32_t c = CB_, ia = 11u + ((uint32_t)TILE * q + c) / 4u, ib = 4u + ((uint32_t)TILE * q + c) / 4u;   \
+                constexpr uint32_t ja = ia < AD - 1u ? ia : AD - 2u, jb = ib < BD - 1u ? ib : BD - 2u;                         \
+                const U32 r0 = W::opaque(A[ja]), r1 = W::opaque(A[ja + 1u]); /* a-bytes at first + 44 + TILE q + c */             \
+                const U32 x0 = r0 ^ 0x0C0C0C0Cu, x1 = r1 ^ 0x0C0C0C0Cu;                                           \
+                const U32 b0 = W::opaque(Bw[jb]), b1 = W::opaque(Bw[jb + 1u]); /* b-bytes at STILE T + TILE q + c */              \
+                TA_TR_STEP(0, b0, r0, x0) TA_TR_STEP(1, b0, r0, x0) TA_TR_STEP(2, b0, r0, x0) TA_TR_STEP(3, b0, r0, x0)          \
+                TA_TR_STEP(4, b1, r1, x1) TA_TR_STEP(5, b1, r1, x1) TA_TR_STEP(6, b1, r1, x1) TA_TR_STEP(7, b1, r1, x1)          \
             }
+            TA_TR_BLOCK(0u) TA_TR_BLOCK(8u) TA_TR_BLOCK(16u) TA_TR_BLOCK(24u)
+#undef TA_TR_BLOCK
+#undef TA_TR_STEP
             if (REC) W::lds_write32(rec, raddr(R_BOT), bot);
+        };
+        // the walk's characters of tile q into the lanes' slots
+        auto stage_walk = [&](auto qc) {
+            constexpr uint32_t q = decltype(qc)::value, d0 = (uint32_t)TILE * q / 4u;
+#pragma unroll
+            for (uint32_t w = 0; w < XW; w++) W::lds_write32(lds, wlane + 4u * w, A[d0 + w < AD ? d0 + w : AD - 1u]);
+#pragma unroll
+            for (uint32_t w = 0; w < YW; w++) W::lds_write32(lds, wlane + 4u * (XW + w), Bw[d0 + w < BD ? d0 + w : BD - 1u]);
         };
         auto save_ckpt = [&](uint32_t t) {
             uint32_t *c = ck + (uint64_t)t * (CK_WORDS * 64u);
@@ -218,10 +225,12 @@ struct LevBitsTrace {
             fetch_ckpt(tiles); take_ckpt();
         } else {
             for (uint32_t t = 0; t < tiles; t++) {
-                load_strings(t / RT);
-                if (t == 0) rebuild_window(T0);
-                save_ckpt(t);
-                run_tile(t, std::false_type());
+                if (t % RT == 0u) load_strings(t / RT);
+                for_q(t % RT, [&](auto qc) {
+                    if (t == 0u) rebuild_window(qc);
+                    save_ckpt(t);
+                    run_tile(qc, std::false_type());
+                });
             }
         }
         // ---- B: backwards, tile by tile
@@ -238,23 +247,25 @@ struct LevBitsTrace {
             cur = W::sel(on, e, cur);
         };
         U32 nxt_vp = st.VP[0], nxt_vn = st.VN[0];                          // the pre-state of the column behind the last tile
-        // string tiles from the last one down; the tile in front is in flight (registers) while this one's RT tiles are worked on.  It is
-        // asked for unconditionally (tile 0 asks for itself again), so that the loads write the registers the next commit reads, and inside
-        // the string tile's FIRST tile, behind the wait for that tile's checkpoint and in front of the request for the next one: every
-        // later wait finds loads that have had a whole tile's work to arrive.
-        Q sa[PA], sb[PB];
-        uint32_t T = tiles > 0u ? (tiles - 1u) / RT : 0u, t = tiles;
-        auto do_tile = [&](auto ahead_tag) {
-            t--;
-            const uint32_t tb = T0 + (uint32_t)TILE * t, j_lo = (uint32_t)TILE * t;      // the tile's columns: j_lo + 1 .. j_lo + TILE
+        uint32_t t = tiles;
+        auto do_tile = [&](uint32_t q) {                                    // tile t = RT T + q
+            const uint32_t j_lo = (uint32_t)TILE * t;                       // the tile's columns: j_lo + 1 .. j_lo + TILE
             take_ckpt();
-            if (decltype(ahead_tag)::value) fetch_strings(T > 0u ? T - 1u : 0u, sa, sb);
             if (t > 0u) fetch_ckpt(t - 1u);
-            rebuild_window(tb);
-            W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
-            W::lds_write32(rec, raddr(R_VP + TILE), nxt_vp); W::lds_write32(rec, raddr(R_VN + TILE), nxt_vn);
-            nxt_vp = st.VP[0]; nxt_vn = st.VN[0];                          // (this tile's first pre-state is the tile before's "behind")
-            run_tile(t, std::true_type());
+            for_q(q, [&](auto qc) {
+                rebuild_window(qc);
+                W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
+                W::lds_write32(rec, raddr(R_VP + TILE), nxt_vp); W::lds_write32(rec, raddr(R_VN + TILE), nxt_vn);
+                nxt_vp = st.VP[0]; nxt_vn = st.VN[0];                      // (this tile's first pre-state is the tile before's "behind")
+                stage_walk(qc);
+                run_tile(qc, std::true_type());
+            });
+            // the wait for the next checkpoint HERE, where only it and the walk before this one's stores are in flight: at the next tile's
+            // start it would also wait for the stores of the walk below (one counter for loads and stores, in order)
+#pragma unroll
+            for (uint32_t w = 0; w < CK_WORDS; w++) ckv[w] = W::opaque(ckv[w]);
+            const U32 xbase = first + (uint32_t)TILE * q;                   // a-index of the walk slot's first byte
+            const uint32_t ybase = j_lo - 16u;                              // b-index (mod 2^32)
             W::lds_wave_sync();
             Bool act = some & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u);
             if (P.runs_cap == 0u) act = W::bfalse();            // (a timing probe, TA_TRACE_SKIP_WALK=1: the recomputation without the walk -- no scripts)
@@ -267,7 +278,7 @@ struct LevBitsTrace {
                 // (lanes that are not walking read the tile's first record and the slot's first bytes: every address stays inside the block)
                 const U32 c = W::sel(act, (j - j_lo) - 1u, W::splat(0));   // column within the tile
                 const U32 bi = W::sel(act, (i + dhi) - j, W::splat(1));    // window bit of row i at column j: 0 .. 32
-                const U32 xo = slot + W::sel(act, (i - 1u) - a_lo, W::splat(12)), yo = slot + 16u * PA + W::sel(act, (j - 1u) - b_lo, W::splat(12));
+                const U32 xo = wlane + W::sel(act, (i - 1u) - xbase, W::splat(12)), yo = wlane + 4u * XW + W::sel(act, (j - 1u) - ybase, W::splat(12));
                 const U32 X2 = W::lds_read32u(lds, xo - 3u), X1 = W::lds_read32u(lds, xo - 7u), X0 = W::lds_read32u(lds, xo - 11u);    // x[i-4..i-1], x[i-8..i-5], x[i-12..i-9]
                 const U32 Y2 = W::lds_read32u(lds, yo - 3u), Y1 = W::lds_read32u(lds, yo - 7u), Y0 = W::lds_read32u(lds, yo - 11u);
                 const U32 d0w = W::lds_read32(rec, raddr_v(c + R_D0)), botw = W::lds_read32(rec, raddr(R_BOT));
@@ -321,13 +332,11 @@ struct LevBitsTrace {
                 act = act & (j > j_lo) & (j <= j_lo + (uint32_t)TILE) & (i > 0u) & (i <= n);
             }
         };
-        if (tiles > 0u) { fetch_ckpt(tiles - 1u); fetch_strings(T, sa, sb); }
-        while (t > 0u) {
-            commit_strings(T, sa, sb);
-            const uint32_t t_lo = T * RT;
-            do_tile(std::true_type());
-            while (t > t_lo) do_tile(std::false_type());
-            T = T > 0u ? T - 1u : 0u;
+        if (tiles > 0u) fetch_ckpt(tiles - 1u);
+        while (t > 0u) {                                                    // string tiles from the last one down
+            const uint32_t T = (t - 1u) / RT;
+            load_strings(T);
+            while (t > T * RT) { t--; do_tile(t - T * RT); }
         }
         // the borders: row 0 (j steps left) and column 0 (i steps up), each one run
         note(e_left, j, some & (i == 0u) & (j > 0u) & (j <= m));
