@@ -15,10 +15,10 @@ namespace ta {
 template <bool TRANS, int TILE, int STILE, bool HAVE_CKPT = false>
 __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P, ta_edit *edits, uint32_t *n_edits, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    LevBitsTrace<DevWave, TRANS, TILE, STILE, HAVE_CKPT>::run(P, blockIdx.x, lds);
+    uint32_t nr = 0;
+    LevBitsTrace<DevWave, TRANS, TILE, STILE, HAVE_CKPT>::run(P, blockIdx.x, lds, &nr);
     const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
-    if (pair >= P.n) return;
-    const uint32_t nr = P.n_runs[pair];                        // (this lane's own stores: program order)
+    if (pair >= P.n) return;                                   // (the run list below: this lane's own stores, program order)
     n_edits[pair] = nr;
     const uint32_t have = nr < P.runs_cap ? nr : P.runs_cap;
     const uint32_t *mine = P.runs + (uint64_t)pair * P.runs_cap;

@@ -76,7 +76,8 @@ struct LevBitsTrace {
         else f(IC<0u>());
     }
 
-    static TA_HD inline void run(const LevBitsTraceParams &P, uint32_t wave_index, uint8_t *lds) {
+    // (runs_out: the lane's run count, as stored to P.n_runs -- the caller's last step needs no reload)
+    static TA_HD inline void run(const LevBitsTraceParams &P, uint32_t wave_index, uint8_t *lds, U32 *runs_out = nullptr) {
         const U32 lane = W::lane();
         const U32 slot_idx = lane + wave_index * 64u;
         const Bool in_batch = slot_idx < P.n;
@@ -343,6 +344,7 @@ struct LevBitsTrace {
         note(e_up, i, some & (j == 0u) & (i > 0u) & (i <= n));
         note(W::splat(7), W::splat(0), some & (cur != 7u));                // close the last run
         W::store_u32(P.n_runs, pair, W::sel(some, nruns, W::splat(0)), in_batch);
+        if (runs_out) *runs_out = W::sel(some, nruns, W::splat(0));
     }
 
 };
