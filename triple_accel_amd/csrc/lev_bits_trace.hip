@@ -37,10 +37,11 @@ __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P
 }
 
 uint32_t lev_bits_trace_ckpt_words(bool trans) { return trans ? 5u : 2u; }
-// columns per checkpoint (TA_TRACE_TILE = 8 | 16 | 32) and per fill of the string slots (TA_TRACE_STILE = 32 | 64)
+// columns per checkpoint (TA_TRACE_TILE = 8 | 16 | 32) and per fetch of the strings (TA_TRACE_STILE = 32 | 64)
 uint32_t lev_bits_trace_tile() {
     if (const char *e = env_str("TA_TRACE_TILE")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) return (uint32_t)v; }
-    return 16u;                  // cfg2t, ms per million pairs at (TILE, STILE) = (8, 32) 2.12, (8, 64) 2.04, (16, 32) 2.04, (16, 64) 2.02, (32, 64) 2.31
+    return 16u;                  // cfg2t with the kernel's own sweep, ms per million pairs at (TILE, STILE) = (8, 32) 1.62, (8, 64) 1.50, (16, 32) 1.54, (16, 64) 1.48, (32, 64) 1.86
+                                 // (folded sweep: (16, 32) 1.29, (16, 64) 1.23; the round's first version: 2.12 / 2.04 / 2.04 / 2.02 / 2.31)
 }
 static uint32_t lev_bits_trace_stile(uint32_t tile) {
     uint32_t st = 64u;
