@@ -119,3 +119,76 @@ def test_shard_range_covers_everything():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+# ---- pair batches sharded across ranks (distances and tracebacks): slice arithmetic + the ragged gathers, the oracle as every rank's engine
+def _oracle_local_k_batch(a, b, k, costs):
+    import oracle_lib as O
+    c = (costs.mismatch_cost, costs.gap_cost, costs.start_gap_cost, costs.transpose_cost)
+    out = np.empty(len(a), dtype=np.int32)
+    for i in range(len(a)):
+        d = O.levenshtein_simd_k_with_opts(a[i], b[i], k, False, c)[0]
+        out[i] = -1 if d is None else d
+    return out
+
+
+_EDIT_CODE = {"Match": 0, "Mismatch": 1, "AGap": 2, "BGap": 3, "Transpose": 4}
+
+
+def _oracle_local_trace_batch(a, b, k, costs, cap):
+    import oracle_lib as O
+    c = (costs.mismatch_cost, costs.gap_cost, costs.start_gap_cost, costs.transpose_cost)
+    d, e, ne = np.empty(len(a), dtype=np.int32), np.zeros((len(a), cap, 2), dtype=np.int64), np.zeros(len(a), dtype=np.int32)
+    for i in range(len(a)):
+        wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, c)
+        d[i] = -1 if wd is None else wd
+        if wd is not None:
+            ne[i] = len(we)
+            for t, (name, cnt) in enumerate(we):
+                e[i, t] = (_EDIT_CODE.get(name, name) if isinstance(name, str) else int(name), cnt)
+    return d, e, ne
+
+
+def _pairs_worker(rank, world, port, a, b, k, costs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import triple_accel_amd as T
+        from triple_accel_amd import dist as D
+        c = T.EditCosts(*costs)
+        got = D.levenshtein_k_batch_sharded(a, b, k, c, local_batch=_oracle_local_k_batch)
+        lo, hi = D.shard_range(len(a), rank, world)
+        own = D.levenshtein_k_batch_sharded(a, b, k, c, gather=False, local_batch=_oracle_local_k_batch)
+        assert own.numel() == hi - lo and torch.equal(own, got[lo:hi])
+        d, e, ne = D.levenshtein_trace_batch_sharded(a, b, k, c, local_batch=_oracle_local_trace_batch)
+        q.put((rank, got.numpy().copy(), d.numpy().copy(), e.numpy().copy(), ne.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 37), (3, 2), (2, 0)])
+def test_sharded_pair_batches_equal_monolithic(world, n):
+    import datagen as Dg
+    g = Dg.rng(1234 + n)
+    a, b = [], []
+    for i in range(n):
+        x = bytes(g.integers(97, 101, int(g.integers(0, 40)), dtype=np.uint8))
+        a.append(x); b.append(Dg.mutate(g, x, 6, True) if i % 5 else bytes(g.integers(97, 101, 30, dtype=np.uint8)))
+    k, costs = 5, (1, 1, 0, 1)
+    import triple_accel_amd as T
+    want_d = _oracle_local_k_batch(a, b, k, T.EditCosts(*costs))
+    wd, we, wn = _oracle_local_trace_batch(a, b, k, T.EditCosts(*costs), 2 * k + 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_pairs_worker, args=(r, world, port, a, b, k, costs, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got, d, e, ne in outs:                     # the same whole-batch answer on every rank
+        assert np.array_equal(got, want_d) and np.array_equal(d, wd) and np.array_equal(ne, wn)
+        assert e.shape == we.shape and np.array_equal(e, we)

@@ -50,6 +50,18 @@ _WORKER = textwrap.dedent('''
     res = B.levenshtein_k_batch(B.Strings.from_fixed(a), B.Strings.from_fixed(b), 60)
     allr = TD.all_gather_results(res)
     assert torch.equal(allr, res)
+    # the sharded pair-batch entries on the HIP path: distances and tracebacks of a ragged batch, gathered as CUDA tensors
+    la, lb = [], []
+    for i in range(300):
+        x = Dg.rand_str(g, int(g.integers(0, 200)))
+        la.append(x); lb.append(Dg.mutate(g, x, 8, True) if i %% 4 else Dg.rand_str(g, 50))
+    d = TD.levenshtein_k_batch_sharded(la, lb, 10, T.RDAMERAU_COSTS)
+    td, te, tn = TD.levenshtein_trace_batch_sharded(la, lb, 10, T.RDAMERAU_COSTS)
+    assert d.is_cuda and te.is_cuda and te.shape == (300, 21, 2) and torch.equal(d, td)
+    scripts = B.edits_to_lists(te, tn)
+    for i in range(300):
+        wd, we = O.levenshtein_simd_k_with_opts(la[i], lb[i], 10, True, (1, 1, 0, 1))
+        assert (int(d[i]) == -1 and scripts[i] == []) if wd is None else (int(d[i]) == wd and scripts[i] == [tuple(e) for e in we]), i
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_OK " + json.dumps(out))

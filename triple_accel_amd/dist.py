@@ -1,7 +1,8 @@
 """Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
 
 The hot path shards without any data-path collective:
-  * pair batches: contiguous N/G pairs per rank; results stay on the rank (or are all-gathered on request);
+  * pair batches: contiguous N/G pairs per rank; results stay on the rank (or are all-gathered on request):
+    levenshtein_k_batch_sharded, levenshtein_trace_batch_sharded;
   * levenshtein_search over one big haystack: contiguous shards RESIDENT in HBM (never copied or re-uploaded); every
     rank publishes its last needle_len + unit_k + 2 bytes (one all-gather of that many bytes, on the device under RCCL)
     and searches [left context | its first halo bytes] as a tiny head buffer plus its shard in place; every rank emits
@@ -44,6 +45,55 @@ def all_gather_results(local, group=None):
     outs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad, group=group)
     return torch.cat([o[: int(c.item())] for o, c in zip(outs, counts)])
+
+
+def levenshtein_k_batch_sharded(a, b, k, costs=LEVENSHTEIN_COSTS, gather=True, group=None, local_batch=None):
+    """levenshtein_simd_k_with_opts over a pair batch sharded across the ranks (contiguous pairs per rank, NO data-path
+    collective).  `a`, `b`: the WHOLE batch as lists of bytes (the same on every rank: each takes its shard_range slice), or this rank's
+    own slice as batch.Strings already resident in HBM.  Returns int32 distances (-1 == None): of the whole batch in pair order on every
+    rank (`gather`: one ragged all-gather of 4 bytes per pair, the only exchange), or of the rank's slice (gather=False: the results stay
+    where they were computed).  `local_batch(a_list, b_list, k, costs) -> int32 array` replaces the HIP path (tests, gloo)."""
+    costs = _costs(costs)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if isinstance(a, (list, tuple)):
+        lo, hi = shard_range(len(a), rank, world)
+        a, b = a[lo:hi], b[lo:hi]
+    if local_batch is not None:
+        local = torch.from_numpy(np.ascontiguousarray(local_batch(a, b, k, costs), dtype=np.int32))
+    else:
+        from . import batch as B
+        sa = a if isinstance(a, B.Strings) else B.Strings.from_list(a)
+        sb = b if isinstance(b, B.Strings) else B.Strings.from_list(b)
+        local = B.levenshtein_k_batch(sa, sb, k, costs) if sa.n else torch.empty(0, dtype=torch.int32, device=sa.blob.device)
+    return all_gather_results(local, group) if gather else local
+
+
+def levenshtein_trace_batch_sharded(a, b, k, costs=LEVENSHTEIN_COSTS, gather=True, group=None, local_batch=None):
+    """levenshtein_simd_k_with_opts(.., trace_on = true, ..) over a pair batch sharded as levenshtein_k_batch_sharded: -> (distances,
+    edits (n, 2 k + 1, 2) int64, n_edits) -- every rank's records have the same `cap` = 2 k + 1 runs per pair (a script of cost <= k has
+    no more), so the gathered tensors are plain concatenations in pair order.  `local_batch(a_list, b_list, k, costs, cap)` ->
+    (int32 distances, int64 (n, cap, 2) edits, int32 n_edits) replaces the HIP path (tests, gloo)."""
+    costs = _costs(costs)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    cap = 2 * int(k) + 1
+    if isinstance(a, (list, tuple)):
+        lo, hi = shard_range(len(a), rank, world)
+        a, b = a[lo:hi], b[lo:hi]
+    if local_batch is not None:
+        d, e, ne = local_batch(a, b, k, costs, cap)
+        d, e, ne = torch.from_numpy(np.ascontiguousarray(d, dtype=np.int32)), torch.from_numpy(np.ascontiguousarray(e, dtype=np.int64)), torch.from_numpy(np.ascontiguousarray(ne, dtype=np.int32))
+    else:
+        from . import batch as B
+        sa = a if isinstance(a, B.Strings) else B.Strings.from_list(a)
+        sb = b if isinstance(b, B.Strings) else B.Strings.from_list(b)
+        if sa.n:
+            d, e, ne = B.levenshtein_trace_batch(sa, sb, k, costs, cap=cap)
+        else:
+            dev = sa.blob.device
+            d, e, ne = torch.empty(0, dtype=torch.int32, device=dev), torch.empty((0, cap, 2), dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
+    if not gather:
+        return d, e, ne
+    return all_gather_results(d, group), all_gather_results(e.reshape(-1), group).reshape(-1, cap, 2), all_gather_results(ne, group)
 
 
 _MATCH_DT = np.dtype([("start", "<u8"), ("end", "<u8"), ("k", "<u4"), ("pad_", "<u4")])
