@@ -29,7 +29,7 @@ while time.time() < t_end:
     alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
     costs = [(1, 1, 0, None), (1, 1, 0, 1)][int(g.integers(0, 2))]
     k = int(g.choice([0, 1, 3, 10, 20, 29, 30, 32]))
-    n = int(g.choice([1, 40, 64, 65, 700, 3000]))
+    n = int(g.choice([1, 40, 64, 65, 700, 3000, 5000]))            # (CSR batches of >= 4,096 pairs: length order)
     fixed = bool(g.random() < 0.6)
     if fixed:
         la = int(g.choice([1, 2, 7, 15, 16, 17, 63, 64, 65, 100, 128, 255, 256, 257, 500, 1100]))

@@ -223,6 +223,42 @@ def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
             assert (d2[i] == wd and l2[i] == we) if wd is not None else (d2[i] == 0xFFFFFFFF and l2[i] == []), i
 
 
+@pytest.mark.parametrize("trans,k", [(False, 32), (True, 12)])
+def test_trace_batch_csr_in_length_order(trans, k, monkeypatch):
+    """CSR batches of >= 4,096 pairs: the distance pass and the trace kernel take the pairs in length order (one list for both): the same
+    distances and scripts as in batch order (TA_NO_LENGTH_ORDER=1), a sample against the oracle -- lengths 0..300, both orientations,
+    None pairs and pairs outside the band anywhere in the order."""
+    import triple_accel_amd as T
+    from triple_accel_amd import batch as B
+    costs = (1, 1, 0, 1) if trans else (1, 1, 0, None)
+    g = Dg.rng(0x5EED + k)
+    a, b = [], []
+    for i in range(9000):
+        x = Dg.rand_str(g, int(g.integers(0, 300)))
+        t = i % 9
+        y = Dg.rand_str(g, int(g.integers(0, 300))) if t == 0 else Dg.mutate(g, x, int(g.integers(0, k + 3)), trans)
+        if t in (1, 2, 3):
+            x, y = y, x
+        a.append(x); b.append(y)
+    sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+    out, edits, ne = B.levenshtein_trace_batch(sa, sb, k, costs)
+    assert "lev_bits_trace_kernel" in T.last_kernel_name()
+    got_d, got_e = out.cpu().numpy().view(np.uint32), B.edits_to_lists(edits, ne)
+    monkeypatch.setenv("TA_NO_LENGTH_ORDER", "1")
+    out1, edits1, ne1 = B.levenshtein_trace_batch(sa, sb, k, costs)
+    monkeypatch.delenv("TA_NO_LENGTH_ORDER")
+    assert np.array_equal(got_d, out1.cpu().numpy().view(np.uint32)) and got_e == B.edits_to_lists(edits1, ne1)
+    n_some = 0
+    for i in range(0, len(a), 7):
+        wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+        if wd is None:
+            assert got_d[i] == 0xFFFFFFFF and got_e[i] == [], i
+        else:
+            n_some += 1
+            assert got_d[i] == wd and got_e[i] == we, (i, a[i], b[i], got_e[i], we)
+    assert n_some > 400
+
+
 def test_trace_batch_in_a_captured_graph():
     """ta_levenshtein_trace_batch synchronises nothing and fills nothing with memset nodes: the call (distance pass with checkpoints + the
     trace kernel; the DP route's two kernels for weighted costs) can be captured into a graph and replayed -- same scripts."""

@@ -44,6 +44,7 @@ struct LevBitsTraceParams {
     uint32_t *runs;              // [pair][runs_cap]: the runs of the script as the walk closes them -- LAST run first -- (edit type << 29) | count
     uint32_t runs_cap;           // >= 2 u + 2 (a script of cost <= u has at most 2 u + 1 runs) and >= the longest n + m where that is smaller
     uint32_t *n_runs;            // [pair]: runs of the script (0 for None)
+    const uint32_t *subset = nullptr;   // optional: the order in which the pairs are taken (lane l of wavefront w: pair subset[64 w + l]) -- CSR batches in length order
 };
 
 struct LevParams {

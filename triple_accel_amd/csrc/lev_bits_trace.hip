@@ -17,8 +17,9 @@ __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t nr = 0;
     LevBitsTrace<DevWave, TRANS, TILE, STILE, HAVE_CKPT>::run(P, blockIdx.x, lds, &nr);
-    const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
-    if (pair >= P.n) return;                                   // (the run list below: this lane's own stores, program order)
+    const uint32_t slot_idx = blockIdx.x * 64u + threadIdx.x;
+    if (slot_idx >= P.n) return;
+    const uint32_t pair = P.subset ? P.subset[slot_idx] : slot_idx;                                   // (the run list below: this lane's own stores, program order)
     n_edits[pair] = nr;
     const uint32_t have = nr < P.runs_cap ? nr : P.runs_cap;
     const uint32_t *mine = P.runs + (uint64_t)pair * P.runs_cap;

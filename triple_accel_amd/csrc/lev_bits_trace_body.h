@@ -81,7 +81,7 @@ struct LevBitsTrace {
         const U32 lane = W::lane();
         const U32 slot_idx = lane + wave_index * 64u;
         const Bool in_batch = slot_idx < P.n;
-        const U32 pair = W::sel(in_batch, slot_idx, W::splat(0));
+        const U32 pair = P.subset ? W::load_u32(P.subset, slot_idx, in_batch, 0u) : W::sel(in_batch, slot_idx, W::splat(0));
         Ptr xp, yp;
         U32 n, m;
         Bool swapped = W::bfalse();

@@ -1163,7 +1163,12 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
             const LevBitsPlan bp8 = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 3);
             const bool fold = fixed && bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE");
             const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
-            if (!fold && (rc = lev_pass(a, b, (uint32_t)n, nullptr, k, costs, max_len, out_dev, st))) return rc;
+            // CSR batches: both kernels run a wavefront to the longest of its 64 pairs -- the pairs are taken in length order (as
+            // ta_levenshtein_k_batch takes them), the same list for the distance pass and the trace kernel.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
+            const uint32_t *order = nullptr;
+            if (!fixed && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER") &&
+                (rc = order_pairs(a, b, (uint32_t)n, u, max_len, false, false, st, &order, nullptr))) return rc;
+            if (!fold && (rc = lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st))) return rc;
             // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
             uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
             Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
@@ -1172,6 +1177,7 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
             LevBitsTraceParams T;
             T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
             T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = env_int("TA_TRACE_SKIP_WALK") ? 0u : runs_cap; T.n_runs = (uint32_t *)ss.dev;
+            T.subset = order;
             if (fold) {
                 const bool sw = a->len > b->len;
                 LevParams P;
