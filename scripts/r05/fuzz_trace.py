@@ -18,14 +18,16 @@ print("seed", seed, flush=True)
 t_end, rounds, pairs, somes, kinds = time.time() + 60 * minutes, 0, 0, 0, {}
 while time.time() < t_end:
     rounds += 1
-    for sw in ("TA_TRACE_TILE", "TA_TRACE_STILE", "TA_TRACE_OWN_SWEEP"):
+    for sw in ("TA_TRACE_TILE", "TA_TRACE_STILE", "TA_TRACE_OWN_SWEEP", "TA_TRACE_CSR_OWN_SWEEP"):
         os.environ.pop(sw, None)
-    if g.random() < 0.4:
+    if g.random() < 0.3:
         os.environ["TA_TRACE_TILE"] = str(g.choice([8, 16, 32]))
     if g.random() < 0.5:
         os.environ["TA_TRACE_STILE"] = str(g.choice([32, 64]))
     if g.random() < 0.2:
         os.environ["TA_TRACE_OWN_SWEEP"] = "1"
+    if g.random() < 0.2:
+        os.environ["TA_TRACE_CSR_OWN_SWEEP"] = "1"
     alpha = [(1, 256), (97, 101), (0, 256), (12, 14), (33, 127)][int(g.integers(0, 5))]
     costs = [(1, 1, 0, None), (1, 1, 0, 1)][int(g.integers(0, 2))]
     k = int(g.choice([0, 1, 3, 10, 20, 29, 30, 32]))
@@ -68,7 +70,7 @@ while time.time() < t_end:
         ok = (gd[i] == 0xFFFFFFFF and ge[i] == []) if wd is None else (gd[i] == wd and ge[i] == [tuple(e) for e in we])
         pairs += 1; somes += wd is not None
         if not ok:
-            print("MISMATCH", dict(fixed=fixed, n=n, k=k, costs=costs, alpha=alpha, kernel=name, env={s: os.environ.get(s) for s in ("TA_TRACE_TILE", "TA_TRACE_STILE", "TA_TRACE_OWN_SWEEP")}))
+            print("MISMATCH", dict(fixed=fixed, n=n, k=k, costs=costs, alpha=alpha, kernel=name, env={s: os.environ.get(s) for s in ("TA_TRACE_TILE", "TA_TRACE_STILE", "TA_TRACE_OWN_SWEEP", "TA_TRACE_CSR_OWN_SWEEP")}))
             print("pair", i, a[i], b[i], gd[i], ge[i], wd, we)
             sys.exit(1)
     kinds[name] = kinds.get(name, 0) + 1

@@ -12,7 +12,7 @@ ROWS = [("cfg2", "cfg2 1M×256 B, k=32 (the headline)"), ("cfg4", "cfg4 1M×128 
         ("cfg2w_prefilter", "cfg2w with `TA_OPT_UNIT_PREFILTER` (random pairs: an option, not a headline)"), ("cfg2w_mutated_prefilter", "cfg2w with `TA_OPT_UNIT_PREFILTER` on mutated pairs (every pair survives the pre-pass)"),
         ("cfg4w", "cfg4w 1M×128 B, k=8, `EditCosts(2,2,1,Some(3))`"), ("cfg2l", "cfg2l 1M×256 B, k=32, `EditCosts(2,3,0,None)`"),
         ("cfg2s", "cfg2s 1M×256 B, k=32, `EditCosts(2,2,0,None)` = unit × 2"), ("cfg2t", "cfg2t 1M×256 B mutated pairs, k=32, `trace_on` for every pair (checkpoints + recomputation)"),
-        ("cfg2t_own_sweep", "the same with the trace kernel's own forward sweep (what CSR batches take; `TA_TRACE_OWN_SWEEP=1`: an A/B row)"),
+        ("cfg2t_own_sweep", "the same with the trace kernel's own forward sweep (`TA_TRACE_OWN_SWEEP=1`: an A/B row)"),
         ("cfg2t_dp", "cfg2t through the DP kernel's per-cell records (round 4's route, `TA_TRACE_NO_BITS=1`: an A/B row)"),
         ("cfg2_ragged", "cfg2 ragged: 1M pairs, lengths uniform on 32..256, k=32 (CSR)"), ("cfg2_dna", "cfg2 on DNA: 1M×256 B over A C G T, k=32"),
         ("cfg2_dna5", "cfg2 over A C G T N (5 symbols), k=32"), ("hsearch8", "hamming_search, 8 B needle over 1 GiB, k=2"), ("hsearch16", "hamming_search, 16 B needle over 1 GiB, k=4"),

@@ -37,8 +37,7 @@ extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, 
     if (tile == 116) {
         // tile 116 = tiles of 16 columns with the forward sweep done by the distance kernel's CKPT instantiation (fixed-length batches: the
         // launcher's route): rows = the shorter string -- the views swapped where a is the longer one -- the line form beyond one line per string
-        if (a_off || b_off) { free(lds); return 3; }
-        const bool sw = a_len > b_len;
+        const bool sw = !a_off && !b_off && a_len > b_len;       // (CSR batches: the kernel swaps pair by pair)
         const LevBitsPlan pl = lev_bits_make_plan(u, 1, 1, 0, has_t != 0, 1, max_len, 0, 0, 3);
         if (!pl.ok || !pl.s8) { free(lds); return 4; }
         std::vector<uint32_t> dist2(n, 0xDEADBEEFu);
@@ -48,7 +47,7 @@ extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, 
         L.mc = 1; L.gc = 1; L.sg = 0; L.tc = has_t ? 1 : 0;
         L.u = pl.u; L.o = 0; L.L = 1; L.PW = 64; L.lds_per_wave = pl.lds_per_wave; L.Tw = pl.Tw; L.ch = pl.ch;
         L.ckpt = ck.data(); L.ckpt_tiles = P.ckpt_tiles;
-        const bool line = max_len > 128;
+        const bool line = max_len > 128 && !a_off && !b_off;       // (the line form is the fixed-length batches')
         if (line) L.lds_per_wave = 64u * (52u + 36u); else L.tune |= 1u;
         uint8_t *lds2 = (uint8_t *)calloc((size_t)L.lds_per_wave + 64, 1);
         for (uint32_t w = 0; w < waves; w++) {

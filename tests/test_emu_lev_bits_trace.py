@@ -85,3 +85,23 @@ def test_trace_fixed_length_and_long(trans):
     _check(a2, b2, 20, trans, 16)
     _check(a2, b2, 20, trans, 8)
     _check(a2, b2, 20, trans, 32)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_trace_folded_sweep_on_csr_batches(trans):
+    """Tile 116 on CSR batches: the distance kernel's CKPT instantiation (chunk form, rows = the shorter string pair by pair) leaves the
+    checkpoints, the trace kernel's HAVE_CKPT instantiation starts with the walk -- ragged lengths inside a wavefront (capped blocks), both
+    orientations, None pairs, pairs outside the band, empty strings, strings over several chunks."""
+    g = Dg.rng(0x7D1 + int(trans))
+    for k in (3, 12, 30 if trans else 32):
+        a, b = [], []
+        for i in range(150):
+            n = int(g.integers(0, 330 if i % 11 == 0 else 140))
+            x = Dg.rand_str(g, n)
+            y = Dg.mutate(g, x, int(g.integers(0, k + 3)), trans) if i % 5 else Dg.rand_str(g, int(g.integers(0, 140)))
+            if i % 2:
+                x, y = y, x
+            a.append(x); b.append(y)
+        a[5], b[5] = b"", b""
+        a[6], b[6] = b"", b"ab"
+        assert _check(a, b, k, trans, 116) > 60

@@ -225,7 +225,8 @@ def test_trace_batch_checkpoint_kernel(trans, k, monkeypatch):
 
 @pytest.mark.parametrize("trans,k", [(False, 32), (True, 12)])
 def test_trace_batch_csr_in_length_order(trans, k, monkeypatch):
-    """CSR batches of >= 4,096 pairs: the distance pass and the trace kernel take the pairs in length order (one list for both): the same
+    """CSR batches: the distance pass is the forward sweep here too (rows = the shorter string pair by pair inside the kernel), and from
+    4,096 pairs on the distance pass and the trace kernel take the pairs in length order (one list for both): the same
     distances and scripts as in batch order (TA_NO_LENGTH_ORDER=1), a sample against the oracle -- lengths 0..300, both orientations,
     None pairs and pairs outside the band anywhere in the order."""
     import triple_accel_amd as T
@@ -244,10 +245,16 @@ def test_trace_batch_csr_in_length_order(trans, k, monkeypatch):
     out, edits, ne = B.levenshtein_trace_batch(sa, sb, k, costs)
     assert "lev_bits_trace_kernel" in T.last_kernel_name()
     got_d, got_e = out.cpu().numpy().view(np.uint32), B.edits_to_lists(edits, ne)
+    assert T.last_kernel_name().endswith("true>"), T.last_kernel_name()      # (the distance pass was the forward sweep: HAVE_CKPT)
     monkeypatch.setenv("TA_NO_LENGTH_ORDER", "1")
     out1, edits1, ne1 = B.levenshtein_trace_batch(sa, sb, k, costs)
     monkeypatch.delenv("TA_NO_LENGTH_ORDER")
     assert np.array_equal(got_d, out1.cpu().numpy().view(np.uint32)) and got_e == B.edits_to_lists(edits1, ne1)
+    monkeypatch.setenv("TA_TRACE_CSR_OWN_SWEEP", "1")                         # the trace kernel's own forward sweep: an A/B route
+    out2, edits2, ne2 = B.levenshtein_trace_batch(sa, sb, k, costs)
+    assert not T.last_kernel_name().endswith("true>")
+    monkeypatch.delenv("TA_TRACE_CSR_OWN_SWEEP")
+    assert np.array_equal(got_d, out2.cpu().numpy().view(np.uint32)) and got_e == B.edits_to_lists(edits2, ne2)
     n_some = 0
     for i in range(0, len(a), 7):
         wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)

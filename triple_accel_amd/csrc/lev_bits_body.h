@@ -44,7 +44,7 @@ namespace ta {
 // 39 VALU instructions per column instead of 48 (static form).
 // VLINE: the line form for batches whose pairs have their OWN geometry and alignment (CSR batches): every 128-byte line of memory that
 // holds bytes of a string is requested once, whole, by the pair's lane -- see run().
-// CKPT (stride-8 form, fixed-length batches, no subset list): the column state (VP, VN; with the transposition term PM', the bottom
+// CKPT (stride-8 form; fixed-length batches or CSR ones, with or without a subset list): the column state (VP, VN; with the transposition term PM', the bottom
 // diagonal's PM', D0') goes to P.ckpt in front of every 16th column and behind the last one -- the forward sweep of the checkpoint-and-
 // recompute traceback (lev_bits_trace_body.h) done by the distance pass itself.
 template <class W, int NA, bool TRANS, bool STATIC = false, bool LINE = false, bool S8 = false, bool EARLY = false, bool VLINE = false, bool CKPT = false>
@@ -217,6 +217,15 @@ struct LevBits {
         U32 alen, blen;
         W::load_str(P.a, pair, in_batch, aptr, alen);     // rows
         W::load_str(P.b, pair, in_batch, bptr, blen);     // columns
+        if constexpr (CKPT) {
+            // the checkpoints are the trace kernel's forward sweep (lev_bits_trace_body.h): rows = the SHORTER string, pair by pair (the
+            // distance is symmetric; fixed-length batches arrive with their views swapped by the launcher and no lane swaps here)
+            const Bool sw = alen > blen;
+            const Ptr tp_ = W::sel_ptr(sw, bptr, aptr);
+            bptr = W::sel_ptr(sw, aptr, bptr); aptr = tp_;
+            const U32 tl_ = W::sel(sw, blen, alen);
+            blen = W::sel(sw, alen, blen); alen = tl_;
+        }
         if constexpr (VLINE) {
             // The VLINE form runs ONE column count per pass: every event of the column loop is then wave-uniform (no capped blocks, the
             // way down taken once), only the rows' geometry and the alignments are per lane.  The launcher hands it batches ordered

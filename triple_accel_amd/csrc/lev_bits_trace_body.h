@@ -32,7 +32,7 @@ namespace ta {
 // TILE: columns per checkpoint / per set of records in LDS; STILE: columns whose characters one fetch of the strings covers (a multiple
 // of TILE: every 128-byte line of a string is then touched STILE / 16 times less often -- with one fetch per TILE columns the kernel read
 // 90 lines per 256-byte pair, 11.5 GB per million pairs at the L2's fabric side, and waited for them)
-// HAVE_CKPT: the forward sweep was the distance pass's (LevBits<.., CKPT>: fixed-length batches; it left the checkpoints of tiles of 16
+// HAVE_CKPT: the forward sweep was the distance pass's (LevBits<.., CKPT>, rows = the shorter string as here; it left the checkpoints of tiles of 16
 // columns and the state behind the last column in P.ckpt) -- phase F is skipped.
 template <class W, bool TRANS, int TILE = 16, int STILE = 64, bool HAVE_CKPT = false>
 struct LevBitsTrace {

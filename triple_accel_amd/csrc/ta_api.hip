@@ -1158,10 +1158,11 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
         if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len <= 0x7FFFFFF0ull && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
             // Fixed-length batches: the distance pass IS the forward sweep -- the stride-8 kernel's CKPT instantiation stores the column
             // state in front of every 16th column (rows = the shorter string: the views are swapped for it where a is the longer one; the
-            // distance is symmetric).  CSR batches (per-pair orientation) keep the trace kernel's own sweep.  TA_TRACE_OWN_SWEEP=1 pins that.
+            // distance is symmetric; CSR batches: pair by pair inside the kernel).  TA_TRACE_OWN_SWEEP=1 pins the trace kernel's own sweep
+            // (TA_TRACE_CSR_OWN_SWEEP=1: for CSR batches only, an A/B).
             const bool fixed = !a->off && !b->off;
             const LevBitsPlan bp8 = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 3);
-            const bool fold = fixed && bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE");
+            const bool fold = bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE") && (fixed || !env_int("TA_TRACE_CSR_OWN_SWEEP"));
             const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
             // CSR batches: both kernels run a wavefront to the longest of its 64 pairs -- the pairs are taken in length order (as
             // ta_levenshtein_k_batch takes them), the same list for the distance pass and the trace kernel.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
@@ -1179,10 +1180,10 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
             T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = env_int("TA_TRACE_SKIP_WALK") ? 0u : runs_cap; T.n_runs = (uint32_t *)ss.dev;
             T.subset = order;
             if (fold) {
-                const bool sw = a->len > b->len;
+                const bool sw = fixed && a->len > b->len;              // (CSR batches: the kernel swaps pair by pair)
                 LevParams P;
                 P.a = view_of(sw ? b : a); P.b = view_of(sw ? a : b);
-                P.subset = nullptr; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
+                P.subset = order; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
                 P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
                 P.u = bp8.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp8.lds_per_wave; P.Tw = bp8.Tw; P.ch = bp8.ch;
                 P.ckpt = (uint32_t *)cs.dev; P.ckpt_tiles = tiles;
