@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r06"
 ALPHABETS = {"dna": b"ACGT", "dna5": b"ACGTN", "protein": b"ACDEFGHIKLMNPQRSTVWY", "iupac": b"ACGTRYSWKMBDHVNU"}      # --dist values passed with alphabet=...
 
 
@@ -76,6 +76,14 @@ def parse_args():
     ap.add_argument("--unit-prefilter", action="store_true",
                     help="ta_set_option(TA_OPT_UNIT_PREFILTER): weighted batches (cfg2w / cfg4w / cfg2l) run the unit-cost pass with k' first and "
                          "price only its survivors -- same answers, data-dependent work; NOT a headline figure: config.unit_prefilter says so")
+    ap.add_argument("--no-all-configs", action="store_true",
+                    help="default run (cfg2, 1 GPU, random bytes) only: skip the four extra legs that time BASELINE.json's other configs "
+                         "(cfg4, cfg5 at 1 GiB, cfg3, cfg1 -- each its own bench.py process behind its own parity gate, fewer steps, with its own "
+                         "live counter passes) and report them as `all_configs` in the one JSON line")
+    ap.add_argument("--single-process", action="store_true",
+                    help="the multi-GPU split BEHIND the C ABI (ta_set_devices; csrc/ta_multi.hip): ONE process, host buffers in, the library's "
+                         "worker threads shard the batch / the haystack over --gpus devices (a box with fewer GPUs lists device 0 that many "
+                         "times).  Same JSON shape; `value` from the resident sharded handle, `end_to_end_ms` from the host-pointer entry")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed passes for this long BEFORE the W warm-up steps: the input set-up on the host leaves the GPU idle for "
                          "seconds and its clocks take longer than a handful of 0.4 ms passes to come back (0 = off)")
@@ -123,9 +131,145 @@ def host_cpu_facts():
         facts["model"] = None
     return facts
 
+def single_process(args):
+    """`bench.py --gpus N --single-process`: the multi-GPU split behind the C ABI (include/triple_accel_amd.h "the device set").  ONE process;
+    the strings live in host memory; the library's worker threads (one per device of the set) shard them.  `value` is measured on the
+    RESIDENT sharded handle (inputs in HBM when the clock starts, as the contract asks), `end_to_end_ms` on the host-pointer entry
+    (pinned staging + H2D + kernels + D2H over every device's own PCIe link)."""
+    import datagen as Dg
+    import oracle_lib as O
+    import triple_accel_amd as T
+    from triple_accel_amd import multi as M
+
+    N = max(1, args.gpus)
+    ndev = T.device_count()
+    assert ndev >= 1, "bench.py needs a GPU (the product has no CPU fallback)"
+    devices = [i % ndev for i in range(N)]
+    M.set_devices(devices)
+    wl = args.workload
+    strong = args.scaling == "strong"
+    LEV, RDAM = (1, 1, 0, None), (1, 1, 0, 1)
+    t_wall = time.perf_counter
+    if wl in ("cfg2", "cfg4", "cfg2w", "cfg4w"):
+        n_cfg, L, k, costs = {"cfg2": (1_000_000, 256, 32, LEV), "cfg4": (1_000_000, 128, 8, RDAM),
+                              "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3))}[wl]
+        n_cfg = args.pairs or n_cfg
+        n = n_cfg if strong else n_cfg * N
+        a, b = Dg.pairs_random(0x7A00 + 2, n, L)
+        # parity gate: a side batch of mutated pairs through the HOST entry (the fan-out, the chunked staging, the gather) ...
+        am, bm = Dg.pairs_mutated_fixed(0x5EED, 4096, L, (k // max(costs[0], costs[1])) or 1, swaps=costs[3] is not None)
+        want_m = O.levenshtein_k_batch(O.csr_from_fixed(am), O.csr_from_fixed(bm), k, costs)
+        os.environ.setdefault("TA_MULTI_MIN_PAIRS", "256")            # (TA_TUNING only: lets the 4,096-pair side batch reach every device)
+        assert np.array_equal(M.levenshtein_k_batch_host(am, bm, k, costs), want_m), "parity gate failed: host fan-out != oracle"
+        os.environ.pop("TA_MULTI_MIN_PAIRS", None)
+        S = M.ShardedPairs(a, b, N)
+        got = S.levenshtein_k(k, costs)                               # ... and the resident handle on the timed batch
+        ns = min(n, 4000)
+        assert np.array_equal(got[:ns], O.levenshtein_k_batch(O.csr_from_fixed(a[:ns]), O.csr_from_fixed(b[:ns]), k, costs)), "parity gate failed"
+        tail = slice(max(0, n - 1000), n)
+        assert np.array_equal(got[tail], O.levenshtein_k_batch(O.csr_from_fixed(a[tail]), O.csr_from_fixed(b[tail]), k, costs)), "parity gate failed (last shard)"
+        cells_total = O.band_cells(L, L, k, costs) * n
+        bytes_total = (2 * L + 4) * n
+        if args.prewarm_ms > 0:
+            t1 = t_wall()
+            while (t_wall() - t1) * 1e3 < args.prewarm_ms:
+                S.time_levenshtein_k(k, costs, steps=8)
+        S.time_levenshtein_k(k, costs, steps=max(1, args.warmup))
+        t0 = t_wall()
+        dev_ms = S.time_levenshtein_k(k, costs, steps=args.steps) / args.steps      # the slowest shard's device time (HIP events on its worker's stream)
+        elapsed = t_wall() - t0                                                     # dispatch to the workers + the passes + their synchronisation
+        ts = []
+        for _ in range(4):
+            t1 = t_wall()
+            M.levenshtein_k_batch_host(a, b, k, costs)
+            ts.append((t_wall() - t1) * 1e3)
+        e2e_ms = float(np.median(ts[1:]))
+        shards = S.n_shards
+        S.close()
+        desc, unit_name, units = "%s geometry: k=%d, %d random %dB pairs" % (wl, k, n, L), "pairs", n
+        parity_some = int((want_m != 0xFFFFFFFF).sum())
+    elif wl == "cfg5":
+        mib = args.pairs or 1024
+        size = (mib << 20) if strong else (mib << 20) * N
+        needle = Dg.random_bytes(Dg.rng(0x7A05), 32).tobytes()
+        k, costs = 16, LEV
+        g = Dg.rng(0x7A05)
+        hay_np = Dg.random_bytes(g, size)
+        for pos in range(1 << 16, hay_np.size - 100, 1 << 20):
+            mm = np.frombuffer(Dg.mutate(g, needle, 10), dtype=np.uint8)
+            hay_np[pos:pos + mm.size] = mm
+        H = M.ShardedHaystack(hay_np, overlap=4096, n_shards=N)
+        # parity: the sharded All-mode result's records inside every shard cut's neighbourhood and at the front, against the oracle run on
+        # those windows; Best == the fold over the All-mode hits
+        all_hits = [tuple(m) for m in H.levenshtein_search(needle, k, T.SearchType.All, costs)]
+        ns = min(size, 4 << 20)
+        want = O.levenshtein_search_naive_with_opts(needle, hay_np[:ns].tobytes(), k, O.ALL, costs, False)
+        assert [h for h in all_hits if h[1] <= ns] == [w for w in want if w[1] > 0], "parity gate failed: sharded search != oracle (front)"
+        parity_some = len(want)
+        for r in range(1, N):
+            cut = size * r // N
+            lo, hi = max(0, cut - (1 << 20) - 4096), min(size, cut + (1 << 20))
+            w = O.levenshtein_search_naive_with_opts(needle, hay_np[lo:hi].tobytes(), k, O.ALL, costs, False)
+            w = [(s0 + lo, e0 + lo, kk) for s0, e0, kk in w if e0 > 4096 or lo == 0]
+            gotw = [h for h in all_hits if lo + (4096 if lo else 0) < h[1] <= hi]
+            assert gotw == [x for x in w if x[1] > 0], "parity gate failed: sharded search != oracle across cut %d" % r
+            parity_some += len(w)
+        from triple_accel_amd import dist as TD
+        best = [tuple(m) for m in H.levenshtein_search(needle, k, T.SearchType.Best, costs)]
+        assert best == TD.fold_best(all_hits, k, True), "parity gate failed: Best != fold over the All-mode hits"
+        run = lambda: H.levenshtein_search(needle, k, T.SearchType.Best, costs)
+        t1 = t_wall()
+        while (t_wall() - t1) * 1e3 < args.prewarm_ms:
+            run()
+        for _ in range(args.warmup):
+            run()
+        t0 = t_wall()
+        for _ in range(args.steps):
+            run()
+        elapsed = t_wall() - t0
+        dev_ms = None
+        ts = []
+        hay_bytes = hay_np.tobytes() if size <= (2 << 30) else None
+        for _ in range(3 if hay_bytes else 0):
+            t1 = t_wall()
+            list(T.levenshtein_search_simd_with_opts(needle, hay_bytes, k, T.SearchType.Best, T.EditCosts(*costs), False))
+            ts.append((t_wall() - t1) * 1e3)
+        e2e_ms = float(np.median(ts[1:])) if ts else None
+        shards = H.n_shards
+        H.close()
+        cells_total, bytes_total = 32 * size, size
+        desc, unit_name, units = "levenshtein_search 32B needle over %d MiB (%d shards), k=16, Best" % (size >> 20, N), "haystack bytes", size
+    else:
+        sys.exit("bench.py --single-process: workloads cfg2, cfg4, cfg2w, cfg4w, cfg5")
+    value = cells_total * args.steps / elapsed / 1e9
+    ms_step = elapsed / args.steps * 1e3
+    achieved = bytes_total / ((dev_ms if dev_ms else ms_step) / 1e3) / 1e9
+    line = {
+        "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
+        "value": value, "unit": "GCUPS", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "u32 bit-vectors, 1 bit per band cell" if wl in ("cfg2", "cfg4") else "u32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (wl, desc), "units_total": units, "unit": unit_name, "units_per_gpu": units // N,
+                   "parallelism": "single process: ta_set_devices(%s), one worker thread + stream per entry, contiguous shards, no collective "
+                                  "(host gather)" % devices, "devices": devices, "visible_devices": ndev, "shards": shards},
+        "end_to_end_ms": e2e_ms,
+        "end_to_end_note": "host strings in, answers out through the host-pointer entry (pinned staging ring + H2D + kernels + D2H on every device "
+                           "of the set); never the headline",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * len(set(devices)), "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK_GBS * len(set(devices))), "traffic": None,
+                     "device_ms_per_pass": dev_ms, "algorithmic_bytes_per_pass": bytes_total,
+                     "note": "aggregate over the distinct devices of the set; the counters are collected by the one-device run"},
+        "cpu_baseline": None,
+        "timed_region": "%d passes back to back on every worker's stream, wall clock around dispatch + passes + synchronisation" % args.steps,
+        "parity_checked_some": parity_some, "single_process": True,
+    }
+    print(json.dumps(line))
+
 
 def main():
     args = parse_args()
+    if args.single_process:
+        return single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -326,7 +470,7 @@ def main():
                 got = out[:ns].cpu().numpy().view(np.uint32)
                 want = oracle(0, ns, cores)
                 assert np.array_equal(got, want), "parity gate failed: HIP path != oracle"
-                extra_t["parity_some"] = some + int((want != 0xFFFFFFFF).sum())
+                extra_t["parity_some"] = some + int((want != 0xFFFFFFFF).sum())      # (cfg1 / cfg3: every answer is a number)
                 extra_t["parity_side"] = side_n
                 if wl == "cfg2t":                           # the scripts, edit for edit, against the scalar traceback; their bytes
                     scripts = B.edits_to_lists(ed[:600], ne[:600])
@@ -442,6 +586,7 @@ def main():
                 allhits = B.levenshtein_search_dev(needle, hay, k, costs)              # All-mode hits of this rank's shard
                 got = [tuple(int(v) for v in r) for r in allhits if r[1] <= ns]
                 assert got == [w for w in want if w[1] > 0], "parity gate failed: HIP search != oracle"
+                extra_t["parity_some"] = len(got)                   # matches compared record for record
                 if world == 1:
                     want_best = TD.fold_best(allhits, k, True)
                     got_best = [tuple(int(v) for v in m) for m in holder["best"]] if dist_on else holder["best"]
@@ -466,8 +611,8 @@ def main():
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
                 return float(np.median(ts[1:]))
-            return run, hay_np.size, parity, {"hay_np": hay_np, "cells_total": cells_unit * hay_np.size, "bytes_total": bytes_unit * hay_np.size,
-                                              "end_to_end": end_to_end}
+            extra_t = {"hay_np": hay_np, "cells_total": cells_unit * hay_np.size, "bytes_total": bytes_unit * hay_np.size, "end_to_end": end_to_end}
+            return run, hay_np.size, parity, extra_t
 
     # ------------------------------------------------------------------ timing helpers
     def barrier():
@@ -822,6 +967,41 @@ def main():
         # so the gate also runs a side batch of mutated pairs of the same geometry through the same entry point (parity_side_batch)
         "parity_checked_some": parity_some, "parity_side_batch": parity_side,
     }
+    # ------------------------------------------------------------------ BASELINE.json's other configs, in the same driver run
+    # (four of five configs were builder-run claims.)  The default invocation keeps cfg2 as the headline -- everything above --
+    # and then times cfg4, cfg5 (1 GiB), cfg3 and cfg1 each in its own bench.py process: its own parity gate, fewer steps, its own live
+    # counter passes.  Their figures ride in `all_configs`; a leg that fails reports its error and the line is printed regardless.
+    if wl == "cfg2" and world == 1 and not dist_on and args.dist == "random" and not args.no_all_configs and not args.no_pmc and \
+            not args.early_out and not args.unit_prefilter and not args.pairs and not under_profiler:
+        rows = [{"workload": line["config"]["workload"], "ms_per_step": line["ms_per_step"], "value": value, "unit": "GCUPS",
+                 "roofline_frac": achieved / HBM_PEAK_GBS, "cycles_per_valu_inst": (valu_issue or {}).get("cycles_per_valu_inst_per_simd"),
+                 "traffic_ratio": (traffic / extra["bytes_total"]) if traffic else None, "kernel_name": kernel_name, "steps": args.steps,
+                 "parity_checked_some": parity_some}]
+        legs = [("cfg4", 20), ("cfg5", 10), ("cfg3", 3), ("cfg1", 100)]
+        t_legs = time.perf_counter()
+        for leg, leg_steps in legs:
+            row = {"workload": leg}
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", leg, "--steps", str(leg_steps), "--warmup", "2",
+                                    "--no-cpu", "--no-all-configs", "--prewarm-ms", "150"], capture_output=True, text=True, timeout=420)
+                js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not js:
+                    raise RuntimeError("rc %d: %s" % (r.returncode, r.stderr[-300:]))
+                d = json.loads(js[-1])
+                rf = d["roofline"]
+                row = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                       "roofline_frac": rf["frac"], "cycles_per_valu_inst": (rf.get("valu_issue") or {}).get("cycles_per_valu_inst_per_simd"),
+                       "traffic_ratio": (rf["traffic"] / rf["algorithmic_bytes_per_pass"]) if rf.get("traffic") else None,
+                       "kernel_name": rf.get("kernel_name"), "steps": d["steps"], "device_ms_per_pass": rf.get("device_ms_per_pass"),
+                       "parity_checked_some": d.get("parity_checked_some"), "end_to_end_ms": d.get("end_to_end_ms")}
+                if leg == "cfg1":
+                    row["note"] = ("20 MB batch re-read every pass: resident in the 256 MB Infinity Cache and launch-bound -- roofline_frac is a "
+                                   "cache-side figure here, not an HBM one")
+            except Exception as e:
+                row["error"] = "%s: %s" % (type(e).__name__, e)
+            rows.append(row)
+        line["all_configs"] = rows
+        line["all_configs_seconds"] = round(time.perf_counter() - t_legs, 1)
     print(json.dumps(line))
     if dist_on:
         dist.destroy_process_group()

@@ -272,6 +272,59 @@ int ta_queue_push(ta_queue *q, const uint8_t *a, size_t a_len, const uint8_t *b,
 int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n);
 void ta_queue_destroy(ta_queue *q);
 
+/* ---- the device set: the multi-GPU split behind this boundary ----------------------------------------------------------
+ * BASELINE.json north_star: "large batches of independent string pairs -- and for levenshtein_search the haystack itself -- are
+ * partitioned across the 8 GPUs of one node", for callers that stay on the reference's calling convention: host slices, one process
+ * (src/levenshtein.rs:714-720, 1911-1918, 2508-2511; src/hamming.rs:454-475).  The library keeps one worker thread per entry of the
+ * device set (hipSetDevice, its own stream, pinned staging ring and scratch).  Pairs shard as contiguous ranges, a haystack as contiguous
+ * byte ranges behind needle_len + unit_k + 2 bytes of left context (Levenshtein) / in front of needle_len - 1 bytes of overlap (Hamming);
+ * there is no device-to-device traffic: results return over each device's own PCIe link and are concatenated in shard order.
+ *   ta_set_devices(ids, n): the set (NULL / 0: every visible device, also the default).  An id may appear more than once -- that many
+ *   workers share the device (how a one-GPU box exercises the N-way logic).  Not to be called while other calls are in flight; resident
+ *   handles created before keep the workers they were created on.
+ * What fans out when the set has more than one entry: the *_host batch entries below, ta_queue_flush (and through it the bindings'
+ * levenshtein_simd_k_with_opts_many), and the host search entries ta_levenshtein_search_simd_with_opts (unanchored) /
+ * ta_hamming_search_simd_with_opts / ta_hamming_search_naive_with_opts for haystacks of >= 8 MiB (>= 4 MiB per device used).
+ * Results are identical to the one-device path's, bit for bit and in the same order. */
+int ta_set_devices(const int *devices, size_t n);
+int ta_get_devices(int *out, size_t cap, size_t *n_out);
+
+/* Batches whose strings live in HOST memory (ta_strings with host pointers: CSR offsets or the strided form): N x
+ * levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) / levenshtein_exp_with_opts(a_i, b_i, false, costs) / hamming(a_i, b_i)
+ * -> out[i] (host; TA_NONE = None / a length mismatch).  Every device of the set takes a contiguous slice of the pairs (no device gets
+ * fewer than 4,096) and works through it in chunks of <= 64 MiB of strings: staged through pinned memory, uploaded, answered by the
+ * batch entry of the same name, the answers downloaded -- upload and kernels of consecutive chunks overlap.  Synchronous. */
+int ta_levenshtein_k_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n, uint32_t k,
+                                const ta_edit_costs *costs, uint32_t *out_host);
+int ta_levenshtein_exp_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n,
+                                  const ta_edit_costs *costs, uint32_t *out_host);
+int ta_hamming_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n, uint32_t *out_host);
+
+/* A pair batch uploaded ONCE and kept resident, sharded over the first n_shards devices of the set (0: as the *_host entries choose);
+ * every later call runs the shards side by side and downloads 4 bytes per pair.  ta_sharded_pairs_time_levenshtein_k: `steps` passes back
+ * to back with the answers left on the devices; *device_ms = the slowest shard's device time (HIP events on its worker's stream). */
+typedef struct ta_sharded_pairs ta_sharded_pairs;
+int ta_sharded_pairs_upload(const ta_strings *a_host, const ta_strings *b_host, size_t n, size_t n_shards, ta_sharded_pairs **out);
+int ta_sharded_pairs_levenshtein_k(ta_sharded_pairs *s, uint32_t k, const ta_edit_costs *costs, uint32_t *out_host);
+int ta_sharded_pairs_levenshtein_exp(ta_sharded_pairs *s, const ta_edit_costs *costs, uint32_t *out_host);
+int ta_sharded_pairs_hamming(ta_sharded_pairs *s, uint32_t *out_host);
+int ta_sharded_pairs_time_levenshtein_k(ta_sharded_pairs *s, uint32_t k, const ta_edit_costs *costs, int steps, float *device_ms);
+int ta_sharded_pairs_shards(const ta_sharded_pairs *s, size_t *n_shards, size_t *n_pairs);
+void ta_sharded_pairs_free(ta_sharded_pairs *s);
+
+/* A haystack uploaded ONCE and kept resident as contiguous shards (BASELINE config 5: one shard per GPU), each with `overlap` bytes of its
+ * neighbours on either side: every search with needle_len + unit_k + 2 <= overlap (Levenshtein) / needle_len - 1 <= overlap (Hamming) runs
+ * on the resident bytes -- TA_ERR_ARG beyond.  The results are those of ta_levenshtein_search_simd_with_opts (unanchored) /
+ * ta_hamming_search_simd_with_opts over the whole haystack: library-allocated (ta_free). */
+typedef struct ta_sharded_haystack ta_sharded_haystack;
+int ta_sharded_haystack_upload(const uint8_t *haystack, size_t len, size_t overlap, size_t n_shards, ta_sharded_haystack **out);
+int ta_sharded_haystack_levenshtein_search(ta_sharded_haystack *h, const uint8_t *needle, size_t needle_len, uint32_t k, int search_type,
+                                           const ta_edit_costs *costs, ta_match **out, size_t *n_out);
+int ta_sharded_haystack_hamming_search(ta_sharded_haystack *h, const uint8_t *needle, size_t needle_len, uint32_t k, int search_type,
+                                       ta_match **out, size_t *n_out);
+int ta_sharded_haystack_shards(const ta_sharded_haystack *h, size_t *n_shards, size_t *len);
+void ta_sharded_haystack_free(ta_sharded_haystack *h);
+
 /* All-mode hits of one haystack shard resident in HBM (levenshtein_search_simd_with_opts with
  * SearchType::All; the order-dependent Best fold is a sequential host pass, ta_search_fold_best).
  * `base` is added to start/end (global offset of this shard inside a larger haystack);

@@ -24,6 +24,12 @@ ABI_SYMBOLS = [
     "ta_hamming_search", "ta_hamming_search_naive_with_opts", "ta_free", "ta_thread_release", "ta_levenshtein_k_batch", "ta_levenshtein_exp_batch", "ta_hamming_batch",
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
     "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted", "ta_levenshtein_search_resume",
+    # the device set (ta_multi.hip)
+    "ta_set_devices", "ta_get_devices", "ta_levenshtein_k_batch_host", "ta_levenshtein_exp_batch_host", "ta_hamming_batch_host",
+    "ta_sharded_pairs_upload", "ta_sharded_pairs_levenshtein_k", "ta_sharded_pairs_levenshtein_exp", "ta_sharded_pairs_hamming",
+    "ta_sharded_pairs_time_levenshtein_k", "ta_sharded_pairs_shards", "ta_sharded_pairs_free",
+    "ta_sharded_haystack_upload", "ta_sharded_haystack_levenshtein_search", "ta_sharded_haystack_hamming_search",
+    "ta_sharded_haystack_shards", "ta_sharded_haystack_free",
 ]
 
 
@@ -141,6 +147,24 @@ def lib():
     sig("ta_levenshtein_search_best_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, C.c_uint64, C.c_uint64,
                                                 C.c_void_p, sz, C.POINTER(C.c_uint64), mpp, szp, C.c_void_p])
     sig("ta_search_best_hits_dev", i32, [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(MatchC)), C.POINTER(sz), C.c_void_p])
+    vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+    sig("ta_set_devices", i32, [C.POINTER(C.c_int), sz])
+    sig("ta_get_devices", i32, [C.POINTER(C.c_int), sz, szp])
+    sig("ta_levenshtein_k_batch_host", i32, [sp, sp, sz, u32, cp, vp])
+    sig("ta_levenshtein_exp_batch_host", i32, [sp, sp, sz, cp, vp])
+    sig("ta_hamming_batch_host", i32, [sp, sp, sz, vp])
+    sig("ta_sharded_pairs_upload", i32, [sp, sp, sz, sz, vpp])
+    sig("ta_sharded_pairs_levenshtein_k", i32, [vp, u32, cp, vp])
+    sig("ta_sharded_pairs_levenshtein_exp", i32, [vp, cp, vp])
+    sig("ta_sharded_pairs_hamming", i32, [vp, vp])
+    sig("ta_sharded_pairs_time_levenshtein_k", i32, [vp, u32, cp, i32, C.POINTER(C.c_float)])
+    sig("ta_sharded_pairs_shards", i32, [vp, szp, szp])
+    sig("ta_sharded_pairs_free", None, [vp])
+    sig("ta_sharded_haystack_upload", i32, [vp, sz, sz, sz, vpp])
+    sig("ta_sharded_haystack_levenshtein_search", i32, [vp, u8p, sz, u32, i32, cp, mpp, szp])
+    sig("ta_sharded_haystack_hamming_search", i32, [vp, u8p, sz, u32, i32, mpp, szp])
+    sig("ta_sharded_haystack_shards", i32, [vp, szp, szp])
+    sig("ta_sharded_haystack_free", None, [vp])
     _lib = L
     return L
 

@@ -216,7 +216,7 @@ struct LevBitsTrace {
         };
         auto take_ckpt = [&]() {
             st.VP[0] = ckv[0]; st.VN[0] = ckv[1];
-            if (TRANS) { st.PMp[0] = ckv[2]; st.PMp[1] = ckv[3]; st.D0p[0] = ckv[4]; }
+            if constexpr (TRANS) { st.PMp[0] = ckv[2]; st.PMp[1] = ckv[3]; st.D0p[0] = ckv[4]; }
         };
 
         // ---- F: forwards, a checkpoint in front of every tile (HAVE_CKPT: the distance pass did it; the state behind the last tile is its

@@ -798,6 +798,15 @@ int ta_queue_flush(ta_queue *q, const uint32_t **results, size_t *n_out) {
     return rc;
 }
 static int queue_flush_impl(ta_queue *q, const uint32_t **results, size_t n) {
+    // more than one device in the set and enough pairs for more than one of them: contiguous slices of the queue, one per device, each
+    // uploaded through its worker's pinned ring and answered on its own GPU (ta_multi.hip)
+    if (multi_pair_shards(n) > 1) {
+        const ta_strings A = {q->blob[0].data(), q->off[0].data(), 0, 0, 0}, B = {q->blob[1].data(), q->off[1].data(), 0, 0, 0};
+        int rc = ta_levenshtein_k_batch_host(&A, &B, n, q->k, &q->costs, q->results.data());
+        if (rc) return rc;
+        *results = q->results.data();
+        return TA_OK;
+    }
     auto pad = [](size_t x) { return (x + TA_BLOB_SLACK + 255) & ~(size_t)255; };
     const size_t sa = pad(q->blob[0].size()), sb = pad(q->blob[1].size()), so = pad((n + 1) * 8), sr = pad(n * 4);
     const size_t need = sa + sb + 2 * so + sr;

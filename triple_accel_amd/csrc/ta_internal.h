@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/triple_accel_amd.h"
 #include "lev_band_body.h"
@@ -191,5 +192,17 @@ hipError_t lev_search_wave_launch(const SearchParams &P, bool trans, bool best, 
                                   hipStream_t s);
 hipError_t search_report_copy_launch(const unsigned long long *count, const uint32_t *nul_flag, const ta_match *hits, uint64_t cap, uint8_t *box, hipStream_t s);
 hipError_t hamming_search_launch(const SearchParams &P, hipStream_t s, uint32_t *nul_flag = nullptr, bool *nul_done = nullptr);
+
+// ta_multi.hip: the device set (one worker thread per entry).  multi_search_shards / multi_pair_shards: over how many of them a host
+// haystack / a host batch of that size is spread (1: the calling thread's own device path).  The search forms return the All-mode hits
+// sorted by end (best: only those with each shard's smallest k -- all the Best fold can keep), without the end == 0 match.
+size_t multi_search_shards(size_t haystack_len);
+size_t multi_pair_shards(size_t n);
+int multi_levenshtein_search_host(const uint8_t *needle, size_t n, const uint8_t *hay, size_t h, uint32_t k, bool best, const ta_edit_costs *costs,
+                                  std::vector<ta_match> &hits);
+int multi_hamming_search_host(const uint8_t *needle, size_t n, const uint8_t *hay, size_t h, uint32_t k, bool check_nul, std::vector<ta_match> &hits);
+// ta_hamming_search_dev under the scalar routine's contract (NUL bytes are fine, src/hamming.rs:96-146)
+int hamming_search_dev_nocheck(const uint8_t *needle_host, size_t needle_len, const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                               uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream);
 
 }  // namespace ta

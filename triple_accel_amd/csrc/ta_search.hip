@@ -327,6 +327,13 @@ static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len
     return TA_OK;
 }
 
+namespace ta {
+int hamming_search_dev_nocheck(const uint8_t *needle_host, size_t needle_len, const uint8_t *haystack_dev, size_t haystack_len, uint32_t k,
+                               uint64_t base, ta_match *hits_dev, size_t cap, uint64_t *count_host, void *stream) {
+    return hamming_search_dev_impl(needle_host, needle_len, haystack_dev, haystack_len, k, base, hits_dev, cap, count_host, stream, false);
+}
+}  // namespace ta
+
 extern "C" {
 
 int ta_hamming_search_dev(const uint8_t *needle_host, size_t needle_len,
@@ -502,7 +509,15 @@ int ta_levenshtein_search_simd_with_opts(const uint8_t *needle, size_t needle_le
     }
     if (ta_edit_costs_check_search(costs) != TA_OK) return TA_ERR_BAD_COSTS;   // :1965
     std::vector<ta_match> hits;
-    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
+    int rc;
+    // a big haystack and more than one device in the set (ta_set_devices; default: every visible one): contiguous shards, one per device,
+    // each behind needle_len + unit_k + 2 bytes of left context, uploaded and searched side by side (ta_multi.hip).  An anchored search only
+    // reads the haystack's first needle_len + unit_k bytes: one device.
+    if (!anchored && needle_len <= 65535 && multi_search_shards(haystack_len) > 1) {
+        if (!device_ready()) return TA_ERR_HIP;
+        rc = multi_levenshtein_search_host(needle, needle_len, haystack, haystack_len, k, search_type == TA_SEARCH_BEST, costs, hits);
+    } else
+    rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         if (haystack_len == 0) { *cnt = 0; return (int)TA_OK; }
         return ta_levenshtein_search_dev(needle, needle_len, hd, haystack_len, k, costs, anchored, 0, 0, od, cap, cnt, st);
     }, g_resume_upto);
@@ -648,7 +663,12 @@ int ta_hamming_search_simd_with_opts(const uint8_t *needle, size_t needle_len,
     if (needle_len > haystack_len) return TA_OK;                                // src/hamming.rs:455-457
     if (needle_len == 0) return TA_OK;                                          // :459-461
     std::vector<ta_match> hits;
-    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
+    int rc;
+    if (multi_search_shards(haystack_len) > 1) {                                // the windows that start in a shard: its bytes + needle_len - 1 more
+        if (!device_ready()) return TA_ERR_HIP;
+        rc = multi_hamming_search_host(needle, needle_len, haystack, haystack_len, k, true, hits);
+    } else
+    rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         return ta_hamming_search_dev(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, st);
     });
     if (rc) return rc;
@@ -673,7 +693,12 @@ int ta_hamming_search_naive_with_opts(const uint8_t *needle, size_t needle_len,
         for (size_t i = 0; i <= haystack_len; i++) hits.push_back(ta_match{i, i, 0u, 0u});
         return give(hits, out, n_out);
     }
-    int rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
+    int rc;
+    if (multi_search_shards(haystack_len) > 1) {
+        if (!device_ready()) return TA_ERR_HIP;
+        rc = multi_hamming_search_host(needle, needle_len, haystack, haystack_len, k, false, hits);
+    } else
+    rc = run_search_host(haystack, haystack_len, hits, [&](const uint8_t *hd, ta_match *od, size_t cap, uint64_t *cnt, hipStream_t st) {
         return hamming_search_dev_impl(needle, needle_len, hd, haystack_len, k, 0, od, cap, cnt, st, false);
     });
     if (rc) return rc;
