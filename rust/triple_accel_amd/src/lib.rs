@@ -73,6 +73,13 @@ mod ffi {
         pub fn ta_queue_push(q: *mut c_void, a: *const u8, a_len: usize, b: *const u8, b_len: usize, ticket: *mut usize) -> c_int;
         pub fn ta_queue_flush(q: *mut c_void, results: *mut *const u32, n: *mut usize) -> c_int;
         pub fn ta_queue_destroy(q: *mut c_void);
+        pub fn ta_set_devices(devices: *const c_int, n: usize) -> c_int;
+        pub fn ta_get_devices(out: *mut c_int, cap: usize, n_out: *mut usize) -> c_int;
+        pub fn ta_levenshtein_k_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
+                                           out_host: *mut u32) -> c_int;
+        pub fn ta_levenshtein_exp_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, costs: *const TaEditCosts,
+                                             out_host: *mut u32) -> c_int;
+        pub fn ta_hamming_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, out_host: *mut u32) -> c_int;
     }
     /// Frees what a thread holds inside the library (its stream, pinned buffers, device scratch) when the thread ends: the
     /// library itself frees nothing from a thread-exit hook.  Touched by every call through `check`.
@@ -257,6 +264,27 @@ pub mod levenshtein {
         if pending > 0 { out.extend(q.flush()); }
         out
     }
+    /// The same for pairs that already sit in slices: no queue copy -- the strings are gathered into one CSR blob per side and handed to
+    /// the host-pointer batch entry, which shards them over the device set (`device::set_devices`; default: every visible GPU), each
+    /// device uploading its contiguous slice through its own pinned ring and PCIe link (include/triple_accel_amd.h, "the device set").
+    pub fn levenshtein_simd_k_with_opts_slices(pairs: &[(&[u8], &[u8])], k: u32, costs: EditCosts) -> Vec<Option<u32>> {
+        let n = pairs.len();
+        let (mut blob_a, mut blob_b) = (Vec::<u8>::new(), Vec::<u8>::new());
+        let (mut off_a, mut off_b) = (Vec::<u64>::with_capacity(n + 1), Vec::<u64>::with_capacity(n + 1));
+        off_a.push(0);
+        off_b.push(0);
+        for (a, b) in pairs {
+            blob_a.extend_from_slice(a);
+            blob_b.extend_from_slice(b);
+            off_a.push(blob_a.len() as u64);
+            off_b.push(blob_b.len() as u64);
+        }
+        let sa = TaStrings { blob: blob_a.as_ptr(), off: off_a.as_ptr(), stride: 0, len: 0, max_len: 0 };
+        let sb = TaStrings { blob: blob_b.as_ptr(), off: off_b.as_ptr(), stride: 0, len: 0, max_len: 0 };
+        let mut out = vec![0u32; n];
+        check(unsafe { ta_levenshtein_k_batch_host(&sa, &sb, n, k, &costs.raw(), out.as_mut_ptr()) });
+        out.into_iter().map(|v| if v == TA_NONE { None } else { Some(v) }).collect()
+    }
     /// `pairs.map(|(a, b)| levenshtein(a, b))` through the queue
     pub fn levenshtein_many<'a, I>(pairs: I) -> Vec<u32>
     where I: IntoIterator<Item = (&'a [u8], &'a [u8])> {
@@ -397,6 +425,18 @@ pub mod device {
     pub const OPT_EARLY_OUT: c_int = 1;
     pub const OPT_UNIT_PREFILTER: c_int = 2;
     pub fn set_option(option: c_int, on: bool) { unsafe { check(ta_set_option(option, on as c_int)); } }
+
+    /// The GPUs the host entry points fan out over (empty slice: every visible device, the default).  With more than one entry the
+    /// `*_many` / `*_slices` batch functions, `Queue::flush` and the searches over haystacks of >= 8 MiB are partitioned over the set
+    /// inside the library; callers of the reference's functions change nothing.  An id may be listed more than once.
+    pub fn set_devices(devices: &[c_int]) { unsafe { check(ta_set_devices(devices.as_ptr(), devices.len())); } }
+    pub fn get_devices() -> Vec<c_int> {
+        let mut n = 0usize;
+        unsafe { check(ta_get_devices(std::ptr::null_mut(), 0, &mut n)); }
+        let mut v = vec![0 as c_int; n];
+        unsafe { check(ta_get_devices(v.as_mut_ptr(), n, &mut n)); }
+        v
+    }
 
     /// N x `levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs)`
     pub unsafe fn levenshtein_k_batch(a: &TaStrings, b: &TaStrings, n: usize, k: u32, costs: EditCosts, out_dev: *mut u32, stream: *mut c_void) {

@@ -2,7 +2,10 @@
 
 The hot path shards without any data-path collective:
   * pair batches: contiguous N/G pairs per rank; results stay on the rank (or are all-gathered on request):
-    levenshtein_k_batch_sharded, levenshtein_trace_batch_sharded;
+    levenshtein_k_batch_sharded, levenshtein_exp_batch_sharded, hamming_batch_sharded, levenshtein_trace_batch_sharded;
+  * hamming_search over one big haystack: the windows that START in a rank's shard need needle_len - 1 bytes of the
+    ranks behind it -- every rank publishes its first needle_len - 1 bytes, searches its shard in place and a tail buffer of at most
+    2 (needle_len - 1) bytes; one match-list gather, the Best pass (no overlap fold) on every rank: hamming_search_sharded;
   * levenshtein_search over one big haystack: contiguous shards RESIDENT in HBM (never copied or re-uploaded); every
     rank publishes its last needle_len + unit_k + 2 bytes (one all-gather of that many bytes, on the device under RCCL)
     and searches [left context | its first halo bytes] as a tiny head buffer plus its shard in place; every rank emits
@@ -66,6 +69,34 @@ def levenshtein_k_batch_sharded(a, b, k, costs=LEVENSHTEIN_COSTS, gather=True, g
         sb = b if isinstance(b, B.Strings) else B.Strings.from_list(b)
         local = B.levenshtein_k_batch(sa, sb, k, costs) if sa.n else torch.empty(0, dtype=torch.int32, device=sa.blob.device)
     return all_gather_results(local, group) if gather else local
+
+
+def _pairs_sharded(a, b, gather, group, run_local, run_hip):
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if isinstance(a, (list, tuple)):
+        lo, hi = shard_range(len(a), rank, world)
+        a, b = a[lo:hi], b[lo:hi]
+    if run_local is not None:
+        local = torch.from_numpy(np.ascontiguousarray(run_local(a, b), dtype=np.int32))
+    else:
+        from . import batch as B
+        sa = a if isinstance(a, B.Strings) else B.Strings.from_list(a)
+        sb = b if isinstance(b, B.Strings) else B.Strings.from_list(b)
+        local = run_hip(B, sa, sb) if sa.n else torch.empty(0, dtype=torch.int32, device=sa.blob.device)
+    return all_gather_results(local, group) if gather else local
+
+
+def levenshtein_exp_batch_sharded(a, b, costs=LEVENSHTEIN_COSTS, gather=True, group=None, local_batch=None):
+    """levenshtein_exp_with_opts(a_i, b_i, false, costs) over a pair batch sharded as levenshtein_k_batch_sharded (contiguous pairs per rank,
+    no data-path collective; src/levenshtein.rs:1480-1494).  `local_batch(a_list, b_list, costs) -> int32 array` replaces the HIP path."""
+    costs = _costs(costs)
+    return _pairs_sharded(a, b, gather, group, None if local_batch is None else (lambda x, y: local_batch(x, y, costs)),
+                          lambda B, sa, sb: B.levenshtein_exp_batch(sa, sb, costs))
+
+
+def hamming_batch_sharded(a, b, gather=True, group=None, local_batch=None):
+    """hamming(a_i, b_i) over a pair batch sharded the same way (src/hamming.rs:390; -1 where the lengths differ -- the reference panics)."""
+    return _pairs_sharded(a, b, gather, group, local_batch, lambda B, sa, sb: B.hamming_batch(sa, sb))
 
 
 def levenshtein_trace_batch_sharded(a, b, k, costs=LEVENSHTEIN_COSTS, gather=True, group=None, local_batch=None):
@@ -232,4 +263,102 @@ def levenshtein_search_sharded(needle, shard, k, search_type=SearchType.Best, co
         hits.insert(0, (0, 0, whole_gap))
     if search_type == SearchType.Best:
         hits = fold_best(hits, k, True)
+    return [Match(*h) for h in hits]
+
+
+def hamming_search_sharded(needle, shard, k, search_type=SearchType.Best, group=None, local_search=None):
+    """hamming_search_simd_with_opts (src/hamming.rs:454-554) over the concatenation of every rank's `shard`.
+
+    A window belongs to the rank its START lies in and needs `needle_len - 1` bytes of the ranks behind it: every rank publishes its first
+    `needle_len - 1` bytes (one all-gather of that many bytes, on the device under RCCL).  Each rank then runs
+      * the BODY: its shard in place (host bytes, or a haystack RESIDENT in HBM -- never copied or re-uploaded), the windows that lie inside it;
+      * the TAIL: [its last needle_len - 1 bytes | the following ranks' first bytes], at most 2 (needle_len - 1) bytes assembled on the
+        device, the windows that start in those last bytes.
+    The SIMD contract's NUL rule (:463: a zero byte ANYWHERE in the haystack panics) is agreed between the ranks before anyone raises
+    (one all-reduce of a flag), so no rank is left waiting in a collective.  The one exchange step of the data path is the gather of the
+    match lists; the Best pass (running minimum, no overlap fold, :122-143) runs identically on every rank.
+    `local_search(needle, bytes, k, base)` -> int64 rows (start, end, k) of ALL windows with <= k mismatches replaces the HIP kernels
+    (tests, gloo; host-bytes shards only)."""
+    from . import PanicError
+    needle = bytes(needle)
+    n = len(needle)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = _device_for_group(group)
+    dshard = _as_device_shard(shard)
+    if dshard is None:
+        shard = bytes(shard)
+        if local_search is None:
+            from . import batch as B
+            dshard = B.haystack_tensor(shard)
+    elif local_search is not None:
+        raise ValueError("local_search stand-ins take host bytes")
+    slen = dshard[1] if dshard is not None else len(shard)
+    ln = torch.tensor([slen], dtype=torch.int64, device=dev)
+    lens = [torch.zeros_like(ln) for _ in range(world)]
+    dist.all_gather(lens, ln, group=group)
+    lens = [int(x.item()) for x in lens]
+    total = sum(lens)
+    if n == 0 or n > total:                               # :455-461
+        return []
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    ov = n - 1
+    # every rank publishes its first `ov` bytes (left-aligned); a rank's right context is the head of what follows it
+    hl = min(ov, slen)
+    head_t = torch.zeros(max(ov, 1), dtype=torch.uint8, device=dshard[0].device if dshard is not None else "cpu")
+    if hl:
+        head_t[:hl] = dshard[0][:hl] if dshard is not None else torch.from_numpy(np.frombuffer(shard[:hl], dtype=np.uint8).copy())
+    head_t = head_t.to(dev)
+    heads = [torch.zeros_like(head_t) for _ in range(world)]
+    dist.all_gather(heads, head_t, group=group)
+    pieces, have, r = [], 0, rank + 1
+    while r < world and have < ov:
+        take = min(ov - have, min(ov, lens[r]))
+        if take:
+            pieces.append(heads[r][:take])
+            have += take
+        r += 1
+    ctx_t = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.uint8, device=dev)
+    off = int(offs[rank])
+    tl = min(ov, slen)                                    # windows that start in the shard's last `tl` bytes reach into the context
+    nul, parts = 0, []
+    if dshard is not None:
+        from . import batch as B
+        from .batch import SLACK
+        sdev = dshard[0].device
+        try:
+            if slen >= n:
+                parts.append(B.hamming_search_dev(needle, dshard, k, base=off))
+            elif slen and bool((dshard[0][:slen] == 0).any().item()):
+                nul = 1                                   # (a shard too short to hold a window is still part of the haystack: :463)
+            if tl and tl + have >= n:
+                tail = torch.zeros(tl + have + SLACK, dtype=torch.uint8, device=sdev)
+                tail[:tl] = dshard[0][slen - tl:slen]
+                if have:
+                    tail[tl:tl + have] = ctx_t.to(sdev)
+                rows = B.hamming_search_dev(needle, (tail, tl + have), k, base=off + slen - tl)
+                parts.append(rows[rows[:, 0] >= off + max(slen - n + 1, 0)] if len(rows) else rows)   # (the body owns the windows inside the shard)
+        except PanicError:
+            nul = 1
+    else:
+        if b"\0" in shard:
+            nul = 1
+        ext = shard + ctx_t.cpu().numpy().tobytes()
+        if len(ext) >= n and slen:
+            rows = np.asarray(local_search(needle, ext, k, off), dtype=np.int64).reshape(-1, 3)
+            parts.append(rows[rows[:, 0] < off + slen] if len(rows) else rows)
+    flag = torch.tensor([nul], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        raise PanicError("No zero/null bytes allowed in the string!")
+    parts = [np.asarray(x, dtype=np.int64).reshape(-1, 3) for x in parts]
+    local = np.concatenate(parts) if parts else np.empty((0, 3), dtype=np.int64)
+    if len(local):
+        local = local[np.argsort(local[:, 1], kind="stable")]
+        if search_type == SearchType.Best:                # only the hits with the shard's smallest k can survive the fold
+            local = local[local[:, 2] == local[:, 2].min()]
+    flat = torch.from_numpy(np.ascontiguousarray(local).reshape(-1)).to(dev)
+    allhits = all_gather_results(flat, group).cpu().numpy().reshape(-1, 3)
+    hits = [tuple(int(v) for v in row) for row in allhits]
+    if search_type == SearchType.Best:
+        hits = fold_best(hits, k, False)
     return [Match(*h) for h in hits]
