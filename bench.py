@@ -43,13 +43,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5w", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "hsearch"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5w", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "cfg2tp", "hsearch"],
                     help="cfg1..cfg5 = BASELINE.json's configs; cfg2w / cfg4w = the cfg2 / cfg4 geometry under general EditCosts "
                          "((2,3,1,None) k=32 / (2,2,1,3) k=8): the DP band-wavefront kernel; hsearch = hamming_search of a --needle-len byte needle "
                          "over a 1 GiB random shard with planted near copies (src/hamming.rs:454-554), k = needle_len / 4")
     ap.add_argument("--costs", default="2,3,1,-",
                     help="cfg5w: cfg5's geometry (32 B needle, 1 GiB shard, k = 16, Best) under these EditCosts, as mismatch,gap,start_gap,transpose "
                          "('-' = None): the unit-cost scan as a SUPERSET filter with k' = srch_filter_k + the exact kernel on the flagged blocks")
+    ap.add_argument("--tcosts", default="", help="cfg2t / cfg2tp: trace under these EditCosts (mismatch,gap,start_gap,transpose; '-' = None) instead of LEVENSHTEIN_COSTS")
+    ap.add_argument("--tk", type=int, default=0, help="cfg2t / cfg2tp: k (default 32)")
     ap.add_argument("--needle-len", type=int, default=32, help="hsearch: needle bytes (8 / 32: shift-add scan; > 32: SWAR kernel)")
     ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs (cfg5: haystack MiB) per GPU")
     ap.add_argument("--dist", default="random", choices=["random", "mutated", "ragged", "dna", "dna5", "protein", "iupac"],
@@ -322,7 +324,7 @@ def main():
 
     # ------------------------------------------------------------------ workload set-up
     # make(seed, lo, hi) -> (run, units, parity, extra): one rank's share of a batch
-    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t"):
+    if wl in ("cfg2", "cfg4", "cfg3", "cfg1", "cfg2w", "cfg4w", "cfg2l", "cfg2s", "cfg2t", "cfg2tp"):
         n_cfg, L, k, costs = {"cfg1": (10_000, 1024, None, None), "cfg2": (1_000_000, 256, 32, LEV),
                               "cfg3": (100_000, 4096, None, LEV), "cfg4": (1_000_000, 128, 8, RDAM),
                               "cfg2w": (1_000_000, 256, 32, (2, 3, 1, None)), "cfg4w": (1_000_000, 128, 8, (2, 2, 1, 3)),
@@ -331,8 +333,15 @@ def main():
                               "cfg2l": (1_000_000, 256, 32, (2, 3, 0, None)), "cfg2s": (1_000_000, 256, 32, (2, 2, 0, None)),
                               # cfg2's geometry with trace_on = true for every pair (mutated pairs: every pair has a script):
                               # argmin codes from the DP band kernel + the walk kernel, scripts written to HBM as ta_edit runs
-                              "cfg2t": (1_000_000, 256, 32, LEV)}[wl]
+                              "cfg2t": (1_000_000, 256, 32, LEV),
+                              # the same with PACKED records (ta_levenshtein_trace_batch_packed): 4 bytes per run, written by the walk in place
+                              "cfg2tp": (1_000_000, 256, 32, LEV)}[wl]
         n_cfg = args.pairs or n_cfg
+        if wl in ("cfg2t", "cfg2tp") and args.tcosts:
+            cs = args.tcosts.split(",")
+            costs = (int(cs[0]), int(cs[1]), int(cs[2]), None if cs[3] in ("-", "None", "") else int(cs[3]))
+        if wl in ("cfg2t", "cfg2tp") and args.tk:
+            k = args.tk
         ragged = args.dist == "ragged"
         assert not ragged or wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s"), "--dist ragged is a k-bounded batch distribution"
         bytes_unit = 2 * L + 4
@@ -350,14 +359,15 @@ def main():
                     "cfg4w": "levenshtein_simd_k_with_opts EditCosts(2,2,1,Some(3)) k=8, 1M 128B pairs (general costs + transposition)",
                     "cfg2l": "levenshtein_simd_k_with_opts EditCosts(2,3,0,None) k=32, 1M 256B pairs (weighted linear gaps: DP band-wavefront kernel)",
                     "cfg2s": "levenshtein_simd_k_with_opts EditCosts(2,2,0,None) k=32, 1M 256B pairs (unit costs x 2: bit-parallel kernel with k / 2)",
-                    "cfg2t": "levenshtein_simd_k_with_opts k=32 trace_on=true, 1M mutated 256B pairs: distances + edit scripts (ta_levenshtein_trace_batch)"}[wl]
+                    "cfg2t": "levenshtein_simd_k_with_opts k=32 trace_on=true, 1M mutated 256B pairs: distances + edit scripts (ta_levenshtein_trace_batch)",
+                    "cfg2tp": "levenshtein_simd_k_with_opts k=32 trace_on=true, 1M mutated 256B pairs: distances + edit scripts as packed 4-byte runs (ta_levenshtein_trace_batch_packed)"}[wl]
             unit_name, dtype = "pairs", "u32"   # reference width class u8 (ta_levenshtein_select); the kernel computes on 1-bit cells in u32 lanes
             # cells inside the band the kernels evaluate: [min(0,delta) - t, max(0,delta) + t], t = (unit_k - |delta|) / 2
             #  -- about half of the credited reference band; reported beside the credited figure
             uk = min(max(min(k, L * max(costs[0], costs[1])) - costs[2], 0) // costs[1], 2 * L)
             evaluated_unit = sum(min(L, i + uk // 2) - max(1, i - uk // 2) + 1 for i in range(1, L + 1))
 
-        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14, "cfg2l": 22, "cfg2s": 32, "cfg2t": 42}[wl]
+        seed0 = 0x7A00 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 4, "cfg2w": 12, "cfg4w": 14, "cfg2l": 22, "cfg2s": 32, "cfg2t": 42, "cfg2tp": 42}[wl]
 
         def gen(seed, n):
             """-> ((blob_a, off_a), (blob_b, off_b)) as numpy CSR; fixed-length distributions also carry their (n, L) arrays"""
@@ -373,7 +383,7 @@ def main():
                     blob[:int(off[-1])] = Dg.random_bytes(g, int(off[-1]))
                     csr.append((blob, off))
                 return csr[0], csr[1], None
-            if args.dist == "random" and wl != "cfg2t":
+            if args.dist == "random" and wl not in ("cfg2t", "cfg2tp"):
                 a, b = Dg.pairs_random(seed, n, L)
             elif args.dist in ALPHABETS:
                 sym = np.frombuffer(ALPHABETS[args.dist], dtype=np.uint8)
@@ -426,11 +436,15 @@ def main():
                 cells_total, bytes_total = int(sum(memo.values())), int(la.sum() + lb.sum() + 4 * n)
                 host_blobs = [(sa.blob, ca[0]), (sb.blob, cb[0]), (sa.off, ca[1].astype(np.int64)), (sb.off, cb[1].astype(np.int64))]
             out = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
-            if wl == "cfg2t":
+            if wl in ("cfg2t", "cfg2tp"):
                 cap = 2 * k + 1
-                ed = torch.empty((max(n, 1), cap, 2), dtype=torch.int64, device="cuda")[:n]
                 ne = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")[:n]
-                run = lambda: B.levenshtein_trace_batch(sa, sb, k, costs, cap=cap, out=out, edits=ed, n_edits=ne)
+                if wl == "cfg2t":
+                    ed = torch.empty((max(n, 1), cap, 2), dtype=torch.int64, device="cuda")[:n]
+                    run = lambda: B.levenshtein_trace_batch(sa, sb, k, costs, cap=cap, out=out, edits=ed, n_edits=ne)
+                else:
+                    ed = torch.empty((max(n, 1), cap), dtype=torch.int32, device="cuda")[:n]
+                    run = lambda: B.levenshtein_trace_batch_packed(sa, sb, k, costs, cap=cap, out=out, packed=ed, n_edits=ne)
                 oracle = lambda l, h, th: O.levenshtein_k_batch(*csr(l, h), k, costs, threads=th)
             elif wl == "cfg1":
                 run = lambda: B.hamming_batch(sa, sb, out=out)
@@ -458,7 +472,7 @@ def main():
                         sym = np.frombuffer(ALPHABETS[args.dist], dtype=np.uint8)
                         am, bm = sym[am % len(sym)], sym[bm % len(sym)]
                     side = torch.empty(side_n, dtype=torch.int32, device="cuda")
-                    if wl == "cfg2t":
+                    if wl in ("cfg2t", "cfg2tp"):
                         B.levenshtein_trace_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), k, costs, out=side)
                     else:
                         B.levenshtein_k_batch(B.Strings.from_fixed(am), B.Strings.from_fixed(bm), k, costs, out=side, alphabet=ALPHABETS.get(args.dist))
@@ -472,8 +486,8 @@ def main():
                 assert np.array_equal(got, want), "parity gate failed: HIP path != oracle"
                 extra_t["parity_some"] = some + int((want != 0xFFFFFFFF).sum())      # (cfg1 / cfg3: every answer is a number)
                 extra_t["parity_side"] = side_n
-                if wl == "cfg2t":                           # the scripts, edit for edit, against the scalar traceback; their bytes
-                    scripts = B.edits_to_lists(ed[:600], ne[:600])
+                if wl in ("cfg2t", "cfg2tp"):               # the scripts, edit for edit, against the scalar traceback; their bytes
+                    scripts = B.edits_to_lists(ed[:600], ne[:600]) if wl == "cfg2t" else B.packed_to_lists(ed[:600], ne[:600])
                     for i in range(min(n, 600)):
                         wd, we = O.levenshtein_simd_k_with_opts(fixed[0][lo + i].tobytes(), fixed[1][lo + i].tobytes(), k, True, costs)
                         assert scripts[i] == (we if wd is not None else []), "parity gate failed: edit script != oracle's traceback"
@@ -705,8 +719,8 @@ def main():
     run, units, parity, extra = make(strong and world > 1)
     parity_n = parity()
     parity_some, parity_side = extra.get("parity_some"), extra.get("parity_side", 0)
-    if wl == "cfg2t":      # algorithmic bytes of a traceback pass: the strings, the distance and run count per pair, the runs written (16 B each)
-        extra["bytes_total"] += 4 * units + 16 * extra["runs_total"]
+    if wl in ("cfg2t", "cfg2tp"):      # algorithmic bytes of a traceback pass: the strings, the distance and run count per pair, the runs written (16 / 4 B each)
+        extra["bytes_total"] += 4 * units + (16 if wl == "cfg2t" else 4) * extra["runs_total"]
     info = T.last_launch_info()
     kernel_name = T.last_kernel_name()
     elapsed, dev_ms, n_ramp = timed_region(run, args.steps, args.warmup)
@@ -859,7 +873,7 @@ def main():
             cpu = {"value": cells_unit * cpu_sample / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                    "sample": "first %d MiB of the shard, single thread (the scalar search is one serial scan), oracle/ta_oracle.c "
                              "(restated scalar path), %.1f s" % (cpu_sample >> 20, dt), "host": facts}
-        elif wl == "cfg2t":
+        elif wl in ("cfg2t", "cfg2tp"):
             a_np, b_np = extra["csr"](0, min(units, 2000))
             sample = min(units, 2000)
             sa_l = [bytes(a_np[0][int(a_np[1][i]):int(a_np[1][i + 1])]) for i in range(sample)]

@@ -212,7 +212,11 @@ void ta_free(void *p);
  * functions run on the stream the caller passes; a thread that switches streams between two such calls is ordered by an
  * event the library records at the end of each call (the thread-local scratch of the first call may still be in use).
  * ta_thread_release() frees what the calling thread holds inside the library (device scratch, its stream, the pinned
- * buffer); optional -- without it they live until process exit. */
+ * buffer); optional -- without it they live until process exit.
+ * Graph capture.  The batch / *_dev entries that say so may be captured into a hipGraph (hipStreamBeginCapture on the stream they are given).
+ * A captured call bakes the calling thread's scratch pointers into the graph: run the same call once OUTSIDE the capture first (it sizes the
+ * scratch); a call that would have to grow the scratch during a capture returns TA_ERR_UNSUPPORTED instead of allocating.  The graph is
+ * invalid after any later call of the thread that grows the scratch (a bigger batch, a wider band) and after ta_thread_release(). */
 void ta_thread_release(void);
 
 /* ---- batch API on device-resident data (new surface; N = 1 equals the single-call form) -- */
@@ -250,10 +254,21 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
  * `stream` and returns (no synchronisation).  2 k + 1 records per pair always suffice; a longer script is cut at `cap` records and
  * n_edits_dev[i] says how many it has.  LEVENSHTEIN_COSTS / RDAMERAU_COSTS with k <= 32 (30): no per-cell records -- the distance pass leaves a
  * checkpoint of its column state every 16th column, one more kernel recomputes tile after tile backwards and walks; any
- * other costs / wider bands: 2-bit argmin codes of the DP band kernel + a walk kernel (3.4b).  TA_ERR_UNSUPPORTED for bands beyond the
- * register kernel (> 4222 diagonals). */
+ * other costs / wider bands: 2-bit argmin codes of the DP band kernel + a walk kernel (3.4b).  EditCosts(g, g, 0, None | Some(g)) -- unit costs
+ * times g -- ride the checkpoint route with k / g (the script is the unit-cost script, the distance g times the unit one).  Batches whose
+ * scratch (checkpoints, run lists) would not fit are worked through in sub-batches of whole wavefronts on the same stream.
+ * TA_ERR_UNSUPPORTED for bands beyond the register kernel (> 4222 diagonals). */
 int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, void *stream);
+
+/* ta_levenshtein_trace_batch with PACKED records: one 32-bit word per run, (edit type << 29) | count; pair i's script is the
+ * min(n_edits_dev[i], cap) words that END at packed_dev[(i + 1) * cap] -- front to back, right-aligned in the pair's slot of `cap` words (a
+ * script of more than `cap` runs keeps its LAST cap runs and n_edits_dev[i] says how long it is; the words in front of a script are not
+ * written).  A quarter of the bytes of the 16-byte ta_edit form, which stays the ABI's default; the bindings expand the words on the host.
+ * On the checkpoint route (LEVENSHTEIN_COSTS / RDAMERAU_COSTS and their multiples EditCosts(g, g, 0, None | Some(g)), k / g <= 32 (30)) the
+ * walk writes every run where it belongs: no run lists in scratch, no reversal step.  Strings of 2^29 bytes and more: TA_ERR_UNSUPPORTED. */
+int ta_levenshtein_trace_batch_packed(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                      uint32_t *out_dev, uint32_t *packed_dev, uint32_t *n_edits_dev, size_t cap, void *stream);
 
 /* N x hamming(a_i, b_i); out[i] = TA_NONE where the lengths differ (Rust: panic). */
 int ta_hamming_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out_dev, void *stream);

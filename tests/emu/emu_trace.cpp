@@ -15,6 +15,9 @@ using namespace ta;
 #include "lev_plan.h"
 // dist[n]: the pass's answers (0xFFFFFFFF = None); runs[n * runs_cap] ((edit type << 29) | count), n_runs[n] out.  tile = 8, 16 or 32.  Reads are range-checked: a byte
 // outside the blobs (+ 16 of slack) reads as 0xA5.
+// packed form (LevBitsTraceParams::packed_cap): `runs` is then the packed script buffer, packed_cap words per pair, scripts right-aligned
+static uint32_t g_packed_cap = 0;
+extern "C" void emu_lev_bits_trace_set_packed(uint32_t cap) { g_packed_cap = cap; }
 extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, uint64_t a_len, const uint8_t *b_blob, const uint64_t *b_off,
                                   uint64_t b_len, uint32_t n, uint32_t u, int has_t, int tile, const uint32_t *dist, uint64_t max_len,
                                   uint32_t *runs, uint32_t runs_cap, uint32_t *n_runs) {
@@ -27,7 +30,7 @@ extern "C" int emu_lev_bits_trace(const uint8_t *a_blob, const uint64_t *a_off, 
     P.ckpt_tiles = (uint32_t)((max_len + (uint64_t)cols_per_tile - 1) / (uint64_t)cols_per_tile) + 1u;
     const uint32_t waves = (n + 63) / 64;
     std::vector<uint32_t> ck((size_t)waves * P.ckpt_tiles * 5u * 64u, 0xDEADBEEFu);
-    P.ckpt = ck.data(); P.runs = runs; P.runs_cap = runs_cap; P.n_runs = n_runs;
+    P.ckpt = ck.data(); P.runs = runs; P.runs_cap = runs_cap; P.n_runs = n_runs; P.packed_cap = g_packed_cap;
     struct RangeGuard { ~RangeGuard() { EmuWave::clear_ranges(); } } range_guard;
     EmuWave::clear_ranges();
     EmuWave::add_range(a_blob, (a_off ? a_off[n] : (uint64_t)n * a_len) + 16);

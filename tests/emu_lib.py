@@ -123,16 +123,20 @@ def lev_bits(a_list, b_list, k, trans=False, force_NA=0, chunk=0, static=0):
     return res, dict(NA=int(plan[0]), u=int(plan[1]), Tw=int(plan[2]), static=int(plan[3]) == 1, s8=int(plan[3]) == 3)
 
 
-def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False):
+def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False, packed=0):
     """Batch tracebacks by checkpoints + recomputation (lev_bits_trace_body.h): the run-length script the reference returns --
     [(edit name, count)] per pair, None for a pair whose distance is None (the body leaves the runs last run first: turned round here, as
     the kernel's last step does).  dists: the pass's answers (None = no script); u: the pass's unit_k.  fixed: the strided (fixed-length)
-    view of the batch instead of CSR."""
+    view of the batch instead of CSR.  packed = c > 0: the packed form (LevBitsTraceParams::packed_cap = c) -- the walk writes the runs
+    right-aligned into c words per pair, front to back; a script of more than c runs keeps its LAST c runs."""
     n = len(a_list)
     ab, ao = pack(a_list)
     bb, bo = pack(b_list)
     max_len = max([len(x) for x in a_list] + [len(x) for x in b_list] + [0])
     cap = min(2 * max_len + 1, 2 * u + 2)
+    lib().emu_lev_bits_trace_set_packed(int(packed))
+    if packed:
+        cap = int(packed)
     runs = np.full(n * cap, 0xDEADBEEF, dtype=np.uint32)
     n_runs = np.full(n, 0xDEADBEEF, dtype=np.uint32)
     dist = np.array([0xFFFFFFFF if d is None else d for d in dists], dtype=np.uint32)
@@ -146,9 +150,22 @@ def lev_bits_trace(a_list, b_list, u, dists, trans=False, tile=16, fixed=False):
         rc = f(ab.ctypes.data, None, la, bb.ctypes.data, None, lb, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, runs.ctypes.data, cap, n_runs.ctypes.data)
     else:
         rc = f(ab.ctypes.data, ao.ctypes.data, 0, bb.ctypes.data, bo.ctypes.data, 0, n, u, int(bool(trans)), tile, dist.ctypes.data, max_len, runs.ctypes.data, cap, n_runs.ctypes.data)
+    lib().emu_lev_bits_trace_set_packed(0)
     if rc:
         raise RuntimeError("emu_lev_bits_trace rc=%d" % rc)
     names = ["Match", "Mismatch", "AGap", "BGap", "Transpose"]
+    if packed:
+        out = []
+        for p in range(n):
+            if dists[p] is None:
+                assert n_runs[p] == 0 and np.all(runs[p * cap:(p + 1) * cap] == 0xDEADBEEF)
+                out.append(None)
+                continue
+            have = min(int(n_runs[p]), cap)
+            assert np.all(runs[p * cap:(p + 1) * cap - have] == 0xDEADBEEF)          # nothing outside the script's words
+            ws = [int(w) for w in runs[(p + 1) * cap - have:(p + 1) * cap]]
+            out.append((int(n_runs[p]), [(names[w >> 29], w & 0x1FFFFFFF) for w in ws]))
+        return out
     out = []
     for p in range(n):
         if dists[p] is None:

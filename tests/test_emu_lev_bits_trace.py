@@ -105,3 +105,84 @@ def test_trace_folded_sweep_on_csr_batches(trans):
         a[5], b[5] = b"", b""
         a[6], b[6] = b"", b"ab"
         assert _check(a, b, k, trans, 116) > 60
+
+
+# ---- adversarial alphabets: NUL is what load_strings pads with outside the strings (lev_bits_trace_body.h: pieces
+# outside a string are zeroed) and 0x0C is the byte-test constant (`x ^ 0x0C0C0C0C`, wave.h ne12): strings made of exactly those bytes
+# must trace like any other (the reference's own NUL cases: tests/basic_tests.rs:503-537, 774-802)
+ALPHABETS = {"nul": [0], "nul_0c": [0, 0x0C], "0c_0d": [0x0C, 0x0D], "all": list(range(256))}
+
+
+def _alpha_batch(g, sym, n_pairs, max_len, k, trans):
+    sym = np.array(sym, dtype=np.uint8)
+    a, b = [], []
+    for i in range(n_pairs):
+        n = int(g.integers(0, max_len))
+        x = bytearray(sym[g.integers(0, len(sym), size=n)].tobytes())
+        y = bytearray(x)
+        for _ in range(int(g.integers(0, k + 2))):
+            t = int(g.integers(0, 4 if trans else 3))
+            pos = int(g.integers(0, len(y) + 1))
+            c = int(sym[int(g.integers(0, len(sym)))])
+            if t == 0 and pos < len(y):
+                y[pos] = c
+            elif t == 1:
+                y.insert(pos, c)
+            elif t == 2 and pos < len(y):
+                del y[pos]
+            elif t == 3 and pos + 1 < len(y):
+                y[pos], y[pos + 1] = y[pos + 1], y[pos]
+        x, y = bytes(x), bytes(y)
+        if i % 2:
+            x, y = y, x
+        a.append(x); b.append(y)
+    return a, b
+
+
+@pytest.mark.parametrize("name", sorted(ALPHABETS))
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("tile", [8, 16, 32, 116])
+def test_trace_adversarial_alphabets(name, trans, tile):
+    g = Dg.rng(0xAD5 + tile + 7 * int(trans) + len(name))
+    for k in (4, 13, 30):
+        if tile == 116:                                    # the folded sweep: fixed-length batches
+            sym = np.array(ALPHABETS[name], dtype=np.uint8)
+            L = 150
+            a = [bytes(sym[g.integers(0, len(sym), size=L)]) for _ in range(70)]
+            b = []
+            for x in a:
+                y = bytearray(x)
+                for q in g.integers(0, L, size=int(g.integers(0, k // 2 + 1))):
+                    y[int(q)] = int(sym[int(g.integers(0, len(sym)))])
+                if trans and len(sym) > 1:
+                    q = int(g.integers(0, L - 1))
+                    y[q], y[q + 1] = y[q + 1], y[q]
+                b.append(bytes(y))
+            assert _check(a, b, k, trans, tile, fixed=True) > 30
+        else:
+            a, b = _alpha_batch(g, ALPHABETS[name], 110, 150, k, trans)
+            assert _check(a, b, k, trans, tile) > 40
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_trace_packed_form(trans):
+    """LevBitsTraceParams::packed_cap: the walk writes each run where it belongs -- right-aligned in the pair's slot, front to back -- and a
+    script of more runs than the slot holds keeps its last runs; n_runs still says how long the script is."""
+    g = Dg.rng(0x9AC + int(trans))
+    costs = (1, 1, 0, 1) if trans else (1, 1, 0, None)
+    for k, cap in ((6, 13), (20, 41), (20, 7), (30, 61)):
+        a, b = _alpha_batch(g, list(range(97, 101)), 100, 120, k, trans)
+        want = [O.levenshtein_naive_k_with_opts(x, y, k, True, costs) for x, y in zip(a, b)]
+        dists = [w[0] for w in want]
+        u = min(k, max([len(x) for x in a] + [len(y) for y in b] + [1]))
+        for tile in (16, 116) if False else (16,):
+            got = E.lev_bits_trace(a, b, u, dists, trans, tile, False, packed=cap)
+            cut = 0
+            for p, (gp, w) in enumerate(zip(got, want)):
+                if w[0] is None:
+                    assert gp is None
+                    continue
+                nr, script = gp
+                assert nr == len(w[1]) and script == w[1][max(0, len(w[1]) - cap):], (p, k, cap)
+                cut += nr > cap
+            assert cap >= 2 * k + 1 or cut > 0

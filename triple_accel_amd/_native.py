@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_search_dev", "ta_hamming_search_dev", "ta_search_fold_best", "ta_search_best_hits_dev",
     "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted", "ta_levenshtein_search_resume",
     # the device set (ta_multi.hip)
+    "ta_levenshtein_trace_batch_packed",
     "ta_set_devices", "ta_get_devices", "ta_levenshtein_k_batch_host", "ta_levenshtein_exp_batch_host", "ta_hamming_batch_host",
     "ta_sharded_pairs_upload", "ta_sharded_pairs_levenshtein_k", "ta_sharded_pairs_levenshtein_exp", "ta_sharded_pairs_hamming",
     "ta_sharded_pairs_time_levenshtein_k", "ta_sharded_pairs_shards", "ta_sharded_pairs_free",
@@ -137,6 +138,7 @@ def lib():
     sig("ta_levenshtein_k_batch_alphabet", i32, [sp, sp, sz, u32, cp, u8p, sz, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_exp_batch", i32, [sp, sp, sz, cp, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_trace_batch", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p])
+    sig("ta_levenshtein_trace_batch_packed", i32, [sp, sp, sz, u32, cp, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p])
     sig("ta_hamming_batch", i32, [sp, sp, sz, C.c_void_p, C.c_void_p])
     sig("ta_levenshtein_search_dev", i32, [u8p, sz, C.c_void_p, sz, u32, cp, i32, C.c_uint64, C.c_uint64,
                                            C.c_void_p, sz, C.POINTER(C.c_uint64), C.c_void_p])

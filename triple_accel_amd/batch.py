@@ -149,6 +149,38 @@ def edits_to_lists(edits, n_edits, allow_cut=False):
     return [[(_EDIT_NAMES[int(e[i, t, 0]) & 0xFFFFFFFF], int(e[i, t, 1])) for t in range(min(int(ne[i]), e.shape[1]))] for i in range(len(ne))]
 
 
+def levenshtein_trace_batch_packed(a: Strings, b: Strings, k, costs=LEVENSHTEIN_COSTS, cap=None, out=None, packed=None, n_edits=None):
+    """levenshtein_trace_batch with PACKED records (ta_levenshtein_trace_batch_packed): -> (out, packed, n_edits); packed is (n, cap) int32,
+    one word per run -- (edit type << 29) | count -- pair i's script the min(n_edits[i], cap) words at the END of row i, front to back (words in
+    front of a script are not written).  A quarter of the bytes of the (n, cap, 2) int64 form; packed_to_lists expands it on the host."""
+    assert a.n == b.n
+    n, dev = a.n, a.blob.device
+    if cap is None:
+        cap = min(2 * int(k) + 1, 2 * max(a.longest(), b.longest(), 1) + 1)
+    out = _out(n, dev) if out is None else out
+    packed = torch.empty((n, cap), dtype=torch.int32, device=dev) if packed is None else packed
+    n_edits = torch.empty(n, dtype=torch.int32, device=dev) if n_edits is None else n_edits
+    cc = _costs(costs)._c()
+    rc = _n.lib().ta_levenshtein_trace_batch_packed(a._ref(), b._ref(), n, k, _C.byref(cc), out.data_ptr(), packed.data_ptr(), n_edits.data_ptr(),
+                                                     cap, _stream())
+    if rc:
+        _raise(rc)
+    return out, packed, n_edits
+
+
+def packed_to_lists(packed, n_edits, allow_cut=False):
+    """the result of levenshtein_trace_batch_packed as Python lists [(name, count), ...] per pair (host copy); a script longer than the row
+    is an error unless allow_cut (then its LAST cap runs are returned)."""
+    import numpy as np
+    p, ne = packed.cpu().numpy().view(np.uint32), n_edits.cpu().numpy()
+    cap = p.shape[1]
+    cut = [i for i in range(len(ne)) if int(ne[i]) > cap]
+    if cut and not allow_cut:
+        raise ValueError("levenshtein_trace_batch_packed: %d script(s) longer than cap = %d runs (first: pair %d with %d runs); pass a larger cap"
+                         % (len(cut), cap, cut[0], int(ne[cut[0]])))
+    return [[(_EDIT_NAMES[int(w) >> 29], int(w) & 0x1FFFFFFF) for w in p[i, cap - min(int(ne[i]), cap):]] for i in range(len(ne))]
+
+
 def hamming_batch(a: Strings, b: Strings, out=None):
     assert a.n == b.n
     out = _out(a.n, a.blob.device) if out is None else out

@@ -45,6 +45,8 @@ struct LevBitsTraceParams {
     uint32_t runs_cap;           // >= 2 u + 2 (a script of cost <= u has at most 2 u + 1 runs) and >= the longest n + m where that is smaller
     uint32_t *n_runs;            // [pair]: runs of the script (0 for None)
     const uint32_t *subset = nullptr;   // optional: the order in which the pairs are taken (lane l of wavefront w: pair subset[64 w + l]) -- CSR batches in length order
+    uint32_t packed_cap = 0;     // != 0: `runs` is the CALLER's packed script buffer, packed_cap words per pair -- the walk writes every run where it belongs, right-aligned in the
+                                 // pair's slot (run r from the script's end at word (pair + 1) packed_cap - 1 - r): no run list in scratch, no reversal step
 };
 
 struct LevParams {

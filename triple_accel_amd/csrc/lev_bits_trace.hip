@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64) void lev_bits_trace_kernel(LevBitsTraceParams P
     if (slot_idx >= P.n) return;
     const uint32_t pair = P.subset ? P.subset[slot_idx] : slot_idx;                                   // (the run list below: this lane's own stores, program order)
     n_edits[pair] = nr;
+    if (P.packed_cap) return;                                                                         // (packed form: the walk has written the script in place)
     const uint32_t have = nr < P.runs_cap ? nr : P.runs_cap;
     const uint32_t *mine = P.runs + (uint64_t)pair * P.runs_cap;
     ta_edit *slot = edits + (uint64_t)pair * cap;

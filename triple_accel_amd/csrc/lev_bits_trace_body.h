@@ -242,7 +242,9 @@ struct LevBitsTrace {
         auto note = [&](const U32 &e, const U32 &r, const Bool &on) {
             const Bool same = on & (e == cur);
             const Bool close = on & !same & (cur != 7u);
-            W::store_u32(P.runs, pair * P.runs_cap + nruns, (cur << 29) | cnt, close & (nruns < P.runs_cap));
+            // (packed form: the run goes straight into the caller's buffer, the script's last run in the last word of the pair's slot)
+            const U32 at = P.packed_cap ? (pair + 1u) * P.packed_cap - 1u - nruns : pair * P.runs_cap + nruns;
+            W::store_u32(P.runs, at, (cur << 29) | cnt, close & (nruns < (P.packed_cap ? P.packed_cap : P.runs_cap)));
             nruns = W::sel(close, nruns + 1u, nruns);
             cnt = W::sel(same, cnt + r, W::sel(on, r, cnt));
             cur = W::sel(on, e, cur);

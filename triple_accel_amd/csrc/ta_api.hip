@@ -51,9 +51,18 @@ bool device_ready() {
 // set by every Scratch::ensure, consumed by the StreamGuard of the call: did this call put thread-local scratch to use?
 static thread_local bool g_scratch_in_use = false;
 
+// true while the call's stream is being captured into a graph (StreamGuard): thread-local scratch must not grow then -- hipFree / hipMalloc are
+// illegal inside a capture, and the graph bakes the scratch pointers in
+static thread_local bool g_call_capturing = false;
+
 int Scratch::ensure(size_t bytes) {
     g_scratch_in_use = true;
     if (bytes <= cap) return TA_OK;
+    if (g_call_capturing) {
+        set_last_error_msg("stream capture: the call needs more thread-local scratch than this thread holds -- run the same call once outside the capture first "
+                           "(the graph stays valid until a later call of the thread grows the scratch, or ta_thread_release)");
+        return TA_ERR_UNSUPPORTED;
+    }
     if (dev) { (void)hipFree(dev); dev = nullptr; cap = 0; }
     size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
     TA_HIP(hipMalloc(&dev, want));
@@ -128,12 +137,16 @@ static bool stream_is_capturing(hipStream_t s) {
 }
 StreamGuard::StreamGuard(hipStream_t s) : st(s) {
     LastUse &u = last_use();
-    if (u.pending && u.st != s && u.ev && !stream_is_capturing(s)) (void)hipStreamWaitEvent(s, u.ev, 0);
+    was_capturing = g_call_capturing;
+    capturing = stream_is_capturing(s);
+    g_call_capturing = capturing;
+    if (u.pending && u.st != s && u.ev && !capturing) (void)hipStreamWaitEvent(s, u.ev, 0);
 }
 StreamGuard::~StreamGuard() {
+    g_call_capturing = was_capturing;
     if (!g_scratch_in_use) return;
     g_scratch_in_use = false;
-    if (stream_is_capturing(st)) return;
+    if (capturing) return;
     LastUse &u = last_use();
     if (!u.ev && hipEventCreateWithFlags(&u.ev, hipEventDisableTiming) != hipSuccess) { u.ev = nullptr; return; }
     if (hipEventRecord(u.ev, st) == hipSuccess) { u.st = st; u.pending = true; }
@@ -1052,6 +1065,62 @@ static int trace_wide(const uint8_t *x, size_t n, const uint8_t *y, size_t m, bo
     return TA_OK;
 }
 
+// The checkpoint-and-recompute traceback of one (sub-)batch of the unit-cost families, bands of up to 33 diagonals: the
+// caller (ta_levenshtein_trace_batch) has validated the arguments and bounded n so that n x runs_cap fits 32 bits and the scratch fits memory.
+// packed != nullptr: the packed form -- the walk writes the runs straight into the caller's buffer (cap words per pair, right-aligned): no run
+// lists in scratch, no last step.
+static int trace_bits_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs, uint64_t max_len,
+                            uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, hipStream_t st, uint32_t *packed = nullptr) {
+    int rc;
+    const bool trans = costs->has_transpose != 0;
+    const uint32_t u = lev_batch_unit_k(k, 1, 1, 0, max_len);
+    // Fixed-length batches: the distance pass IS the forward sweep -- the stride-8 kernel's CKPT instantiation stores the column
+    // state in front of every 16th column (rows = the shorter string: the views are swapped for it where a is the longer one; the
+    // distance is symmetric; CSR batches: pair by pair inside the kernel).  TA_TRACE_OWN_SWEEP=1 pins the trace kernel's own sweep
+    // (TA_TRACE_CSR_OWN_SWEEP=1: for CSR batches only, an A/B).
+    const bool fixed = !a->off && !b->off;
+    const LevBitsPlan bp8 = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 3);
+    const bool fold = bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE") && (fixed || !env_int("TA_TRACE_CSR_OWN_SWEEP"));
+    const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
+    // CSR batches: both kernels run a wavefront to the longest of its 64 pairs -- the pairs are taken in length order (as
+    // ta_levenshtein_k_batch takes them), the same list for the distance pass and the trace kernel.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
+    const uint32_t *order = nullptr;
+    if (!fixed && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER") &&
+        (rc = order_pairs(a, b, (uint32_t)n, u, max_len, false, false, st, &order, nullptr))) return rc;
+    if (!fold && (rc = lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st))) return rc;
+    // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
+    uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
+    Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
+    if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (!packed && (rc = ps.ensure((size_t)n * runs_cap * 4u))) ||
+        (rc = ss.ensure((size_t)n * 4u))) return rc;
+    LevBitsTraceParams T;
+    T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
+    T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = env_int("TA_TRACE_SKIP_WALK") ? 0u : runs_cap; T.n_runs = (uint32_t *)ss.dev;
+    T.subset = order;
+    if (packed) { T.runs = packed; T.packed_cap = (uint32_t)cap; }
+    if (fold) {
+        const bool sw = fixed && a->len > b->len;              // (CSR batches: the kernel swaps pair by pair)
+        LevParams P;
+        P.a = view_of(sw ? b : a); P.b = view_of(sw ? a : b);
+        P.subset = order; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
+        P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
+        P.u = bp8.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp8.lds_per_wave; P.Tw = bp8.Tw; P.ch = bp8.ch;
+        P.ckpt = (uint32_t *)cs.dev; P.ckpt_tiles = tiles;
+        TA_HIP(lev_bits_launch(P, bp8, trans, max_len, st, nullptr, nullptr));
+        ta_launch_info l0 = {};
+        ta_lev_select sel;
+        ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
+        l0.cell_bits = sel.cell_bits; l0.transpose = trans;
+        g_last_launch = l0;
+    }
+    ta_launch_info li = g_last_launch;                 // (the distance pass's: kernel 3)
+    uint32_t grid = 0, lds = 0;
+    TA_HIP(lev_bits_trace_launch(T, trans, fold, edits_dev, n_edits_dev, cap, st, &grid, &lds));
+    li.kernel = 8; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
+    g_last_launch = li;
+    return TA_OK;
+}
+
 extern "C" {
 
 /* levenshtein_simd_k_with_opts(..., trace_on = true): distance + run-length edit script.
@@ -1143,11 +1212,30 @@ int ta_levenshtein_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_
  * working through the batch in chunks), a second kernel walks them, one lane per pair.  A script of more than `cap` runs is cut
  * (n_edits_dev[i] > cap says so); 2 k + 1 runs always hold a script of cost <= k.  Bands beyond the register kernel (more than 4222
  * diagonals) are TA_ERR_UNSUPPORTED here -- ta_levenshtein_trace serves those pairs one by one. */
+static int trace_batch_impl(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                            uint32_t *out_dev, ta_edit *edits_dev, uint32_t *packed_dev, uint32_t *n_edits_dev, size_t cap, void *stream);
 int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
                                uint32_t *out_dev, ta_edit *edits_dev, uint32_t *n_edits_dev, size_t cap, void *stream) {
+    if (n && !edits_dev) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    return trace_batch_impl(a, b, n, k, costs, out_dev, edits_dev, nullptr, n_edits_dev, cap, stream);
+}
+/* The same with PACKED records: one word per run, (edit << 29) | count, pair i's script the min(n_edits_dev[i], cap) words that END at
+ * packed_dev[(i + 1) * cap] -- front to back, right-aligned in the pair's slot of `cap` words (a script of more runs keeps its LAST cap runs;
+ * words in front of the script are not written).  A quarter of the 16-byte records' bytes; on the checkpoint route (LEVENSHTEIN_COSTS /
+ * RDAMERAU_COSTS and their multiples, k / g <= 32 (30)) the walk writes every run where it belongs: no run lists in scratch, no reversal step.
+ * Strings of 2^29 bytes and more: TA_ERR_UNSUPPORTED (a run's count has 29 bits). */
+int ta_levenshtein_trace_batch_packed(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                      uint32_t *out_dev, uint32_t *packed_dev, uint32_t *n_edits_dev, size_t cap, void *stream) {
+    if (n && !packed_dev) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    return trace_batch_impl(a, b, n, k, costs, out_dev, nullptr, packed_dev, n_edits_dev, cap, stream);
+}
+}  // extern "C"
+
+static int trace_batch_impl(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                            uint32_t *out_dev, ta_edit *edits_dev, uint32_t *packed_dev, uint32_t *n_edits_dev, size_t cap, void *stream) {
     int rc = check_batch_args(a, b, n, out_dev);
     if (rc) return rc;
-    if (n && (!edits_dev || !n_edits_dev || cap == 0)) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    if (n && (!n_edits_dev || cap == 0)) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
     if (!costs_ok(costs)) return TA_ERR_BAD_COSTS;
     if (!device_ready()) return TA_ERR_HIP;
     if (n == 0) return TA_OK;
@@ -1156,6 +1244,24 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
     uint64_t max_len = 0;
     if ((rc = batch_max_len(a, b, (uint32_t)n, st, &max_len))) return rc;
     const uint32_t gc = costs->gap_cost, sg = costs->start_gap_cost;
+    if (packed_dev && (max_len >= (1ull << 29) || cap > 0xFFFFFFFFull)) { set_last_error_msg("packed tracebacks: strings of 2^29 bytes and more"); return TA_ERR_UNSUPPORTED; }
+    // Unit costs times g (lev_unit_scale): every alignment costs g times its unit cost, every comparison of the recurrence and of the walk
+    // keeps its outcome -- the script IS the unit-cost script for k / g, the distance g times the unit one (3.4c): the checkpoint kernel
+    // serves EditCosts(g, g, 0, None | Some(g)) too.  TA_NO_UNIT_SCALE=1 keeps the DP band kernel's records.
+    if (const uint32_t g = lev_unit_scale(costs->mismatch_cost, gc, sg, costs->has_transpose != 0, costs->transpose_cost);
+        g && !env_int("TA_NO_BITS") && !env_int("TA_NO_UNIT_SCALE") && !env_int("TA_TRACE_NO_BITS")) {
+        const bool tr = costs->has_transpose != 0;
+        const uint32_t uu = lev_batch_unit_k(k / g, 1, 1, 0, max_len);
+        if ((uint64_t)uu + 1u + (tr ? 2u : 0u) <= 33u && max_len < (1ull << 29)) {
+            const ta_edit_costs uc = {1, 1, 0, (uint8_t)(tr ? 1 : 0), (uint8_t)(tr ? 1 : 0)};
+            if ((rc = trace_batch_impl(a, b, n, k / g, &uc, out_dev, edits_dev, packed_dev, n_edits_dev, cap, stream))) return rc;
+            TA_HIP(scale_results_launch(out_dev, nullptr, (uint32_t)n, nullptr, g, st));
+            ta_lev_select sel;
+            ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
+            g_last_launch.cell_bits = sel.cell_bits;
+            return TA_OK;
+        }
+    }
     // LEVENSHTEIN_COSTS / RDAMERAU_COSTS with a band of up to 33 diagonals (k <= 32; 30 with the transposition term): no per-cell records --
     // the distance pass, then ONE kernel that sweeps the columns forwards with a checkpoint (8 bytes per pair) every 16 columns, recomputes
     // tile after tile backwards with the column states of the tile in LDS, walks, and writes the runs (lev_bits_trace_body.h): 2 x the
@@ -1164,52 +1270,56 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
         const bool trans = costs->has_transpose != 0;
         const bool unit = costs->mismatch_cost == 1 && gc == 1 && sg == 0 && (!trans || costs->transpose_cost == 1);
         const uint32_t u = lev_batch_unit_k(k, 1, 1, 0, max_len);
-        if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len <= 0x7FFFFFF0ull && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
-            // Fixed-length batches: the distance pass IS the forward sweep -- the stride-8 kernel's CKPT instantiation stores the column
-            // state in front of every 16th column (rows = the shorter string: the views are swapped for it where a is the longer one; the
-            // distance is symmetric; CSR batches: pair by pair inside the kernel).  TA_TRACE_OWN_SWEEP=1 pins the trace kernel's own sweep
-            // (TA_TRACE_CSR_OWN_SWEEP=1: for CSR batches only, an A/B).
-            const bool fixed = !a->off && !b->off;
-            const LevBitsPlan bp8 = lev_bits_make_plan(k, 1, 1, 0, trans, trans ? 1u : 0u, max_len, 0, 0, 3);
-            const bool fold = bp8.ok && bp8.s8 && !env_int("TA_TRACE_OWN_SWEEP") && !env_int("TA_TRACE_TILE") && (fixed || !env_int("TA_TRACE_CSR_OWN_SWEEP"));
-            const uint32_t tile = fold ? 16u : lev_bits_trace_tile(), tiles = (uint32_t)((max_len + tile - 1) / tile) + 1u, waves = (uint32_t)((n + 63) / 64);
-            // CSR batches: both kernels run a wavefront to the longest of its 64 pairs -- the pairs are taken in length order (as
-            // ta_levenshtein_k_batch takes them), the same list for the distance pass and the trace kernel.  TA_NO_LENGTH_ORDER=1 keeps the batch order.
-            const uint32_t *order = nullptr;
-            if (!fixed && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER") &&
-                (rc = order_pairs(a, b, (uint32_t)n, u, max_len, false, false, st, &order, nullptr))) return rc;
-            if (!fold && (rc = lev_pass(a, b, (uint32_t)n, order, k, costs, max_len, out_dev, st))) return rc;
-            // (a script of cost <= u has at most 2 u + 1 runs, and never more than n + m)
-            uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
-            Scratch &cs = tls_scratch(9), &ps = tls_scratch(8), &ss = tls_scratch(7);
-            if ((rc = cs.ensure((size_t)waves * tiles * lev_bits_trace_ckpt_words(trans) * 64u * 4u)) || (rc = ps.ensure((size_t)n * runs_cap * 4u)) ||
-                (rc = ss.ensure((size_t)n * 4u))) return rc;
-            LevBitsTraceParams T;
-            T.a = view_of(a); T.b = view_of(b); T.dist = out_dev; T.n = (uint32_t)n; T.u = u;
-            T.ckpt = (uint32_t *)cs.dev; T.ckpt_tiles = tiles; T.runs = (uint32_t *)ps.dev; T.runs_cap = env_int("TA_TRACE_SKIP_WALK") ? 0u : runs_cap; T.n_runs = (uint32_t *)ss.dev;
-            T.subset = order;
-            if (fold) {
-                const bool sw = fixed && a->len > b->len;              // (CSR batches: the kernel swaps pair by pair)
-                LevParams P;
-                P.a = view_of(sw ? b : a); P.b = view_of(sw ? a : b);
-                P.subset = order; P.trace = nullptr; P.out = out_dev; P.n = (uint32_t)n; P.k = k;
-                P.mc = 1; P.gc = 1; P.sg = 0; P.tc = trans ? 1 : 0;
-                P.u = bp8.u; P.o = 0; P.L = 1; P.PW = 64; P.lds_per_wave = bp8.lds_per_wave; P.Tw = bp8.Tw; P.ch = bp8.ch;
-                P.ckpt = (uint32_t *)cs.dev; P.ckpt_tiles = tiles;
-                TA_HIP(lev_bits_launch(P, bp8, trans, max_len, st, nullptr, nullptr));
-                ta_launch_info l0 = {};
-                ta_lev_select sel;
-                ta_levenshtein_select((size_t)max_len, (size_t)max_len, k, costs, &sel);
-                l0.cell_bits = sel.cell_bits; l0.transpose = trans;
-                g_last_launch = l0;
+        if (unit && (uint64_t)u + 1u + (trans ? 2u : 0u) <= 33u && max_len < (1ull << 29) /* a run's count has 29 bits */ && !env_int("TA_TRACE_NO_BITS") && !env_int("TA_NO_BITS")) {
+            // The kernel indexes its run lists with 32 bits (pair slot x runs_cap) and its scratch -- checkpoints, run lists, run counts -- is
+            // proportional to the pairs of a launch: a batch beyond either bound is worked through in chunks of whole wavefronts, each an
+            // ordinary sub-batch on the same stream (65M pairs at k = 32 wrapped the index; a huge batch asked for all of its
+            // scratch at once where the record path below chunks by free memory).  TA_TRACE_CHUNK_PAIRS=n pins the chunk (tests).
+            const uint32_t runs_cap = (uint32_t)(2 * max_len + 1 < 2ull * u + 2 ? 2 * max_len + 1 : 2ull * u + 2);
+            const uint64_t tiles16 = (max_len + 15) / 16 + 1;
+            const uint64_t per_pair = tiles16 * lev_bits_trace_ckpt_words(trans) * 4ull + (uint64_t)runs_cap * 4ull + 4ull + 8ull;
+            uint64_t chunk = 0xFFFFFFF0ull / (packed_dev ? (cap > runs_cap ? (uint64_t)cap : runs_cap) : (runs_cap ? runs_cap : 1u));
+            const uint64_t held = tls_scratch(9).cap + tls_scratch(8).cap + tls_scratch(7).cap;
+            if (per_pair * n > held && !stream_is_capturing(st)) {   // the scratch has to grow: not beyond half of what is free right now
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const uint64_t by_mem = (((uint64_t)free_b + held) / 2) / per_pair;
+                    if (by_mem < chunk) chunk = by_mem;
+                }
             }
-            ta_launch_info li = g_last_launch;                 // (the distance pass's: kernel 3)
-            uint32_t grid = 0, lds = 0;
-            TA_HIP(lev_bits_trace_launch(T, trans, fold, edits_dev, n_edits_dev, cap, st, &grid, &lds));
-            li.kernel = 8; li.diags_per_lane = 33; li.lanes_per_pair = 1; li.pairs_per_wave = 64; li.grid = grid; li.lds_bytes = lds;
-            g_last_launch = li;
+            if (env_int("TA_TRACE_CHUNK_PAIRS") > 0) chunk = (uint64_t)env_int("TA_TRACE_CHUNK_PAIRS");
+            chunk &= ~63ull;
+            if (chunk < 64) chunk = 64;
+            if (chunk >= n) return trace_bits_batch(a, b, n, k, costs, max_len, out_dev, edits_dev, n_edits_dev, cap, st, packed_dev);
+            for (uint64_t lo = 0; lo < n; lo += chunk) {
+                const size_t cnt = (size_t)((n - lo) < chunk ? (n - lo) : chunk);
+                const ta_strings sa = a->off ? ta_strings{a->blob, a->off + lo, 0, 0, max_len} : ta_strings{a->blob + lo * a->stride, nullptr, a->stride, a->len, a->len};
+                const ta_strings sb = b->off ? ta_strings{b->blob, b->off + lo, 0, 0, max_len} : ta_strings{b->blob + lo * b->stride, nullptr, b->stride, b->len, b->len};
+                if ((rc = trace_bits_batch(&sa, &sb, cnt, k, costs, max_len, out_dev + lo, edits_dev ? edits_dev + lo * cap : nullptr, n_edits_dev + lo, cap, st,
+                                           packed_dev ? packed_dev + lo * cap : nullptr))) return rc;
+            }
             return TA_OK;
         }
+    }
+    if (packed_dev) {
+        // the record routes write ta_edit records: sub-batches through a bounded ta_edit scratch (<= 256 MiB, whole wavefronts), packed as they come
+        // (the ta_edit form cuts a long script at its FRONT `cap` runs, the packed form keeps the LAST ones: the scratch takes whole scripts -- a
+        // script has at most n + m runs, and one of cost <= k at most 2 k + 1: every edit costs at least 1)
+        const uint64_t cap_in = 2ull * k + 1 < 2 * max_len + 2 ? 2ull * k + 1 : 2 * max_len + 2;
+        uint64_t chunk = (256ull << 20) / (cap_in * sizeof(ta_edit));
+        chunk &= ~63ull;
+        if (chunk < 64) chunk = 64;
+        if (chunk > n) chunk = n;
+        Scratch &es = tls_scratch(12);
+        if ((rc = es.ensure((size_t)(chunk * cap_in * sizeof(ta_edit))))) return rc;
+        for (uint64_t lo = 0; lo < n; lo += chunk) {
+            const size_t cnt = (size_t)((n - lo) < chunk ? (n - lo) : chunk);
+            const ta_strings sa = a->off ? ta_strings{a->blob, a->off + lo, 0, 0, max_len} : ta_strings{a->blob + lo * a->stride, nullptr, a->stride, a->len, a->len};
+            const ta_strings sb = b->off ? ta_strings{b->blob, b->off + lo, 0, 0, max_len} : ta_strings{b->blob + lo * b->stride, nullptr, b->stride, b->len, b->len};
+            if ((rc = trace_batch_impl(&sa, &sb, cnt, k, costs, out_dev + lo, (ta_edit *)es.dev, nullptr, n_edits_dev + lo, (size_t)cap_in, stream))) return rc;
+            TA_HIP(pack_edits_launch((const ta_edit *)es.dev, n_edits_dev + lo, (uint32_t)cnt, cap_in, packed_dev + lo * cap, cap, st));
+        }
+        return TA_OK;
     }
     // the trace kernels exist for 16, 34 and 66 diagonals per lane: the cheapest layout per pair that holds the band
     LevPlan pl = {};
@@ -1264,6 +1374,8 @@ int ta_levenshtein_trace_batch(const ta_strings *a, const ta_strings *b, size_t 
     set_last_kernel_name("lev_band_trace_kernel<%d, %s, %d>", pl.D, sg > 0 ? "true" : "false", costs->has_transpose ? 2 : 0);
     return TA_OK;
 }
+
+extern "C" {
 
 /* levenshtein_exp_with_opts(..., trace_on = true), src/levenshtein.rs:1480-1494 */
 int ta_levenshtein_exp_trace(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,

@@ -57,6 +57,7 @@ CallCtx &call_ctx();
 // stream -- the normal case -- are ordered by the stream itself and cost nothing extra.
 struct StreamGuard {
     hipStream_t st;
+    bool capturing = false, was_capturing = false;     // the stream is being captured into a graph (Scratch::ensure refuses to grow then)
     explicit StreamGuard(hipStream_t s);
     ~StreamGuard();
 };
@@ -112,6 +113,7 @@ hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool h
 hipError_t fill_u32_launch(uint32_t *p, uint32_t v, uint32_t n, hipStream_t st);   // p[0..n) = v, as a kernel (graph-safe)
 hipError_t compact_some_launch(const uint32_t *out, const uint32_t *subset_in, uint32_t n_in, uint32_t *subset_out, uint32_t *count /*device, pre-zeroed*/, hipStream_t st);
 hipError_t scale_results_launch(uint32_t *out, const uint32_t *list /*pairs, or nullptr: 0..n*/, uint32_t n, const uint32_t *n_dev, uint32_t g, hipStream_t st);
+hipError_t pack_edits_launch(const ta_edit *edits, const uint32_t *n_edits, uint32_t n, uint64_t cap_in, uint32_t *packed, uint64_t cap_out, hipStream_t st);
 hipError_t compact_bound_launch(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
                                 const uint32_t *n_in_dev, uint32_t *list_out, uint32_t *count, hipStream_t st);
 hipError_t bag_bound_launch(const StrView &a, const StrView &b, uint32_t n, uint32_t mc, uint32_t gc, uint32_t *bound, hipStream_t st);

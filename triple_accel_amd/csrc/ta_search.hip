@@ -301,7 +301,7 @@ static int hamming_search_dev_impl(const uint8_t *needle_host, size_t needle_len
     // needles of up to 64 bytes travel in the kernel arguments (SearchParams::needle): no upload
     // (the round-1 SWAR kernel -- needles beyond 64 bytes the phased filter does not take, or TA_HAMMING_SEARCH_SWAR=1 -- reads the device copy)
     P.needle_dev = nullptr;
-    if (needle_len > 64 || env_str("TA_HAMMING_SEARCH_SWAR")) {
+    if (needle_len > 64 || env_str("TA_HAMMING_SEARCH_SWAR") || (needle_len > 32 && tuning_enabled())) {   // (any A/B switch may route to the kernel that reads the device copy)
         Scratch &nd = tls_scratch(7);
         if ((rc = nd.ensure(needle_len + 16))) return rc;
         TA_HIP(hipMemcpyAsync(nd.dev, needle_host, needle_len, hipMemcpyHostToDevice, st));
@@ -422,7 +422,15 @@ static int give(std::vector<ta_match> &v, ta_match **out, size_t *n_out) {
 // over a big haystack, k >= needle_len) reports its true count, and the pass is repeated once with room for exactly that.
 // What ta_levenshtein_search_first left in this thread's haystack staging buffer (tls_scratch(TA_SLOT_SEARCH_HAY)): the first `upto` bytes of the caller's
 // haystack.  ta_levenshtein_search_resume -- "the rest of the All-mode result over THE SAME haystack" -- uploads only what is missing.
-struct ResidentHay { const uint8_t *host = nullptr; size_t len = 0; uint64_t upto = 0; const void *dev = nullptr; };
+struct ResidentHay { const uint8_t *host = nullptr; size_t len = 0; uint64_t upto = 0; const void *dev = nullptr; uint8_t fp[128] = {}; };
+// a content fingerprint of the uploaded prefix (its first and last 64 bytes): a caller that reuses the pointer for other bytes -- the C header
+// states the promise, only the Rust borrow enforces it -- degrades ta_levenshtein_search_resume to the plain call instead of wrong matches
+static void hay_fingerprint(const uint8_t *h, uint64_t upto, uint8_t *fp) {
+    memset(fp, 0, 128);
+    const size_t n = upto < 64 ? (size_t)upto : 64;
+    memcpy(fp, h, n);
+    memcpy(fp + 64, h + upto - n, n);
+}
 static ResidentHay &resident_hay() { static thread_local ResidentHay r; return r; }
 namespace ta { void search_resident_reset() { resident_hay() = ResidentHay{}; } }     // (ta_thread_release: the staging buffer is gone)
 static thread_local uint64_t g_resume_upto = 0;      // set by ta_levenshtein_search_resume around its call of the full search
@@ -628,7 +636,12 @@ int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const 
         if (from == upto) upto = to;                               // (the windows' uploads are consecutive)
         return (int)TA_OK;
     });
-    resident_hay() = rc == TA_OK ? ResidentHay{haystack, haystack_len, upto, hs.dev} : ResidentHay{};
+    resident_hay() = ResidentHay{};
+    if (rc == TA_OK && upto) {
+        ResidentHay &r = resident_hay();
+        r.host = haystack; r.len = haystack_len; r.upto = upto; r.dev = hs.dev;
+        hay_fingerprint(haystack, upto, r.fp);
+    }
     return rc;
 }
 
@@ -640,7 +653,12 @@ int ta_levenshtein_search_first(const uint8_t *needle, size_t needle_len, const 
 int ta_levenshtein_search_resume(const uint8_t *needle, size_t needle_len, const uint8_t *haystack, size_t haystack_len,
                                  uint32_t k, const ta_edit_costs *costs, int anchored, ta_match **out, size_t *n_out) {
     const ResidentHay r = resident_hay();
-    const uint64_t upto = (r.host == haystack && r.len == haystack_len && haystack_len) ? r.upto : 0;
+    uint64_t upto = (r.host == haystack && r.len == haystack_len && haystack_len) ? r.upto : 0;
+    if (upto) {                                                                  // same pointer, same length -- and still the same bytes?
+        uint8_t fp[128];
+        hay_fingerprint(haystack, upto, fp);
+        if (memcmp(fp, r.fp, 128) != 0) upto = 0;
+    }
     g_resume_upto = upto;
     const int rc = ta_levenshtein_search_simd_with_opts(needle, needle_len, haystack, haystack_len, k, TA_SEARCH_ALL, costs, anchored, out, n_out);
     g_resume_upto = 0;

@@ -147,6 +147,22 @@ hipError_t scale_results_launch(uint32_t *out, const uint32_t *list, uint32_t n,
     return hipGetLastError();
 }
 
+// ta_levenshtein_trace_batch_packed on the routes whose walk writes ta_edit records: pair i's first min(n_edits[i], cap_in) records -> one word
+// each ((edit << 29) | count), right-aligned in its slot of cap_out words (a script of more than cap_out runs keeps its last ones)
+__global__ void pack_edits_kernel(const ta_edit *edits, const uint32_t *n_edits, uint32_t n, uint64_t cap_in, uint32_t *packed, uint64_t cap_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t have = n_edits[i] < cap_in ? n_edits[i] : cap_in, keep = have < cap_out ? have : cap_out;
+    const ta_edit *src = edits + (uint64_t)i * cap_in + (have - keep);
+    uint32_t *dst = packed + ((uint64_t)i + 1u) * cap_out - keep;
+    for (uint64_t t = 0; t < keep; t++) dst[t] = (src[t].edit << 29) | (uint32_t)(src[t].count & 0x1FFFFFFFu);
+}
+hipError_t pack_edits_launch(const ta_edit *edits, const uint32_t *n_edits, uint32_t n, uint64_t cap_in, uint32_t *packed, uint64_t cap_out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_edits_kernel, dim3((n + 255) / 256), dim3(256), 0, st, edits, n_edits, n, cap_in, packed, cap_out);
+    return hipGetLastError();
+}
+
 // exp search with a lower bound: next round's work list = unresolved pairs whose bound admits the next threshold
 __global__ void compact_bound_kernel(const uint32_t *out, const uint32_t *bound, uint32_t k, const uint32_t *list_in, uint32_t n_in,
                                      const uint32_t *n_in_dev, uint32_t *list_out, uint32_t *count) {
