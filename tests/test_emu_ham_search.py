@@ -81,11 +81,12 @@ def test_bit_sliced_equals_oracle():
 
 
 def test_phase_plan_rules():
-    """(needle length, k) -> (phases per dword, positions counted, counter bits): the subset stays selective (L >= 2k, L - k >= 6) unless it
+    """(needle length, k) -> (phases per dword, positions counted, counter bits): the subset stays selective (L >= 2k, L - k >= 4) unless it
     is the whole needle; the BASELINE-style rows land where DESIGN says."""
     pl = lambda n, k: (E.ham_search_phase(bytes(range(1, n + 1)), bytes(300), k) or (None, None))[1]
     assert pl(32, 8) == (2, 16, 4) and pl(64, 16) == (1, 32, 5) and pl(32, 2) == (4, 8, 2) and pl(16, 2) == (2, 8, 2)
-    assert pl(64, 17) is None and pl(32, 20) == (1, 32, 5) and pl(32, 32) is None and pl(200, 3) == (2, 16, 2) and pl(200, 2) == (4, 8, 2) and pl(8, 2) == (1, 8, 2)
+    assert pl(64, 17) is None and pl(32, 20) == (1, 32, 5) and pl(32, 32) is None and pl(200, 3) == (4, 8, 2) and pl(200, 2) == (4, 8, 2) and pl(8, 2) == (1, 8, 2)
+    assert pl(16, 4) == (2, 8, 3) and pl(24, 6) == (2, 12, 3)          # (round 6: a 16-byte needle takes two phases of 8, not one of 16)
     for n in range(1, 80):
         for k in range(0, 32):
             p = pl(n, k)
@@ -93,7 +94,7 @@ def test_phase_plan_rules():
                 continue
             q, l, b = p
             assert k < n and (1 << b) - 1 >= k and q * l <= 32 and q * (l - 1) <= n - 1
-            assert (q == 1 and l == n) or (l >= 2 * k and l - k >= 6), (n, k, p)
+            assert (q == 1 and l == n) or (l >= 2 * k and l - k >= 4), (n, k, p)
 
 
 def test_phase_form_equals_oracle():

@@ -47,8 +47,10 @@ TA_HD inline HamPhaseGeom ham_phase_geom(uint32_t Q, uint32_t L) {
     return g;
 }
 // The plan for (needle length, k): Q phases of L positions and B counter bits; false where this form does not apply or does not pay.
-// Selectivity: the subset must still tell a hit from noise -- L >= 2 k and L - k >= 6 (random bytes pass a position with probability 1/256:
-// C(L, k) / 256^(L - k) false candidates per offset; a four-letter text passes 2.7 % of its offsets at L = 16, k = 8, each recounted).
+// Selectivity: the subset must still tell a hit from noise -- L >= 2 k and L - k >= 4 (random bytes pass a position with probability 1/256:
+// C(L, k) / 256^(L - k) false candidates per offset; a four-letter text passes 2.7 % of its offsets at L = 16, k = 8 and 11 % at L = 8, k = 4,
+// each recounted over the whole needle).  (Round 5 asked for L - k >= 6: a 16-byte needle with k = 4 then ran ONE phase of 16 positions at
+// 14 instructions per byte, 0.61 ms per GiB -- slower than a 32-byte needle's two phases at 0.49; with two phases of 8 it is 8 per byte.)
 // A filter over ALL positions (n <= 32, Q = 1) is exact and needs no margin.
 TA_HD inline bool ham_phase_plan(uint32_t n, uint32_t k, uint32_t &Q, uint32_t &L, int &B) {
     B = ham_bits_planes(k);
@@ -58,7 +60,7 @@ TA_HD inline bool ham_phase_plan(uint32_t n, uint32_t k, uint32_t &Q, uint32_t &
         uint32_t l = (n + q - 1u) / q;                       // Q (L - 1) <= n - 1
         if (l > w) l = w;
         const bool exact = q == 1u && l == n;
-        if (!exact && (l < 2u * k || l < k + 6u)) continue;
+        if (!exact && (l < 2u * k || l < k + 4u)) continue;
         Q = q; L = l;
         return true;
     }

@@ -81,7 +81,7 @@ struct LevBits {
         U32 AW[NA];             // byte i = a[row(i) - 1] ^ 0x0C, row(i) = j - d_hi + i: window bit i <-> byte i
         U32 PMp[NW], D0p[NW];   // TRANS: previous column's match vector and D0
         U32 acc;                // D0 of the window's top diagonal (bit 0), the last columns' bits from bit 31 down; zeros below them
-        U32 rD0, rBot;          // step8<.., REC>: the column's D0 (window bits 0..31) and the bottom diagonal's D0 in bit 0 (lev_bits_trace_body.h)
+        U32 rD0, rBot, rHP;     // step8<.., REC>: the column's D0 and its horizontal +1 steps HP (window bits 0..31), the bottom diagonal's D0 in bit 0 (lev_bits_trace_body.h)
     };
 
     // the window moves one row down: byte i <- byte i+1, the next byte of `a` enters on top
@@ -196,8 +196,8 @@ struct LevBits {
                 d0_bot = W::template byte_eq_or<(C & 3)>(a_raw, b_dw, cm);
             }
             st.acc = W::template alignbit<1>(CAP ? W::sel(live, D0, W::splat(0)) : D0, st.acc);
-            if (REC) { st.rD0 = D0; st.rBot = d0_bot; }
             const U32 HP = st.VN[0] | ~(D0 | st.VP[0]);
+            if (REC) { st.rD0 = D0; st.rBot = d0_bot; st.rHP = HP; }
             const U32 HN = D0 & st.VP[0];
             const U32 D0s = W::template alignbit<1>(d0_bot, D0);
             st.VP[0] = HN | ~(D0s | HP);

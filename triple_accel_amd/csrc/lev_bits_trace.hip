@@ -47,21 +47,23 @@ uint32_t lev_bits_trace_tile() {
 }
 static uint32_t lev_bits_trace_stile(uint32_t tile) {
     uint32_t st = 64u;
-    if (const char *e = env_str("TA_TRACE_STILE")) { const int v = atoi(e); if (v == 32 || v == 64) st = (uint32_t)v; }
+    if (const char *e = env_str("TA_TRACE_STILE")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) st = (uint32_t)v; }
     return st < tile ? tile : st;
 }
 
 // have_ckpt: the distance pass (lev_bits_s8_ckpt_kernel) left the checkpoints of tiles of 16 columns in P.ckpt: no forward sweep here
 hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool have_ckpt, ta_edit *edits, uint32_t *n_edits, uint64_t cap, hipStream_t s,
                                  uint32_t *grid_out, uint32_t *lds_out) {
-    const uint32_t waves = (P.n + 63u) / 64u, tile = have_ckpt ? 16u : lev_bits_trace_tile(), stile = lev_bits_trace_stile(tile);
+    const uint32_t waves = (P.n + 63u) / 64u, tile = have_ckpt ? 16u : lev_bits_trace_tile();
+    uint32_t stile = lev_bits_trace_stile(tile);
     if (grid_out) *grid_out = waves;
     if (waves == 0) return hipSuccess;
     if (have_ckpt) {
         set_last_kernel_name("lev_bits_trace_kernel<%s, 16, %u, true>", trans ? "true" : "false", stile);
 #define TA_BTC(T_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, 16, SL_, true>::LDS_PER_WAVE + 1024u * (uint32_t)env_int("TA_TRACE_LDS_PAD_KB"); if (lds_out) *lds_out = lds; \
         hipLaunchKernelGGL((lev_bits_trace_kernel<T_, 16, SL_, true>), dim3(waves), dim3(64), lds, s, P, edits, n_edits, cap); } while (0)
-        if (stile == 64u) { if (trans) TA_BTC(true, 64); else TA_BTC(false, 64); }
+        if (stile == 128u) { if (trans) TA_BTC(true, 128); else TA_BTC(false, 128); }      // (an A/B: every line of a string touched 2-3 times instead of 3-4, at 34 more VGPRs)
+        else if (stile == 64u) { if (trans) TA_BTC(true, 64); else TA_BTC(false, 64); }
         else { if (trans) TA_BTC(true, 32); else TA_BTC(false, 32); }
 #undef TA_BTC
         return hipGetLastError();
@@ -70,6 +72,7 @@ hipError_t lev_bits_trace_launch(const LevBitsTraceParams &P, bool trans, bool h
 #define TA_BT(T_, TL_, SL_) do { const uint32_t lds = LevBitsTrace<DevWave, T_, TL_, SL_>::LDS_PER_WAVE; if (lds_out) *lds_out = lds; \
         hipLaunchKernelGGL((lev_bits_trace_kernel<T_, TL_, SL_>), dim3(waves), dim3(64), lds, s, P, edits, n_edits, cap); } while (0)
 #define TA_BT2(TL_, SL_) do { if (trans) TA_BT(true, TL_, SL_); else TA_BT(false, TL_, SL_); } while (0)
+    if (stile > 64u) stile = 64u;                        // (128-column string tiles exist for the folded sweep only)
     if (tile == 8u) { if (stile == 64u) TA_BT2(8, 64); else TA_BT2(8, 32); }
     else if (tile == 16u) { if (stile == 64u) TA_BT2(16, 64); else TA_BT2(16, 32); }
     else TA_BT2(32, 64);

@@ -58,9 +58,15 @@ struct LevBitsTrace {
     // the walk's characters of ONE tile, per lane in LDS: XW dwords of a from first + TILE q, YW dwords of b from STILE T - 16 + TILE q
     static constexpr uint32_t XW = (TILE + 48) / 4, YW = (TILE + 16) / 4;
     static constexpr uint32_t WSLOT = 4 * (XW + YW) + (((XW + YW) % 2u) == 0u ? 4u : 0u);   // bytes per lane (an odd number of dwords)
-    // records, [word][lane]: pre-column VP / VN of columns 0 .. TILE (TILE = the column behind the tile), D0 of columns 0 .. TILE - 1,
-    // one word of bottom-diagonal D0 bits (bit c = column c), and for the transposition test the D0 of the column in front of the tile
-    static constexpr uint32_t R_VP = 0, R_VN = TILE + 1, R_D0 = 2 * (TILE + 1), R_BOT = R_D0 + TILE, R_D0P = R_BOT + 1, R_WORDS = R_D0P + 1;
+    // records, [word][lane]: D0 and HP (the horizontal +1 steps) of columns 0 .. TILE - 1, one word of bottom-diagonal D0 bits (bit c =
+    // column c), and for the transposition test the D0 of the column in front of the tile.  Two words per column are all the walk needs:
+    // with V = D[i][j] the scalar routine's candidates are sub = D[i-1][j-1] + (x != y), a_gap = D[i][j-1] + 1, b_gap = D[i-1][j] + 1 and
+    // V is their minimum, so  D0 = 0 (V = diag + 1)  or  x == y (then D0 = 1, sub = V)  =>  the diagonal, whatever the gaps cost (ties go to
+    // it, :493-515);  D0 = 1 and x != y (sub = V + 1)  =>  a gap: the left one iff D[i][j-1] = V - 1, i.e. HP, else the upper one (left wins
+    // their tie);  the transposition (:517-532, taken on `<=`) iff its characters fit and D[i-2][j-2] + 1 = V, i.e. not both D0(i, j) and
+    // D0(i-1, j-1).  (Round 5 kept the vertical differences VP / VN of every column too: 52 words per lane and tile instead of 34 -- 19.7 KB
+    // of LDS per wavefront, 8 wavefronts per CU; now 15.1 KB and 10.)
+    static constexpr uint32_t R_D0 = 0, R_HP = TILE, R_BOT = 2 * TILE, R_D0P = R_BOT + 1, R_WORDS = R_D0P + 1;
     static constexpr uint32_t REC_BYTES = 64 * 4 * R_WORDS > 64 * BOUNCE ? 64 * 4 * R_WORDS : 64 * BOUNCE;
     static constexpr uint32_t LDS_PER_WAVE = 64 * WSLOT + REC_BYTES;
     template <uint32_t N> using IC = std::integral_constant<uint32_t, N>;
@@ -173,9 +179,8 @@ struct LevBitsTrace {
             const Bool all = (lane == lane);
             U32 bot = W::splat(0);
 #define TA_TR_STEP(C_, bw, rw, xw)                                                                              \
-                if (REC) { W::lds_write32(rec, raddr(R_VP + c + C_), st.VP[0]); W::lds_write32(rec, raddr(R_VN + c + C_), st.VN[0]); } \
                 K::template step8<false, C_, true, REC>(st, bw, rw, xw, all);                                         \
-                if (REC) { W::lds_write32(rec, raddr(R_D0 + c + C_), st.rD0); bot = bot | W::shlv(st.rBot & 1u, W::splat(c + C_)); }
+                if (REC) { W::lds_write32(rec, raddr(R_D0 + c + C_), st.rD0); W::lds_write32(rec, raddr(R_HP + c + C_), st.rHP); bot = bot | W::shlv(st.rBot & 1u, W::splat(c + C_)); }
 #define TA_TR_BLOCK(CB_)                                                                                         \
             if ((uint32_t)TILE > CB_) {                                                                          \
                 constexpr uint32_t c = CB_, ia = 11u + ((uint32_t)TILE * q + c) / 4u, ib = 4u + ((uint32_t)TILE * q + c) / 4u;   \
@@ -222,9 +227,7 @@ struct LevBitsTrace {
         // ---- F: forwards, a checkpoint in front of every tile (HAVE_CKPT: the distance pass did it; the state behind the last tile is its
         // last checkpoint)
         init_state();
-        if (HAVE_CKPT) {
-            fetch_ckpt(tiles); take_ckpt();
-        } else {
+        if (!HAVE_CKPT) {
             for (uint32_t t = 0; t < tiles; t++) {
                 if (t % RT == 0u) load_strings(t / RT);
                 for_q(t % RT, [&](auto qc) {
@@ -249,7 +252,6 @@ struct LevBitsTrace {
             cnt = W::sel(same, cnt + r, W::sel(on, r, cnt));
             cur = W::sel(on, e, cur);
         };
-        U32 nxt_vp = st.VP[0], nxt_vn = st.VN[0];                          // the pre-state of the column behind the last tile
         uint32_t t = tiles;
         auto do_tile = [&](uint32_t q) {                                    // tile t = RT T + q
             const uint32_t j_lo = (uint32_t)TILE * t;                       // the tile's columns: j_lo + 1 .. j_lo + TILE
@@ -257,9 +259,7 @@ struct LevBitsTrace {
             if (t > 0u) fetch_ckpt(t - 1u);
             for_q(q, [&](auto qc) {
                 rebuild_window(qc);
-                W::lds_write32(rec, raddr(R_D0P), TRANS ? st.D0p[0] : W::splat(0));
-                W::lds_write32(rec, raddr(R_VP + TILE), nxt_vp); W::lds_write32(rec, raddr(R_VN + TILE), nxt_vn);
-                nxt_vp = st.VP[0]; nxt_vn = st.VN[0];                      // (this tile's first pre-state is the tile before's "behind")
+                if (TRANS) W::lds_write32(rec, raddr(R_D0P), st.D0p[0]);
                 stage_walk(qc);
                 run_tile(qc, std::true_type());
             });
@@ -284,41 +284,30 @@ struct LevBitsTrace {
                 const U32 xo = wlane + W::sel(act, (i - 1u) - xbase, W::splat(12)), yo = wlane + 4u * XW + W::sel(act, (j - 1u) - ybase, W::splat(12));
                 const U32 X2 = W::lds_read32u(lds, xo - 3u), X1 = W::lds_read32u(lds, xo - 7u), X0 = W::lds_read32u(lds, xo - 11u);    // x[i-4..i-1], x[i-8..i-5], x[i-12..i-9]
                 const U32 Y2 = W::lds_read32u(lds, yo - 3u), Y1 = W::lds_read32u(lds, yo - 7u), Y0 = W::lds_read32u(lds, yo - 11u);
-                const U32 d0w = W::lds_read32(rec, raddr_v(c + R_D0)), botw = W::lds_read32(rec, raddr(R_BOT));
-                const U32 vp1 = W::lds_read32(rec, raddr_v(c + (R_VP + 1u))), vn1 = W::lds_read32(rec, raddr_v(c + (R_VN + 1u)));
-                const U32 vp0 = W::lds_read32(rec, raddr_v(c + R_VP)), vn0 = W::lds_read32(rec, raddr_v(c + R_VN));
+                const U32 d0w = W::lds_read32(rec, raddr_v(c + R_D0)), hpw = W::lds_read32(rec, raddr_v(c + R_HP)), botw = W::lds_read32(rec, raddr(R_BOT));
                 const Bool first_col = c == 0u;
                 const U32 d0m = TRANS ? W::lds_read32(rec, raddr_v(W::sel(first_col, W::splat(R_D0P), c + (R_D0 - 1u)))) : W::splat(0);
-                const U32 d0 = W::sel(bi >= 32u, W::shrv(botw, c), W::shrv(d0w, bi)) & 1u;
-                // v(i, j): the pre-state of column j + 1 at bit bi - 1 (bi = 0: the row above is outside the window)
-                const Bool up_ok = bi >= 1u;
-                const U32 sh1 = W::sel(up_ok, bi - 1u, W::splat(0));
-                const U32 v_ij = (W::shrv(vp1, sh1) & 1u) - (W::shrv(vn1, sh1) & 1u);
-                // v(i, j - 1): the pre-state of column j at bit bi (bi = 32: the bottom diagonal has no left neighbour)
-                const Bool left_ok = bi <= 31u;
-                const U32 sh0 = W::sel(left_ok, bi, W::splat(0));
-                const U32 v_l = (W::shrv(vp0, sh0) & 1u) - (W::shrv(vn0, sh0) & 1u);
-                // values relative to V = D[i][j], biased by BIAS so that they stay unsigned
-                constexpr uint32_t BIAS = 8u, INF = 64u;
-                const U32 diag = W::splat(BIAS) - (d0 ^ 1u);
-                const U32 up = W::sel(up_ok, W::splat(BIAS) - v_ij, W::splat(INF));
-                const U32 left = W::sel(left_ok, diag + v_l, W::splat(INF));
+                const Bool bottom = bi >= 32u;                             // the 33rd diagonal: no left neighbour inside the band
+                const Bool top = bi == 0u;                                 // the band's first diagonal: no upper neighbour
+                const U32 sh0 = W::sel(bottom, W::splat(0), bi);
+                const Bool d0 = (W::sel(bottom, W::shrv(botw, c), W::shrv(d0w, sh0)) & 1u) != 0u;
+                const Bool hp = (!bottom) & ((W::shrv(hpw, sh0) & 1u) != 0u);
                 const U32 x1 = X2 >> 24, y1 = Y2 >> 24;                     // x[i - 1], y[j - 1]
-                const U32 sub = diag + W::sel(x1 == y1, W::splat(0), W::splat(1)), ag = left + 1u, bg = up + 1u;
-                const U32 m1 = W::umin(sub, ag);
-                U32 code = W::sel(bg < m1, W::splat(2), W::sel(ag < sub, W::splat(1), W::splat(0)));      // :493-515
+                const Bool eq = x1 == y1;
+                // :493-515 (see R_D0 above): the diagonal unless D0 and a mismatch; then left iff HP, else up (a gap that would leave the band
+                // cannot be the minimum: the diagonal stands, as the scalar routine's INF makes it)
+                const Bool gap = d0 & (!eq);
+                U32 code = W::sel(gap & hp, W::splat(1), W::sel(gap & (!top), W::splat(2), W::splat(0)));
                 if (TRANS) {
                     const U32 x2 = (X2 >> 16) & 255u, y2 = (Y2 >> 16) & 255u;                               // x[i - 2], y[j - 2]
                     const Bool tt = (i > 1u) & (j > 1u) & (x1 == y2) & (x2 == y1);                           // :517-532
-                    // D[i-2][j-2] = D0(i-1, j-1) ? diag : diag - 1; (i-1, j-1) is window bit bi of column j - 1
+                    // D0(i-1, j-1): window bit bi of column j - 1 (the bottom bit of the column in front of the tile is not kept: a band-edge cell)
                     const U32 botm = W::sel(first_col, W::splat(0), W::shrv(botw, W::sel(first_col, W::splat(0), c - 1u)));
-                    const U32 d0p = W::sel(bi >= 32u, botm, W::shrv(d0m, sh0)) & 1u;
-                    const Bool dd_ok = (bi <= 31u) | !first_col;          // (the bottom bit of the column in front of the tile is not kept: a band-edge cell)
-                    const U32 tval = W::sel(dd_ok, (diag - (d0p ^ 1u)) + 1u, W::splat(INF));
-                    const U32 nv = W::umin(bg, m1);
-                    code = W::sel(tt & (tval <= nv), W::splat(3), code);
+                    const Bool d0p = (W::sel(bottom, botm, W::shrv(d0m, sh0)) & 1u) != 0u;
+                    const Bool dd_ok = (!bottom) | (!first_col);
+                    code = W::sel(tt & dd_ok & (!(d0 & d0p)), W::splat(3), code);                              // D[i-2][j-2] + 1 = V
                 }
-                note(W::sel(code == 0u, W::sel(x1 == y1, W::splat(0), W::splat(1)), W::sel(code == 1u, e_left, W::sel(code == 2u, e_up, W::splat(4)))), W::splat(1), act);
+                note(W::sel(code == 0u, W::sel(eq, W::splat(0), W::splat(1)), W::sel(code == 1u, e_left, W::sel(code == 2u, e_up, W::splat(4)))), W::splat(1), act);
                 const U32 two = W::sel(code == 3u, W::splat(2), W::splat(1));
                 const U32 di = W::sel(code != 1u, two, W::splat(0)), dj = W::sel(code != 2u, two, W::splat(0));
                 const U32 i1 = i - di, j1 = j - dj;

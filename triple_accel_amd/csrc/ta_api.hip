@@ -652,6 +652,15 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
     uint32_t *sub_in = nullptr, *bufs[2] = {(uint32_t *)s0.dev, (uint32_t *)s1.dev};
     uint32_t n_left = (uint32_t)n;                          // unresolved pairs (sub_in == nullptr: all of them)
     uint32_t k = 30;                                        // src/levenshtein.rs:1446, 1486, 1517
+    // The FIRST threshold as wide as the cheapest kernel's window: the stride-8 form holds 33 diagonals whatever k <= 32 asks for (31 with the
+    // transposition term's two extra ones: k = 30), so unit costs start at k = 32 (g x unit costs: 32 g) for the price of 30 -- a pair at distance
+    // 31 or 32 is answered by the first round instead of the 61-diagonal one (cfg3 on similar strings: 32 substitutions per pair; 2.29 -> 0.9 ms per
+    // 100K pairs).  levenshtein_exp returns the distance: any schedule of thresholds finds the same value (:1445-1454); from the second round on
+    // the reference's 60, 120, ... stand.  TA_EXP_FAITHFUL=1 keeps 30.
+    uint32_t k_first = 30;
+    if (!env_int("TA_EXP_FAITHFUL") && !costs->has_transpose && costs->start_gap_cost == 0 && costs->mismatch_cost == costs->gap_cost)
+        k_first = 32u * costs->gap_cost;                    // (gap_cost <= 255: no overflow)
+    k = k_first;
     // ragged (CSR) batches: the rounds take their pairs in length order, as ta_levenshtein_k_batch does (the list of the still
     // unresolved pairs is compacted from the ordered one, which keeps it ordered block by block)
     if ((a->off || b->off) && n >= 4096 && max_len >= 16 && !env_int("TA_NO_LENGTH_ORDER")) {
@@ -698,7 +707,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
             sub_in = bufs[flip];
             n_in_dev = counters + 2 * round + 1;
             flip ^= 1;
-            k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;    // k *= 2 (:1452); saturate instead of wrapping
+            k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : (round == 0 && k == k_first && k_first != 30u ? 60u * costs->gap_cost : k * 2);    // k *= 2 (:1452); saturate instead of wrapping
         }
         g_answer_single_store = false;
         return TA_OK;
@@ -737,7 +746,7 @@ int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
             flip ^= 1;
             n_left = left;
         }
-        k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : k * 2;        // k *= 2 (:1452); saturate instead of wrapping
+        k = (k > 0x7FFFFFFFu) ? 0xFFFFFFFFu : (round == 0 && k == k_first && k_first != 30u ? 60u * costs->gap_cost : k * 2);        // k *= 2 (:1452); saturate instead of wrapping
     }
     return TA_OK;
 }
