@@ -404,7 +404,7 @@ def test_hamming_search_forms_and_fused_nul_scan(monkeypatch):
     hay_np[hay_np == 0] = 1
     for n, k, kern in [(4, 1, "swar16"), (8, 2, "swar16"), (12, 3, "phase_kernel<1,2>"), (16, 7, "phase_kernel<1,3>"), (16, 8, "swar16"),
                        (24, 6, "phase_kernel<2,3>"), (32, 8, "phase_kernel<2,4>"), (32, 2, "phase_kernel<4,2>"), (32, 31, "phase_kernel<1,5>"),
-                       (32, 32, "swar16"), (40, 9, "phase_kernel<1,4>"), (64, 16, "phase_kernel<1,5>"), (64, 20, "swar16"), (9, 1, "phase_kernel<1,1>"),
+                       (32, 32, "swar16"), (40, 9, "phase_kernel<1,4>"), (64, 16, "phase_kernel<1,5>"), (64, 20, "swar16"), (9, 1, "phase_kernel<2,1>"), (16, 4, "phase_kernel<2,3>"),
                        (70, 10, "phase_kernel<1,4>"), (300, 40, "hamming_search_kernel")]:
         needle = bytes(int(c) or 1 for c in Dg.random_bytes(g, n))
         hay = hay_np.copy()
