@@ -994,7 +994,10 @@ def main():
     evaluated_value = value * evaluated_unit / cells_unit if evaluated_unit else None
     line = {
         "metric": "GCUPS (DP cell updates/s) for k-banded Levenshtein, 1M x 256B pairs" if wl == "cfg2" else "GCUPS (%s)" % wl,
-        "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
+        "value": value, "unit": "GCUPS",
+        "value_is": ("weak scaling: every GPU its own batch of the configured size (%d units in all); the SAME batch split over the GPUs is `strong_scaling`" % all_units)
+                    if (world > 1 and not strong) else ("strong scaling: ONE batch of the configured size split over the GPUs" if world > 1 else "one GPU"),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
         "prewarm_passes": n_ramp,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",

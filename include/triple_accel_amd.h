@@ -245,7 +245,11 @@ int ta_levenshtein_k_batch_alphabet(const ta_strings *a, const ta_strings *b, si
 /* N x levenshtein_exp_with_opts(a_i, b_i, false, costs): doubling k from 30 over the still-unresolved
  * subset (src/levenshtein.rs:1480-1494).  Batches of >= 1024 pairs: the whole k schedule is enqueued at once -- every list's length stays on
  * the device -- and the call returns without synchronising (capturable in a graph; a CSR side with max_len = 0 costs one synchronisation to
- * measure it).  Smaller batches synchronise the stream between rounds. */
+ * measure it).  Smaller batches synchronise the stream between rounds.  The device-driven rounds size every launch for the whole batch (a list's
+ * length is only known on the device): a round whose list is short or empty still costs its launches (10-15 us each) and takes the kernel the
+ * batch size suggests -- a batch where a handful of long pairs survive to the unbounded pass pays for that; TA_EXP_HOST_ROUNDS=1 (TA_TUNING) keeps
+ * the host-driven loop, which sizes every round for the pairs that are left.  The first threshold is the widest the cheapest kernel's window
+ * holds (k = 32 for LEVENSHTEIN_COSTS: the price of 30), then the reference's 60, 120, ...: the returned distances do not depend on the schedule. */
 int ta_levenshtein_exp_batch(const ta_strings *a, const ta_strings *b, size_t n,
                              const ta_edit_costs *costs, uint32_t *out_dev, void *stream);
 /* Batch form of ta_levenshtein_trace (no reference analogue: the reference's trace_on is per call, src/levenshtein.rs:714-720, :561-606):
