@@ -138,6 +138,35 @@ inline std::vector<std::optional<std::uint32_t>> levenshtein_simd_k_with_opts_ma
     if (pending) { auto r = q.flush(); out.insert(out.end(), r.begin(), r.end()); }
     return out;
 }
+// The device set (include/triple_accel_amd.h): the GPUs the host entry points fan out over (empty: every visible device, the default).  With
+// more than one entry the *_many / *_slices functions, Queue::flush and the searches over haystacks of >= 8 MiB are partitioned inside the library.
+inline void set_devices(const std::vector<int> &devices) { check_(ta_set_devices(devices.empty() ? nullptr : devices.data(), devices.size())); }
+inline std::vector<int> get_devices() {
+    std::size_t n = 0;
+    check_(ta_get_devices(nullptr, 0, &n));
+    std::vector<int> v(n);
+    check_(ta_get_devices(v.data(), n, &n));
+    return v;
+}
+// pairs that already sit in memory: gathered into one CSR blob per side and handed to the host-pointer batch entry (no queue copy)
+inline std::vector<std::optional<std::uint32_t>> levenshtein_simd_k_with_opts_slices(const std::vector<std::pair<bytes, bytes>> &pairs, std::uint32_t k,
+                                                                                     const EditCosts &costs) {
+    std::vector<std::uint8_t> blob[2];
+    std::vector<std::uint64_t> off[2] = {{0}, {0}};
+    for (const auto &pr : pairs) {
+        blob[0].insert(blob[0].end(), pr.first.begin(), pr.first.end());
+        blob[1].insert(blob[1].end(), pr.second.begin(), pr.second.end());
+        off[0].push_back(blob[0].size());
+        off[1].push_back(blob[1].size());
+    }
+    const ta_strings a = {blob[0].data(), off[0].data(), 0, 0, 0}, b = {blob[1].data(), off[1].data(), 0, 0, 0};
+    std::vector<std::uint32_t> out(pairs.size());
+    check_(ta_levenshtein_k_batch_host(&a, &b, pairs.size(), k, costs.raw(), out.data()));
+    std::vector<std::optional<std::uint32_t>> v;
+    v.reserve(out.size());
+    for (std::uint32_t d : out) v.push_back(opt_(d));
+    return v;
+}
 // `.next()` on the reference's lazy All-mode iterator (src/levenshtein.rs:2282-2420): the first match, found without scanning the rest
 inline std::optional<Match> levenshtein_search_first(bytes needle, bytes haystack, std::uint32_t k, const EditCosts &costs, bool anchored) {
     ta_match m; int found = 0;

@@ -45,6 +45,14 @@ int main(int argc, char **argv) {
     CHECK(ta::levenshtein_exp(B("abc"), B("abcd")) == 1);
     CHECK(ta::rdamerau_exp(B("abc"), B("acb")) == 1);
     CHECK(ta::levenshtein_simd_k(B("abc"), B("ab"), 1).value() == 1);
+    {   // the device set: device 0 listed three times -- the host-pointer batch entry shards the pairs over three workers
+        ta::set_devices({0, 0, 0});
+        CHECK(ta::get_devices().size() == 3);
+        const auto r = ta::levenshtein_simd_k_with_opts_slices({{B("kitten"), B("sitting")}, {B("abc"), B("abd")}, {B(""), B("xy")}, {B("abcdefgh"), B("zzzzzzzz")}}, 3, ta::LEVENSHTEIN_COSTS);
+        CHECK(r.size() == 4 && r[0].value() == 3 && r[1].value() == 1 && r[2].value() == 2 && !r[3].has_value());
+        ta::set_devices({});
+        CHECK(ta::get_devices().size() >= 1);
+    }
     CHECK(!ta::levenshtein_simd_k(B("abcdef"), B("uvwxyz"), 3).has_value());
     auto r = ta::levenshtein_simd_k_with_opts(B("abc"), B("ab"), 1, true, ta::LEVENSHTEIN_COSTS);
     CHECK(r.has_value() && r->first == 1 && r->second.has_value());

@@ -79,7 +79,13 @@ hipError_t lev_band_trace_launch(const LevParams &P, const LevPlan &pl, bool aff
                   else hipLaunchKernelGGL((lev_band_trace_kernel<D_, true, 0>), g, b, lds, s, P); } \
     else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 2>), g, b, lds, s, P); \
            else hipLaunchKernelGGL((lev_band_trace_kernel<D_, false, 0>), g, b, lds, s, P); }
-    if (pl.D == 16) { TA_T(16) }
+    if (pl.D == 16 && pl.L == 1 && !env_int("TA_TRACE_NO_L1")) {    // a band of up to 16 diagonals in one lane: the L1 instantiation, as for 34 (round 6: the generic one spent 247 instructions per iteration on 16 cells)
+        if (affine) { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<16, true, 2, true>), g, b, lds, s, P);
+                      else hipLaunchKernelGGL((lev_band_trace_kernel<16, true, 0, true>), g, b, lds, s, P); }
+        else { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<16, false, 2, true>), g, b, lds, s, P);
+               else hipLaunchKernelGGL((lev_band_trace_kernel<16, false, 0, true>), g, b, lds, s, P); }
+    }
+    else if (pl.D == 16) { TA_T(16) }
     else if (pl.D == 34 && pl.L == 1) {                      // the batch layout: the whole band in one lane -- no neighbour traffic (L1)
         if (affine) { if (trans) hipLaunchKernelGGL((lev_band_trace_kernel<34, true, 2, true>), g, b, lds, s, P);
                       else hipLaunchKernelGGL((lev_band_trace_kernel<34, true, 0, true>), g, b, lds, s, P); }
@@ -125,7 +131,9 @@ __global__ __launch_bounds__(64) void lev_trace_walk_kernel(StrView a, StrView b
     const uint32_t o_pair = (uint32_t)tb | 1u;
     const uint32_t *tr = trace + (uint64_t)blockIdx.x * wave_words;
     const uint32_t lane0 = lane * L;
-    uint32_t *my_path = path + (uint64_t)(mine ? idx : 0u) * path_words;
+    // the path words of the chunk's pairs are interleaved: word w of pair idx at path[w * pitch + idx] (lev_trace_emit.h)
+    const uint64_t pitch = (uint64_t)gridDim.x * PW;
+    uint32_t *my_path = path + (mine ? idx : 0u);
     // ---- phase A: backwards through the records, window by window
     uint32_t i = some ? (uint32_t)n : 0u, j = some ? (uint32_t)m : 0u, steps = 0, acc = 0;
     uint32_t top = (i + j) ? (i + j - 1u) >> 1 : 0u;
@@ -150,15 +158,18 @@ __global__ __launch_bounds__(64) void lev_trace_walk_kernel(StrView a, StrView b
             const uint32_t code = (word >> ((2u * c) & 31u)) & 3u;
             if (code == 0u) { i--; j--; } else if (code == 1u) { j--; } else if (code == 2u) { i--; } else { i -= 2u; j -= 2u; }
             acc |= code << (2u * (steps & 15u));
-            if ((steps & 15u) == 15u) { my_path[steps >> 4] = acc; acc = 0; }
+            if ((steps & 15u) == 15u) { my_path[(uint64_t)(steps >> 4) * pitch] = acc; acc = 0; }
             steps++;
         }
         if (lo == 0u) break;
     }
+    __syncthreads();                                           // (phase B reuses the rows' LDS for the lanes' string slots)
     if (!some) return;
-    if (steps & 15u) my_path[steps >> 4] = acc;
-    // ---- phase B: the path forwards, runs written as they close (lev_trace_emit.h)
-    n_edits[pair] = trace_emit_runs(my_path, steps, x, y, swap, edits + (uint64_t)pair * cap, cap);
+    if (steps & 15u) my_path[(uint64_t)(steps >> 4) * pitch] = acc;
+    if (cap == 0) return;                                      // (a timing probe, TA_TRACE_SKIP_EMIT=1: the walk without its replay -- no scripts)
+    // ---- phase B: the path forwards, runs written as they close (lev_trace_emit.h); the strings 64 bytes at a time through the lane's LDS slots
+    uint8_t *xs = (uint8_t *)rows + lane * TRACE_EMIT_SLOT, *ys = (uint8_t *)rows + (64u + lane) * TRACE_EMIT_SLOT;
+    n_edits[pair] = trace_emit_runs_lds(my_path, pitch, steps, x, (uint32_t)n, y, (uint32_t)m, swap, edits + (uint64_t)pair * cap, cap, xs, ys);
 }
 
 // a chunk of a batch: pairs [pair_base, pair_base + n_chunk) through the trace kernel (records into `trace`), then the walk
@@ -169,8 +180,10 @@ hipError_t lev_band_trace_batch_launch(const LevParams &P, const LevPlan &pl, bo
     if (e != hipSuccess) return e;
     const uint32_t tw = (uint32_t)lev_trace_words(pl.D), waves = (P.n + pl.PW - 1) / pl.PW;
     const uint32_t win = tw >= 4u ? 4u : 16u / tw;                     // <= 8 KB of rows per wavefront: twenty of them per CU
-    hipLaunchKernelGGL(lev_trace_walk_kernel, dim3(waves), dim3(64), (size_t)win * 2u * 64u * tw * 4u, s, P.a, P.b, P.out, P.trace, P.trace_wave_words,
-                       (uint32_t)pl.D, pl.L, pl.PW, tw, pl.u, P.pair_base, P.n, win, edits, n_edits, cap, path, path_words);
+    size_t walk_lds = (size_t)win * 2u * 64u * tw * 4u;
+    if (walk_lds < 2u * 64u * TRACE_EMIT_SLOT) walk_lds = 2u * 64u * TRACE_EMIT_SLOT;    // (the replay's string slots live in the same bytes)
+    hipLaunchKernelGGL(lev_trace_walk_kernel, dim3(waves), dim3(64), walk_lds, s, P.a, P.b, P.out, P.trace, P.trace_wave_words,
+                       (uint32_t)pl.D, pl.L, pl.PW, tw, pl.u, P.pair_base, P.n, win, edits, n_edits, env_int("TA_TRACE_SKIP_EMIT") ? 0ull : cap, path, path_words);
     return hipGetLastError();
 }
 
