@@ -50,7 +50,7 @@ def main():
     for nm in names:
         shutil.rmtree(tmp, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + SETS[nm].split() + ["-d", tmp, "-o", "p", "-f", "csv", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu", "--no-pmc", "--no-all-configs", "--no-side-batch"] + args.extra.split()
+               os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu", "--no-pmc", "--no-all-configs", "--no-side-batch"] + ([] if "--prewarm-ms" in args.extra else ["--prewarm-ms", "0"]) + args.extra.split()
         r = subprocess.run(cmd, cwd="/tmp", capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"))
         files = glob.glob(tmp + "/**/p_counter_collection.csv", recursive=True)
         if r.returncode != 0 or not files:
