@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 D = os.path.join(ROOT, "profiles", RND)
 
 
@@ -52,7 +52,7 @@ def main():
     out += ["| config | GCUPS credited | GCUPS evaluated | ms / pass (wall, driver protocol) | device ms / pass | algorithmic GB/s | % of 8 TB/s | fabric-side bytes / algorithmic | "
             "VALU instr / launch | cycles / VALU instr | of the 2-cycle ceiling | of the measured mixed-stream rate | files |", "|" + "---|" * 13]
     for wl in ("cfg2", "cfg2_mutated", "cfg4", "cfg4_mutated", "cfg3", "cfg3_mutated", "cfg3_mutated_host_rounds", "cfg5", "cfg5w_220", "cfg5w_231", "cfg5w_2213", "cfg5w_1101",
-               "cfg5w_231_nofilter", "cfg1", "cfg2w", "cfg2w_prefilter", "cfg2w_mutated", "cfg2w_mutated_prefilter", "cfg4w", "cfg4w_prefilter", "cfg2l", "cfg2s", "cfg2t", "cfg2t_own_sweep", "cfg2t_dp",
+               "cfg5w_231_nofilter", "cfg1", "cfg2w", "cfg2w_prefilter", "cfg2w_mutated", "cfg2w_mutated_prefilter", "cfg4w", "cfg4w_prefilter", "cfg2l", "cfg2s", "cfg2t", "cfg2tp", "cfg2tp_stile128", "cfg2t_220", "cfg2tp_220", "cfg2t_231", "cfg2t_2213", "cfg2t_own_sweep", "cfg2t_dp",
                "cfg2_ragged", "cfg2_ragged_vline", "cfg2_dna",
                "cfg2_dna5", "cfg2_protein_table", "hsearch8", "hsearch16", "hsearch32", "hsearch32_r04", "hsearch64", "hsearch64_r04", "cfg2_early_out", "cfg2_2m"):
         b = J("bench_%s.json" % wl)
@@ -86,6 +86,43 @@ def main():
             "(TA_SEARCH_NOWFILTER=1, an A/B row); cfgNw_prefilter / cfg2w_mutated_prefilter: ta_set_option(TA_OPT_UNIT_PREFILTER) -- same answers, data-dependent work, NOT a "
             "headline figure; cfg2t: the checkpoint-and-recompute kernel, its forward sweep done by the distance pass (cfg2t_own_sweep: the trace kernel's own forward sweep, TA_TRACE_OWN_SWEEP=1; cfg2t_dp: the DP kernel's records, TA_TRACE_NO_BITS=1: A/B rows); hsearchN_r04: round 4's routing "
             "(TA_HAMMING_SEARCH_NO_PHASE=1, A/B rows).)", ""]
+    out += ["(Round 6: cfg2tp: cfg2t with PACKED records (ta_levenshtein_trace_batch_packed: 4-byte runs written in place by the walk); cfg2tp_stile128: the same with 128 columns per "
+            "string fetch (TA_TRACE_STILE=128, an A/B row); cfg2t_220 / cfg2tp_220: EditCosts(2,2,0,None) -- unit costs x 2 on the checkpoint route with k / 2; cfg2t_231 / cfg2t_2213: "
+            "EditCosts(2,3,1,None) / (2,2,1,Some(3)), k = 32 -- the DP band kernel's records + the walk kernel; cfg2t_dp: unit costs forced through that route; cfg3_mutated: the first "
+            "threshold is the stride-8 window's k = 32.)", ""]
+    b2 = J("bench_cfg2.json")
+    if b2 and b2.get("all_configs"):
+        out += ["## The driver's one line: every BASELINE config (`bench_cfg2.json` `all_configs`; each leg its own bench.py process behind its own parity gate, %s s in all)" % b2.get("all_configs_seconds"), "",
+                "| workload | ms / pass | GCUPS | % of 8 TB/s | cycles per VALU instr | fabric-side / algorithmic | parity: answers that were numbers | kernel |", "|" + "---|" * 8]
+        for r in b2["all_configs"]:
+            if "error" in r:
+                out.append("| %s | FAILED: %s |" % (r["workload"], r["error"][:120]))
+                continue
+            f = lambda v, fmt: (fmt % v) if v is not None else "—"
+            out.append("| %s | %.4f | %.0f | %.1f %% | %s | %s | %s | `%s`%s |" % (r["workload"][:80], r["ms_per_step"], r["value"], 100 * r["roofline_frac"], f(r.get("cycles_per_valu_inst"), "%.2f"),
+                                                                                 f(r.get("traffic_ratio"), "%.2f"), r.get("parity_checked_some"), r.get("kernel_name"), " — " + r["note"] if r.get("note") else ""))
+        out.append("")
+    ov = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg2w", "cfg4w", "cfg2l", "cfg2s")]
+    if any(b and b.get("overlapped_passes") for _, b in ov):
+        out += ["## Consecutive passes on two streams (`overlapped_passes`: disclosed, never the headline -- DESIGN.md section 8, round 6 item 7)", "",
+                "| config | device ms / pass, one stream | two streams | GCUPS credited, two streams |", "|---|---|---|---|"]
+        for wl, b in ov:
+            if b and b.get("overlapped_passes"):
+                o = b["overlapped_passes"]
+                out.append("| %s | %.4f | %.4f | %.0f |" % (wl, b["roofline"]["device_ms_per_pass"], o["device_ms_per_pass"], o["value"]))
+        out.append("")
+    sp = [(n, sc, J("bench_sp_cfg2_%s_n%d.json" % (sc, n))) for sc in ("weak", "strong") for n in (1, 2, 8)]
+    if any(b for _, _, b in sp):
+        out += ["## The device set: one process, `bench.py --gpus N --single-process` (THIS box has one GPU: device 0 listed N times -- N workers share it and its one PCIe link)", "",
+                "| workload | N | scaling | pairs | ms / pass (wall) | slowest shard's device ms | GCUPS credited | end to end ms (host strings in, answers out) |", "|" + "---|" * 8]
+        for n, sc, b in sp:
+            if b:
+                out.append("| cfg2 | %d | %s | %d | %.4f | %.4f | %.0f | %.2f |" % (n, sc, b["config"]["units_total"], b["ms_per_step"], b["roofline"]["device_ms_per_pass"], b["value"], b["end_to_end_ms"]))
+        for n in (1, 8):
+            b = J("bench_sp_cfg5_n%d.json" % n)
+            if b:
+                out.append("| cfg5 (resident sharded haystack, Best) | %d | weak | %d | %.4f | — | %.0f | %s |" % (n, b["config"]["units_total"], b["ms_per_step"], b["value"], "%.2f" % b["end_to_end_ms"] if b.get("end_to_end_ms") else "—"))
+        out.append("")
     e2e = [(wl, J("bench_%s.json" % wl)) for wl in ("cfg2", "cfg4", "cfg5", "cfg1", "cfg2_ragged")]
     out += ["## Host buffers in, answers out (`end_to_end_ms`: pinned H2D of the batch + the pass + D2H; never the headline)", "",
             "| config | ms per pass, inputs resident | ms end to end | untimed ramp passes before the timed region |", "|---|---|---|---|"]
@@ -108,7 +145,7 @@ def main():
                        ("cfg2_ragged", "lev_bits_"), ("cfg2_ragged", "len_hist"), ("cfg2_ragged", "len_scan"), ("cfg2_ragged", "len_scatter"),
                        ("cfg2_dna", "lev_bitsq_kernel"), ("cfg2_dna", "lev_bits_s8"), ("cfg2_dna5", "lev_bitsqw_kernel"), ("cfg2_protein_table", "lev_bitsqw_kernel"), ("cfg2_ragged_vline", "lev_bits_s8v"), ("cfg2_ragged_vline", "len_scatter"),
                        ("cfg2l", "lev_band_score"), ("cfg2s", "lev_bits_line"), ("cfg2s", "scale_results"), ("cfg2t", "lev_band_trace_kernel"), ("cfg2t", "lev_trace_walk"),
-                       ("cfg2t", "lev_bits_trace_kernel"), ("cfg2t", "lev_bits_s8_ckpt_kernel"), ("cfg3_mutated", "lev_bits_"), ("cfg3_mutated", "lev_widebits_kernel"), ("cfg3_mutated", "compact_"),
+                       ("cfg2t", "lev_bits_trace_kernel"), ("cfg2t", "lev_bits_s8_ckpt_kernel"), ("cfg2tp", "lev_bits_trace_kernel"), ("cfg2tp", "lev_bits_s8_ckpt_kernel"), ("cfg2t_231", "lev_band_trace_kernel"), ("cfg2t_231", "lev_trace_walk"), ("cfg2t_dp", "lev_band_trace_kernel"), ("cfg2t_dp", "lev_trace_walk"), ("cfg3_mutated", "lev_bits_"), ("cfg3_mutated", "lev_widebits_kernel"), ("cfg3_mutated", "compact_"),
                        ("cfg3_mutated", "bag_bound"), ("cfg4_mutated", "lev_bits2"), ("cfg5w_231", "lev_filter_kernel"), ("cfg5w_231", "lev_search_wave_kernel"),
                        ("cfg5w_2213", "lev_filter_kernel"), ("cfg5w_2213", "lev_search_wave_kernel"),
                        ("cfg2w_prefilter", "lev_bits_"), ("cfg2w_prefilter", "compact_some"), ("cfg2w_prefilter", "lev_band_score"),

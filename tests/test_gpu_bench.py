@@ -92,3 +92,21 @@ def test_traffic_measured_in_the_run():
     assert r["timed_region"].startswith("one hipGraph")
     assert r["roofline"]["traffic_source"].startswith("measured in this run"), r["roofline"]["traffic_source"]
     assert 0.8 < r["roofline"]["traffic"] / r["roofline"]["algorithmic_bytes_per_pass"] < 1.5
+
+
+def test_single_process_device_set_lines():
+    """`bench.py --gpus N --single-process`: ONE process, the library's device set (device 0 listed N times on this box) shards the batch /
+    the haystack -- the same JSON shape, `value` from the resident sharded handle, `end_to_end_ms` through the host-pointer entry."""
+    w = _bench("--single-process", "--gpus", "3", "--pairs", "20000")
+    assert w["n_gpus"] == 3 and w["scaling"] == "weak" and w["single_process"] and w["config"]["units_total"] == 60000
+    assert w["config"]["shards"] == 3 and w["value"] > 0 and w["end_to_end_ms"] > 0 and w["parity_checked_some"] > 1000
+    s = _bench("--single-process", "--gpus", "8", "--pairs", "40000", "--scaling", "strong")
+    assert s["n_gpus"] == 8 and s["config"]["units_total"] == 40000 and s["config"]["devices"] == [0] * 8
+    r = _bench("--single-process", "--gpus", "2", "--workload", "cfg5", "--pairs", "8")
+    assert r["n_gpus"] == 2 and r["config"]["units_total"] == 2 * (8 << 20) and r["parity_checked_some"] > 0 and r["end_to_end_ms"] > 0
+
+
+def test_default_line_carries_the_overlapped_figure_and_value_is():
+    r = _bench("--pairs", "300000")
+    assert r["value_is"] == "one GPU" and r["overlapped_passes"]["device_ms_per_pass"] > 0
+    assert r["overlapped_passes"]["value"] > 0.9 * r["value"]
