@@ -296,6 +296,9 @@ def main():
     backend = os.environ.get("TA_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
     local = local % ndev
     torch.cuda.set_device(local)
+    if world > 1:                       # one process per GPU: this rank's host entry points stay on its own device (the default set is every visible one)
+        from triple_accel_amd import multi as TM
+        TM.set_devices([local])
     dist = None
     # a ONE-rank run under a launcher with TA_BENCH_BACKEND set also joins a process group: every collective of the multi-rank path
     # (barrier, all_reduce, the sharded search's all-gathers) then executes on RCCL / gloo with world size 1

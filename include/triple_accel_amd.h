@@ -300,7 +300,8 @@ void ta_queue_destroy(ta_queue *q);
  * there is no device-to-device traffic: results return over each device's own PCIe link and are concatenated in shard order.
  *   ta_set_devices(ids, n): the set (NULL / 0: every visible device, also the default).  An id may appear more than once -- that many
  *   workers share the device (how a one-GPU box exercises the N-way logic).  Not to be called while other calls are in flight; resident
- *   handles created before keep the workers they were created on.
+ *   handles created before keep the workers they were created on.  A process that owns ONE GPU of a node (one rank per GPU under a launcher,
+ *   all GPUs visible) should name it -- ta_set_devices(&mine, 1) -- or its big host calls fan out over its neighbours' devices too.
  * What fans out when the set has more than one entry: the *_host batch entries below, ta_queue_flush (and through it the bindings'
  * levenshtein_simd_k_with_opts_many), and the host search entries ta_levenshtein_search_simd_with_opts (unanchored) /
  * ta_hamming_search_simd_with_opts / ta_hamming_search_naive_with_opts for haystacks of >= 8 MiB (>= 4 MiB per device used).

@@ -60,6 +60,29 @@ def test_no_cpu_fallback():
         T.hamming(b"ab", b"abc")
 
 
+def test_device_set_has_no_cpu_fallback_either():
+    """The device set (ta_multi.hip) without a device: an empty set, every host-pointer entry TA_ERR_HIP -- after the argument checks."""
+    import numpy as np
+    import torch
+    import triple_accel_amd as T
+    from triple_accel_amd import multi as M
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert M.get_devices() == []
+    with pytest.raises(T.TripleAccelError):
+        M.set_devices([0])
+    with pytest.raises(T.TripleAccelError):
+        M.levenshtein_k_batch_host([b"abc"], [b"abd"], 2)
+    with pytest.raises(T.TripleAccelError):
+        M.hamming_batch_host(np.zeros((3, 8), dtype=np.uint8), np.zeros((3, 8), dtype=np.uint8))
+    with pytest.raises(T.TripleAccelError):
+        M.ShardedHaystack(b"x" * 100)
+    with pytest.raises(T.PanicError):                          # EditCosts::new's assert comes first
+        M.levenshtein_k_batch_host([b"abc"], [b"abd"], 2, (0, 1, 0, None))
+    with pytest.raises(ValueError):
+        M.levenshtein_k_batch_host([b"abc"], [], 2)
+
+
 def test_product_never_touches_the_oracle():
     """The product package must not import, link or load anything under oracle/ or tests/."""
     pkg = os.path.join(ROOT, "triple_accel_amd")

@@ -294,3 +294,18 @@ def test_options_travel_with_the_jobs():
         assert np.array_equal(M.levenshtein_k_batch_host(a, b, 32), want)
     finally:
         T.set_option(1, 0)
+
+
+def test_many_small_calls_and_set_switches():
+    """Thousands of tiny jobs and device-set switches in a row: a worker's last touch of a call's latch may come after the caller has already
+    returned (round 6's fuzz run found the latch on the caller's stack: heap corruption once in ~11,000 rounds; it lives on the heap now)."""
+    from triple_accel_amd import multi as M
+    _tune(TA_MULTI_MIN_PAIRS=1)
+    a, b = [b"kitten", b"abc", b"", b"flaw"], [b"sitting", b"abd", b"xy", b"lawn"]
+    for it in range(2500):
+        M.set_devices([0] * (1 + it % 4))
+        assert M.levenshtein_k_batch_host(a, b, 3).tolist() == [3, 1, 2, 2]
+        if it % 50 == 0:
+            S = M.ShardedPairs(a, b)
+            assert S.hamming().tolist() == [0xFFFFFFFF, 1, 0xFFFFFFFF, 4]
+            S.close()

@@ -201,32 +201,45 @@ static std::shared_ptr<Pool> pool() {
 // Runs fn(r, worker) on the first `n_use` workers at once and waits for all of them; the first failure's status and message are the call's.
 // The calling thread's options (ta_set_option) travel with the jobs.
 static int run_on(Pool &P, size_t n_use, const std::function<int(size_t, Worker &)> &fn) {
-    struct Latch { std::mutex mu; std::condition_variable cv; size_t left; } latch;
-    latch.left = n_use;
-    std::vector<int> rcs(n_use, TA_OK);
-    std::vector<std::string> errs(n_use);
+    // The latch and the result slots live on the HEAP and every job holds a reference: a worker's last touch of them (the notify) may come after
+    // the caller has seen left == 0 and returned -- on the caller's stack that was a use after scope (found by scripts/r06/fuzz_r06.py: "double
+    // free or corruption" once in ~11,000 rounds).  `fn` itself is only used before the job counts down.
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t left;
+        std::vector<int> rcs;
+        std::vector<std::string> errs;
+        explicit Shared(size_t n) : left(n), rcs(n, TA_OK), errs(n) {}
+    };
+    auto sh = std::make_shared<Shared>(n_use);
     const bool eo = early_out_enabled(), pf = unit_prefilter_enabled();
     for (size_t r = 0; r < n_use; r++) {
         Worker *w = P.w[r].get();
-        w->post([&, r, w] {
-            if (w->init_rc) { rcs[r] = w->init_rc; errs[r] = w->init_err; }
+        w->post([sh, &fn, eo, pf, r, w] {
+            int rc;
+            std::string err;
+            if (w->init_rc) { rc = w->init_rc; err = w->init_err; }
             else {
                 ta_set_option(TA_OPT_EARLY_OUT, eo);
                 ta_set_option(TA_OPT_UNIT_PREFILTER, pf);
-                rcs[r] = fn(r, *w);
-                if (rcs[r]) {
-                    errs[r] = ta_last_error();
+                rc = fn(r, *w);
+                if (rc) {
+                    err = ta_last_error();
                     (void)hipStreamSynchronize(w->st);            // a failed job leaves nothing in flight behind it
                     (void)w->up.drain(); (void)w->down.drain();
                 }
             }
-            { std::lock_guard<std::mutex> lk(latch.mu); latch.left--; }
-            latch.cv.notify_one();
+            std::lock_guard<std::mutex> lk(sh->mu);                // (the notify under the lock: the caller cannot run ahead of it)
+            sh->rcs[r] = rc; sh->errs[r] = std::move(err);
+            sh->left--;
+            sh->cv.notify_one();
         });
     }
-    { std::unique_lock<std::mutex> lk(latch.mu); latch.cv.wait(lk, [&] { return latch.left == 0; }); }
+    std::unique_lock<std::mutex> lk(sh->mu);
+    sh->cv.wait(lk, [&] { return sh->left == 0; });
     for (size_t r = 0; r < n_use; r++)
-        if (rcs[r]) { set_last_error_msg(errs[r].c_str()); return rcs[r]; }
+        if (sh->rcs[r]) { set_last_error_msg(sh->errs[r].c_str()); return sh->rcs[r]; }
     return TA_OK;
 }
 
