@@ -14,6 +14,8 @@ import oracle_lib as O
 import triple_accel_amd as T
 from triple_accel_amd import batch as B
 from triple_accel_amd import multi as M
+from triple_accel_amd import _native as _N
+if os.environ.get("FUZZ_BACKTRACE"): _N.lib().ta_debug_install_abort_backtrace()
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
@@ -51,8 +53,11 @@ def fail(what, **kw):
     sys.exit(1)
 
 
+SKIP_UNTIL = int(os.environ.get("FUZZ_SKIP_UNTIL", "0"))
+SKIP_UNTIL = int(os.environ.get("FUZZ_SKIP_UNTIL", "0"))
 t_end, rounds, kinds = time.time() + 60 * minutes, 0, {}
-while time.time() < t_end:
+STOP_AT = int(os.environ.get("FUZZ_STOP_AT", "0"))
+while time.time() < t_end and not (STOP_AT and rounds >= STOP_AT):
     rounds += 1
     for s in SW: os.environ.pop(s, None)
     kind = int(g.integers(0, 6))
@@ -60,7 +65,8 @@ while time.time() < t_end:
     costs = COSTS[int(g.integers(0, len(COSTS)))]
     sym = ALPHAS[int(g.integers(0, len(ALPHAS)))]
     trans = costs[3] is not None
-    if os.environ.get("FUZZ_VERBOSE"): print("round", rounds, "kind", kind, costs, sym, flush=True)
+    live = rounds >= SKIP_UNTIL            # replaying a seed: earlier rounds only draw their random numbers (in the same order)
+    if os.environ.get("FUZZ_VERBOSE") and live: print("round", rounds, "kind", kind, costs, sym, flush=True)
     if kind in (0, 1):                                   # batch tracebacks
         if g.random() < 0.3: os.environ["TA_TRACE_TILE"] = str(g.choice([8, 16, 32]))
         if g.random() < 0.5: os.environ["TA_TRACE_STILE"] = str(g.choice([32, 64, 128]))
@@ -81,13 +87,16 @@ while time.time() < t_end:
                 m = (mutate(A[i].tobytes(), sym, int(g.integers(0, unit_k + 2)), trans) + g.integers(sym[0], sym[1], lb, dtype=np.uint8).tobytes())[:lb]
                 Bm[i] = np.frombuffer(m, dtype=np.uint8)
             a, b = [r.tobytes() for r in A], [r.tobytes() for r in Bm]
-            sa, sb = B.Strings.from_fixed(A), B.Strings.from_fixed(Bm)
+            sa, sb = (B.Strings.from_fixed(A), B.Strings.from_fixed(Bm)) if live else (None, None)
         else:
             a, b = pairs(n, 0, int(g.integers(1, 400)), sym, unit_k, trans)
-            sa, sb = B.Strings.from_list(a), B.Strings.from_list(b)
+            sa, sb = (B.Strings.from_list(a), B.Strings.from_list(b)) if live else (None, None)
         packed = kind == 1
-        if os.environ.get("FUZZ_VERBOSE"): print("  trace n", n, "k", k, "fixed", fixed, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
+        if os.environ.get("FUZZ_VERBOSE") and live: print("  trace n", n, "k", k, "fixed", fixed, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
         cap = None if g.random() < 0.7 else int(g.integers(1, 12))
+        if not live:
+            g.integers(0, max(1, n // 250))               # (the sample offset drawn below)
+            continue
         if packed:
             o, p, ne = B.levenshtein_trace_batch_packed(sa, sb, k, costs, cap=cap)
             scripts, nn = B.packed_to_lists(p, ne, allow_cut=True), ne.cpu().numpy()
@@ -107,14 +116,14 @@ while time.time() < t_end:
                 fail("trace", i=i, a=a[i], b=b[i], k=k, costs=costs, packed=packed, got=(int(d[i]), scripts[i]), want=(wd, want), fixed=fixed)
     elif kind in (2, 3):                                 # the device set: pair batches
         world = int(g.choice([1, 2, 3, 5, 8]))
-        M.set_devices([0] * world)
+        if live: M.set_devices([0] * world)
         os.environ["TA_MULTI_MIN_PAIRS"] = str(int(g.choice([1, 16, 100, 4096])))
         os.environ["TA_MULTI_CHUNK_BYTES"] = str(int(g.choice([2048, 30000, 1 << 20, 64 << 20])))
         os.environ["TA_MULTI_PIECE"] = str(int(g.choice([4096, 65536, 4 << 20])))
         if g.random() < 0.3: os.environ["TA_MULTI_CHUNK_PAIRS"] = str(int(g.integers(1, 500)))
         n = int(g.integers(0, 4000))
         unit_k = int(g.integers(0, 40))
-        if os.environ.get("FUZZ_VERBOSE"): print("  pairs world", world, "n", n, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
+        if os.environ.get("FUZZ_VERBOSE") and (live or rounds >= STOP_AT - 3): print("  pairs world", world, "n", n, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
         k = unit_k * max(costs[0], costs[1]) + costs[2]
         if g.random() < 0.4 and n:
             la = int(g.integers(1, 200))
@@ -124,6 +133,12 @@ while time.time() < t_end:
         else:
             a, b = pairs(n, 0, int(g.integers(1, 300)), sym, unit_k, trans)
             ha, hb, ca, cb = a, b, O.csr_from_list(a), O.csr_from_list(b)
+        if not live:
+            if kind == 2:
+                if n: g.random()
+            else:
+                g.random()
+            continue
         if kind == 2:
             got, want = M.levenshtein_k_batch_host(ha, hb, k, costs), O.levenshtein_k_batch(ca, cb, k, costs)
             if not np.array_equal(got, want): fail("k_batch_host", world=world, n=n, k=k, costs=costs)
@@ -140,7 +155,7 @@ while time.time() < t_end:
         M.set_devices([0])
     else:                                                # the device set: searches
         world = int(g.choice([2, 3, 5, 8]))
-        M.set_devices([0] * world)
+        if live: M.set_devices([0] * world)
         h = int(g.integers(100, 60000))
         os.environ["TA_MULTI_MIN_HAY"] = str(int(g.choice([4, 50, 1000, 8000])))
         os.environ["TA_MULTI_PIECE"] = str(int(g.choice([4096, 65536])))
@@ -152,10 +167,13 @@ while time.time() < t_end:
             m = mutate(needle, (max(1, s2[0]), s2[1]), int(g.integers(0, 4)), trans)
             hay[pos:pos + len(m)] = m
         hay = bytes(hay)
-        if os.environ.get("FUZZ_VERBOSE"): print("  search world", world, "h", h, "nl", nl, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
+        if os.environ.get("FUZZ_VERBOSE") and live: print("  search world", world, "h", h, "nl", nl, {x: os.environ.get(x) for x in SW if os.environ.get(x)}, flush=True)
         if kind == 4:
             sc = costs if O.costs_valid_search(costs) else (1, 1, 0, None)
             k = int(g.integers(0, max(1, nl // 2) + 1)) * max(sc[0], sc[1])
+            if not live:
+                if g.random() < 0.5: g.integers(nl + k + 2, nl + k + 300)
+                continue
             for st in (T.SearchType.All, T.SearchType.Best):
                 got = [tuple(m) for m in T.levenshtein_search_simd_with_opts(needle, hay, k, st, T.EditCosts(*sc), False)]
                 want = O.levenshtein_search_naive_with_opts(needle, hay, k, st, sc, False)
@@ -169,6 +187,7 @@ while time.time() < t_end:
             k = int(g.integers(0, nl // 2 + 1))
             if g.random() < 0.2:
                 hz = bytearray(hay); hz[int(g.integers(0, h))] = 0; hay = bytes(hz)
+            if not live: continue
             for st in (T.SearchType.All, T.SearchType.Best):
                 try:
                     want = O.hamming_search_simd_with_opts(needle, hay, k, st)

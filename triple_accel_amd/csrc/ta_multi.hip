@@ -14,6 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
@@ -145,28 +149,50 @@ struct Worker {
     }
 };
 
+// Worker threads are created on demand and NEVER exit: the k-th worker of device d serves the k-th occurrence of d in any device set.  A set
+// (Pool) is a list of borrowed workers.  (Round 6's first form joined a set's threads when the set changed; a fuzz run that switched sets
+// ~10,000 times died three times in five with "double free or corruption" inside that tear-down -- a worker's exit racing with the runtime's own
+// per-thread state -- and a thread that never exits has no tear-down.  A worker that leaves the set frees what it holds: trim().)  At process
+// exit the workers are blocked on their condition variables and die with the process.
+struct Registry {
+    std::mutex mu;
+    std::vector<std::vector<Worker *>> by_device;            // leaked with the process
+    Worker *get(int device, size_t occurrence) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (by_device.size() <= (size_t)device) by_device.resize((size_t)device + 1);
+        auto &v = by_device[(size_t)device];
+        while (v.size() <= occurrence) {
+            Worker *w = new Worker();
+            w->device = device;
+            w->index = (int)v.size();
+            w->th = std::thread([w] { w->main_loop(); });
+            w->th.detach();
+            v.push_back(w);
+        }
+        return v[occurrence];
+    }
+    std::vector<Worker *> all() {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<Worker *> r;
+        for (auto &v : by_device) r.insert(r.end(), v.begin(), v.end());
+        return r;
+    }
+};
+static Registry &registry() { static Registry *r = new Registry(); return *r; }
+
 struct Pool {
-    std::vector<std::unique_ptr<Worker>> w;
+    std::vector<Worker *> w;                                   // borrowed from the registry
     std::vector<int> devices;
     explicit Pool(const std::vector<int> &devs) : devices(devs) {
-        for (size_t i = 0; i < devs.size(); i++) {
-            w.emplace_back(new Worker());
-            w.back()->device = devs[i];
-            w.back()->index = (int)i;
+        std::vector<size_t> seen;
+        for (int d : devs) {
+            if (seen.size() <= (size_t)d) seen.resize((size_t)d + 1, 0);
+            w.push_back(registry().get(d, seen[(size_t)d]++));
         }
-        for (auto &x : w) x->th = std::thread([p = x.get()] { p->main_loop(); });
-    }
-    ~Pool() {
-        for (auto &x : w) {
-            { std::lock_guard<std::mutex> lk(x->mu); x->stop = true; }
-            x->cv.notify_one();
-        }
-        for (auto &x : w) if (x->th.joinable()) x->th.join();
     }
 };
 
-// The process's device set.  Deliberately leaked at exit (worker threads blocked on their condition variables die with the process: joining
-// them from a static destructor would call into a HIP runtime that may already be gone).
+// The process's device set.
 static std::mutex g_pool_mu;
 static std::shared_ptr<Pool> *g_pool = nullptr;
 
@@ -215,7 +241,7 @@ static int run_on(Pool &P, size_t n_use, const std::function<int(size_t, Worker 
     auto sh = std::make_shared<Shared>(n_use);
     const bool eo = early_out_enabled(), pf = unit_prefilter_enabled();
     for (size_t r = 0; r < n_use; r++) {
-        Worker *w = P.w[r].get();
+        Worker *w = P.w[r];
         w->post([sh, &fn, eo, pf, r, w] {
             int rc;
             std::string err;
@@ -575,6 +601,18 @@ static int give_matches(std::vector<ta_match> &v, ta_match **out, size_t *n_out)
 
 extern "C" {
 
+// (debugging aid, not part of the ABI header: a native backtrace of the thread that aborts -- glibc's heap checks, an assert -- on stderr)
+static void ta_abort_backtrace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "[triple_accel_amd] SIGABRT backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+void ta_debug_install_abort_backtrace(void) { signal(SIGABRT, ta_abort_backtrace); }
+
 int ta_set_devices(const int *devices, size_t n) {
     std::vector<int> d;
     const int visible = ta_device_count();
@@ -596,7 +634,23 @@ int ta_set_devices(const int *devices, size_t n) {
         old = *g_pool;
         *g_pool = std::make_shared<Pool>(d);
     }
-    old.reset();               // the old workers finish their queues, free what they hold and exit -- unless a resident handle still owns them
+    // workers that are not part of the new set give back what they hold (pinned rings, device buffers, thread-local scratch); they stay alive
+    // -- a resident handle created on them keeps working (its buffers are its own, the rings come back on demand)
+    std::shared_ptr<Pool> now = pool();
+    std::vector<Worker *> idle;
+    for (Worker *w : registry().all())
+        if (std::find(now->w.begin(), now->w.end(), w) == now->w.end()) idle.push_back(w);
+    if (!idle.empty()) {
+        Pool tmp(std::vector<int>{});
+        tmp.w = idle;
+        (void)run_on(tmp, idle.size(), [](size_t, Worker &w) -> int {
+            (void)hipStreamSynchronize(w.st);
+            w.up.release(); w.down.release();
+            for (DevBuf &b : w.buf) b.release();
+            ta_thread_release();
+            return TA_OK;
+        });
+    }
     return TA_OK;
 }
 
