@@ -312,9 +312,9 @@ int ta_get_devices(int *out, size_t cap, size_t *n_out);
 /* Batches whose strings live in HOST memory (ta_strings with host pointers: CSR offsets or the strided form): N x
  * levenshtein_simd_k_with_opts(a_i, b_i, k, false, costs) / levenshtein_exp_with_opts(a_i, b_i, false, costs) / hamming(a_i, b_i)
  * -> out[i] (host; TA_NONE = None / a length mismatch).  Every device of the set takes a contiguous slice of the pairs (no device gets
- * fewer than 4,096) and works through it in chunks of <= 64 MiB of strings: staged through pinned memory, uploaded, answered by the
- * batch entry of the same name, the answers downloaded -- upload and kernels of consecutive chunks overlap; a device whose slice holds >= 16 MiB
- * of strings is fed by two staging threads (one thread's memcpy does not fill a PCIe link).  Synchronous. */
+ * fewer than 4,096) and works through it in chunks of <= 64 MiB of strings: uploaded (big pieces by the runtime's path for pageable memory, CSR
+ * offsets rebased through a pinned ring), answered by the batch entry of the same name, the answers downloaded; a device whose slice holds >= 16 MiB
+ * of strings is fed by two threads and streams.  Synchronous. */
 int ta_levenshtein_k_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n, uint32_t k,
                                 const ta_edit_costs *costs, uint32_t *out_host);
 int ta_levenshtein_exp_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n,

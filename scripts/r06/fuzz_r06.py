@@ -24,7 +24,7 @@ print("seed", seed, flush=True)
 COSTS = [(1, 1, 0, None), (1, 1, 0, 1), (2, 2, 0, None), (3, 3, 0, 3), (2, 3, 1, None), (2, 2, 1, 3), (2, 3, 0, None), (1, 2, 0, None), (3, 2, 1, 2), (1, 1, 1, None)]
 ALPHAS = [(33, 127), (97, 99), (0, 1), (0, 13), (12, 14), (0, 256), (65, 69)]
 SW = ("TA_TRACE_TILE", "TA_TRACE_STILE", "TA_TRACE_OWN_SWEEP", "TA_TRACE_CSR_OWN_SWEEP", "TA_TRACE_CHUNK_PAIRS", "TA_TRACE_NO_L1", "TA_MULTI_MIN_PAIRS", "TA_MULTI_MIN_HAY",
-      "TA_MULTI_CHUNK_BYTES", "TA_MULTI_CHUNK_PAIRS", "TA_MULTI_PIECE")
+      "TA_MULTI_CHUNK_BYTES", "TA_MULTI_CHUNK_PAIRS", "TA_MULTI_PIECE", "TA_MULTI_DIRECT_FROM", "TA_MULTI_STAGERS_FROM")
 
 
 def mutate(x, sym, edits, trans):
@@ -120,6 +120,8 @@ while time.time() < t_end and not (STOP_AT and rounds >= STOP_AT):
         os.environ["TA_MULTI_MIN_PAIRS"] = str(int(g.choice([1, 16, 100, 4096])))
         os.environ["TA_MULTI_CHUNK_BYTES"] = str(int(g.choice([2048, 30000, 1 << 20, 64 << 20])))
         os.environ["TA_MULTI_PIECE"] = str(int(g.choice([4096, 65536, 4 << 20])))
+        os.environ["TA_MULTI_DIRECT_FROM"] = str(int(g.choice([1, 4096, 65536, 1 << 40])))
+        os.environ["TA_MULTI_STAGERS_FROM"] = str(int(g.choice([1, 50000, 16 << 20])))
         if g.random() < 0.3: os.environ["TA_MULTI_CHUNK_PAIRS"] = str(int(g.integers(1, 500)))
         n = int(g.integers(0, 4000))
         unit_k = int(g.integers(0, 40))

@@ -21,7 +21,7 @@ WORLDS = [2, 3, 8]
 @pytest.fixture(autouse=True)
 def _reset_device_set():
     from triple_accel_amd import multi as M
-    keys = ["TA_MULTI_MIN_PAIRS", "TA_MULTI_MIN_HAY", "TA_MULTI_CHUNK_BYTES", "TA_MULTI_CHUNK_PAIRS", "TA_MULTI_PIECE"]
+    keys = ["TA_MULTI_MIN_PAIRS", "TA_MULTI_MIN_HAY", "TA_MULTI_CHUNK_BYTES", "TA_MULTI_CHUNK_PAIRS", "TA_MULTI_PIECE", "TA_MULTI_DIRECT_FROM", "TA_MULTI_STAGERS_FROM"]
     saved = {k: os.environ.get(k) for k in keys}
     yield
     for k, v in saved.items():
@@ -77,7 +77,7 @@ def test_host_batch_fixed_equals_oracle(world, costs):
 def test_host_batch_ragged_csr_equals_oracle(world):
     from triple_accel_amd import multi as M
     M.set_devices([0] * world)
-    _tune(TA_MULTI_MIN_PAIRS=32, TA_MULTI_CHUNK_BYTES=40 * 1024, TA_MULTI_PIECE=4096)
+    _tune(TA_MULTI_MIN_PAIRS=32, TA_MULTI_CHUNK_BYTES=40 * 1024, TA_MULTI_PIECE=4096, TA_MULTI_DIRECT_FROM=1 << 40)      # everything through the pinned ring
     a, b = _ragged(17, 5000, 0, 200, 12)                 # empty strings included
     got = M.levenshtein_k_batch_host(a, b, 16)
     want = O.levenshtein_k_batch(O.csr_from_list(a), O.csr_from_list(b), 16)
@@ -106,7 +106,7 @@ def test_host_batch_edge_shapes():
 def test_host_batch_hamming_cfg1_shape(world):
     from triple_accel_amd import multi as M
     M.set_devices([0] * world)
-    _tune(TA_MULTI_MIN_PAIRS=256)
+    _tune(TA_MULTI_MIN_PAIRS=256, TA_MULTI_STAGERS_FROM=1 << 20)                 # (two stagers per device from 1 MiB of strings; big pieces: the runtime's pageable path)
     a, b = Dg.pairs_random(9, 10_000, 1024)              # BASELINE config 1's batch
     b[::3, ::5] = a[::3, ::5]
     got = M.hamming_batch_host(a, b)
@@ -145,7 +145,7 @@ def test_host_search_fans_out(world, costs):
     import triple_accel_amd as T
     from triple_accel_amd import multi as M
     M.set_devices([0] * world)
-    _tune(TA_MULTI_MIN_HAY=20_000, TA_MULTI_PIECE=8192)
+    _tune(TA_MULTI_MIN_HAY=20_000, TA_MULTI_PIECE=8192, TA_MULTI_DIRECT_FROM=(1 << 40) if world == 3 else 65536)   # (world 3: the shards through the ring)
     g = Dg.rng(77)
     needle = Dg.rand_str(g, 24)
     hay = bytearray(Dg.planted_haystack(12, needle, 300_007, 7000, 6))

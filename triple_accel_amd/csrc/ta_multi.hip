@@ -182,8 +182,8 @@ static Registry &registry() { static Registry *r = new Registry(); return *r; }
 
 struct Pool {
     std::vector<Worker *> w;                                   // borrowed from the registry
-    std::vector<Worker *> w2;                                  // a SECOND stager per entry, for big host batches: one thread's memcpy into pinned memory (~35 GB/s)
-                                                               // does not fill a PCIe link (~53 GB/s) -- 1M x 256-byte pairs: 15.4 ms with one stager per device, 9.7 with two
+    std::vector<Worker *> w2;                                  // a SECOND stager per entry, for big host batches: two threads feeding a device's link (two contiguous half slices, two streams) --
+                                                               // 1M x 256-byte pairs end to end: 9.9 ms with one stager per device, 9.4 with two (through the ring: 17.9 / 11.8)
     std::vector<int> devices;
     explicit Pool(const std::vector<int> &devs) : devices(devs) {
         std::vector<size_t> total, seen;
@@ -290,6 +290,14 @@ static void shard_range(size_t n, size_t r, size_t world, size_t *lo, size_t *hi
 
 // ---------------------------------------------------------------- transfers (worker thread)
 static int upload(Worker &w, void *dst_dev, const uint8_t *src, size_t bytes) {
+    // Big pieces of the caller's (pageable) memory go through the runtime's own path -- it pins the pages in place and lets the DMA engine read them:
+    // 1M x 256-byte pairs from host memory on one GPU 9.9 ms end to end against 17.9 through the ring with one stager and 11.8 with two
+    // (scripts/r06/ab_direct_copy.sh).  The ring stays for what is transformed on the way (CSR offsets), for small pieces and for downloads.
+    // TA_MULTI_DIRECT_FROM=n: the threshold in bytes (65,536; the tests raise it so that the ring carries everything).
+    if (bytes >= tuning_size("TA_MULTI_DIRECT_FROM", 65536)) {
+        TA_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, w.st));
+        return TA_OK;
+    }
     int rc = w.up.ensure(piece_bytes());
     if (rc) return rc;
     for (size_t o = 0; o < bytes; o += w.up.piece) {
