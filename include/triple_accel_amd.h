@@ -320,6 +320,12 @@ int ta_levenshtein_k_batch_host(const ta_strings *a_host, const ta_strings *b_ho
 int ta_levenshtein_exp_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n,
                                   const ta_edit_costs *costs, uint32_t *out_host);
 int ta_hamming_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n, uint32_t *out_host);
+/* N x levenshtein_simd_k_with_opts(a_i, b_i, k, true, costs) for HOST strings over the device set: out_host[i] = distance | TA_NONE, n_edits_host[i] =
+ * the runs of pair i's script (0 for None), packed_host[i * cap ..]: the script as packed runs, (edit type << 29) | count, front to back, in the LAST
+ * min(n_edits_host[i], cap) words of the pair's slot (ta_levenshtein_trace_batch_packed's layout; the words in front of a script are undefined).
+ * cap = 2 k + 1 holds every script of cost <= k; a longer script keeps its last cap runs. */
+int ta_levenshtein_trace_batch_host(const ta_strings *a_host, const ta_strings *b_host, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                    uint32_t *out_host, uint32_t *packed_host, uint32_t *n_edits_host, size_t cap);
 
 /* A pair batch uploaded ONCE and kept resident, sharded over the first n_shards devices of the set (0: as the *_host entries choose);
  * every later call runs the shards side by side and downloads 4 bytes per pair.  ta_sharded_pairs_time_levenshtein_k: `steps` passes back

@@ -80,6 +80,8 @@ mod ffi {
         pub fn ta_levenshtein_exp_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, costs: *const TaEditCosts,
                                              out_host: *mut u32) -> c_int;
         pub fn ta_hamming_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, out_host: *mut u32) -> c_int;
+        pub fn ta_levenshtein_trace_batch_host(a_host: *const TaStrings, b_host: *const TaStrings, n: usize, k: u32, costs: *const TaEditCosts,
+                                               out_host: *mut u32, packed_host: *mut u32, n_edits_host: *mut u32, cap: usize) -> c_int;
     }
     /// Frees what a thread holds inside the library (its stream, pinned buffers, device scratch) when the thread ends: the
     /// library itself frees nothing from a thread-exit hook.  Touched by every call through `check`.

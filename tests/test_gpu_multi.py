@@ -309,3 +309,28 @@ def test_many_small_calls_and_set_switches():
             S = M.ShardedPairs(a, b)
             assert S.hamming().tolist() == [0xFFFFFFFF, 1, 0xFFFFFFFF, 4]
             S.close()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_host_batch_tracebacks(world):
+    """ta_levenshtein_trace_batch_host: distances + edit scripts of host strings over the device set (packed runs expanded by the binding) --
+    unit costs (the checkpoint route), unit costs x 2, weighted + affine + transposition (the record route), chunked -- edit for edit the oracle's."""
+    from triple_accel_amd import multi as M
+    M.set_devices([0] * world)
+    _tune(TA_MULTI_MIN_PAIRS=64, TA_MULTI_CHUNK_BYTES=60_000)
+    a, b = _ragged(23, 2500, 0, 180, 10)
+    for k, costs in [(14, (1, 1, 0, None)), (12, (1, 1, 0, 1)), (24, (2, 2, 0, None)), (20, (2, 3, 1, None)), (18, (2, 2, 1, 3))]:
+        d, scripts = M.levenshtein_trace_batch_host(a, b, k, costs)
+        some = 0
+        for i in range(0, len(a), 3):
+            wd, we = O.levenshtein_simd_k_with_opts(a[i], b[i], k, True, costs)
+            if wd is None:
+                assert d[i] == 0xFFFFFFFF and scripts[i] == [], (i, costs)
+            else:
+                some += 1
+                assert d[i] == wd and scripts[i] == we, (i, costs, scripts[i], we)
+        assert some > 200
+    fa, fb = Dg.pairs_mutated_fixed(24, 3000, 200, 16)
+    d, packed, ne = M.levenshtein_trace_batch_host(fa, fb, 32, as_lists=False)
+    assert packed.shape == (3000, 65) and np.array_equal(d, O.levenshtein_k_batch(O.csr_from_fixed(fa), O.csr_from_fixed(fb), 32))
+    assert int(ne.max()) <= 65 and int(ne[d != 0xFFFFFFFF].min()) >= 1

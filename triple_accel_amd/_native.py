@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "ta_levenshtein_search_best_dev", "ta_levenshtein_trace_batch", "ta_hamming_search_dev_sorted", "ta_levenshtein_search_resume",
     # the device set (ta_multi.hip)
     "ta_levenshtein_trace_batch_packed",
-    "ta_set_devices", "ta_get_devices", "ta_levenshtein_k_batch_host", "ta_levenshtein_exp_batch_host", "ta_hamming_batch_host",
+    "ta_set_devices", "ta_get_devices", "ta_levenshtein_k_batch_host", "ta_levenshtein_exp_batch_host", "ta_hamming_batch_host", "ta_levenshtein_trace_batch_host",
     "ta_sharded_pairs_upload", "ta_sharded_pairs_levenshtein_k", "ta_sharded_pairs_levenshtein_exp", "ta_sharded_pairs_hamming",
     "ta_sharded_pairs_time_levenshtein_k", "ta_sharded_pairs_shards", "ta_sharded_pairs_free",
     "ta_sharded_haystack_upload", "ta_sharded_haystack_levenshtein_search", "ta_sharded_haystack_hamming_search",
@@ -155,6 +155,7 @@ def lib():
     sig("ta_levenshtein_k_batch_host", i32, [sp, sp, sz, u32, cp, vp])
     sig("ta_levenshtein_exp_batch_host", i32, [sp, sp, sz, cp, vp])
     sig("ta_hamming_batch_host", i32, [sp, sp, sz, vp])
+    sig("ta_levenshtein_trace_batch_host", i32, [sp, sp, sz, u32, cp, vp, vp, vp, sz])
     sig("ta_sharded_pairs_upload", i32, [sp, sp, sz, sz, vpp])
     sig("ta_sharded_pairs_levenshtein_k", i32, [vp, u32, cp, vp])
     sig("ta_sharded_pairs_levenshtein_exp", i32, [vp, cp, vp])

@@ -117,7 +117,7 @@ struct Worker {
     std::string init_err;
     hipStream_t st = nullptr;
     Ring up, down;
-    DevBuf buf[7];      // 0/1: a blob / offsets, 2/3: b blob / offsets, 4: results, 5: hits, 6: a haystack shard of a host-entry search
+    DevBuf buf[9];      // 0/1: a blob / offsets, 2/3: b blob / offsets, 4: results, 5: hits, 6: a haystack shard of a host-entry search, 7/8: packed scripts / run counts (host batch tracebacks)
 
     void post(std::function<void()> f) {
         { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(f)); }
@@ -383,12 +383,13 @@ static size_t chunk_end(const ta_strings *a, const ta_strings *b, size_t lo, siz
     return l;
 }
 
-enum PairOp { OP_LEV_K = 0, OP_LEV_EXP = 1, OP_HAMMING = 2 };
+enum PairOp { OP_LEV_K = 0, OP_LEV_EXP = 1, OP_HAMMING = 2, OP_TRACE = 3 };
 static int pair_op(PairOp op, const ta_strings *A, const ta_strings *B, size_t n, uint32_t k, const ta_edit_costs *costs, uint32_t *out_dev, hipStream_t st) {
     switch (op) {
         case OP_LEV_K: return ta_levenshtein_k_batch(A, B, n, k, costs, out_dev, st);
         case OP_LEV_EXP: return ta_levenshtein_exp_batch(A, B, n, costs, out_dev, st);
-        default: return ta_hamming_batch(A, B, n, out_dev, st);
+        case OP_HAMMING: return ta_hamming_batch(A, B, n, out_dev, st);
+        default: return TA_ERR_ARG;
     }
 }
 
@@ -408,8 +409,11 @@ static size_t pair_shards(const Pool &P, size_t n) {
     return use;
 }
 
-static int pairs_host(PairOp op, const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs, uint32_t *out) {
+// OP_TRACE: additionally packed (n x cap words, scripts right-aligned as ta_levenshtein_trace_batch_packed leaves them) and n_edits (n), host memory
+static int pairs_host(PairOp op, const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs, uint32_t *out,
+                      uint32_t *packed = nullptr, uint32_t *n_edits = nullptr, size_t cap = 0) {
     if (!host_strings_ok(a, n) || !host_strings_ok(b, n) || (!out && n) || n > 0xFFFFFFF0ull) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
+    if (op == OP_TRACE && n && (!packed || !n_edits || cap == 0 || cap > 0xFFFFFFFFull)) { set_last_error_msg("bad batch arguments"); return TA_ERR_ARG; }
     if (op != OP_HAMMING && (!costs || ta_edit_costs_new(costs->mismatch_cost, costs->gap_cost, costs->start_gap_cost, costs->has_transpose, costs->transpose_cost, nullptr) != TA_OK))
         return TA_ERR_BAD_COSTS;
     if (!device_ready()) return TA_ERR_HIP;
@@ -418,7 +422,8 @@ static int pairs_host(PairOp op, const ta_strings *a, const ta_strings *b, size_
     if (!P) return TA_ERR_HIP;
     const size_t devs_used = pair_shards(*P, n);
     const uint64_t chunk_bytes = tuning_size("TA_MULTI_CHUNK_BYTES", 64u << 20);
-    const size_t chunk_pairs = tuning_size("TA_MULTI_CHUNK_PAIRS", 1u << 20);
+    size_t chunk_pairs = tuning_size("TA_MULTI_CHUNK_PAIRS", 1u << 20);
+    if (op == OP_TRACE && chunk_pairs * cap * 4 > (256u << 20)) chunk_pairs = (256u << 20) / (cap * 4) ? (256u << 20) / (cap * 4) : 1;   // (a chunk's scripts: <= 256 MiB)
     const ta_edit_costs c = costs ? *costs : ta_edit_costs{1, 1, 0, 0, 0};
     // a device whose slice holds >= 16 MiB of strings gets two stagers (two contiguous half slices, two streams on the device): TA_MULTI_STAGERS=1 keeps one
     uint64_t total_bytes = 0;
@@ -440,7 +445,12 @@ static int pairs_host(PairOp op, const ta_strings *a, const ta_strings *b, size_
             if ((rc = stage_side(w, a, c_lo, c_hi, w.buf[0], w.buf[1], &A)) || (rc = stage_side(w, b, c_lo, c_hi, w.buf[2], w.buf[3], &B)) ||
                 (rc = w.buf[4].ensure(cnt * 4)))
                 return rc;
-            if ((rc = pair_op(op, &A, &B, cnt, k, &c, (uint32_t *)w.buf[4].p, w.st))) return rc;
+            if (op == OP_TRACE) {
+                // the scripts as packed runs (4 bytes each): cap words per pair come back -- words in front of a script are whatever the buffer held
+                if ((rc = w.buf[7].ensure(cnt * cap * 4)) || (rc = w.buf[8].ensure(cnt * 4))) return rc;
+                if ((rc = ta_levenshtein_trace_batch_packed(&A, &B, cnt, k, &c, (uint32_t *)w.buf[4].p, (uint32_t *)w.buf[7].p, (uint32_t *)w.buf[8].p, cap, w.st))) return rc;
+                if ((rc = download(w, packed + c_lo * cap, w.buf[7].p, cnt * cap * 4)) || (rc = download(w, n_edits + c_lo, w.buf[8].p, cnt * 4))) return rc;
+            } else if ((rc = pair_op(op, &A, &B, cnt, k, &c, (uint32_t *)w.buf[4].p, w.st))) return rc;
             if ((rc = download(w, out + c_lo, w.buf[4].p, cnt * 4))) return rc;
             c_lo = c_hi;
         }
@@ -696,6 +706,10 @@ int ta_levenshtein_exp_batch_host(const ta_strings *a, const ta_strings *b, size
 }
 int ta_hamming_batch_host(const ta_strings *a, const ta_strings *b, size_t n, uint32_t *out) {
     return pairs_host(OP_HAMMING, a, b, n, 0, nullptr, out);
+}
+int ta_levenshtein_trace_batch_host(const ta_strings *a, const ta_strings *b, size_t n, uint32_t k, const ta_edit_costs *costs,
+                                    uint32_t *out, uint32_t *packed, uint32_t *n_edits, size_t cap) {
+    return pairs_host(OP_TRACE, a, b, n, k, costs, out, packed, n_edits, cap);
 }
 
 /* ---- a pair batch kept RESIDENT, sharded over the device set */

@@ -86,6 +86,36 @@ def hamming_batch_host(a, b):
     return out
 
 
+_EDIT_NAMES = ("Match", "Mismatch", "AGap", "BGap", "Transpose")
+
+
+def levenshtein_trace_batch_host(a, b, k, costs=LEVENSHTEIN_COSTS, cap=None, as_lists=True):
+    """[levenshtein_simd_k_with_opts(a_i, b_i, k, True, costs)] over the device set: -> (distances uint32 (0xFFFFFFFF = None), scripts) with
+    scripts[i] = [(edit name, count), ...] front to back ([] for None); as_lists=False: the raw (n, cap) packed words and the run counts
+    instead (word = (edit type << 29) | count, a script in the LAST min(n_edits, cap) words of its row)."""
+    a, b = _pairs(a, b)
+    c = _costs(costs)._c()
+    if cap is None:
+        longest = 1
+        for side in (a, b):
+            longest = max(longest, int(np.diff(side.off).max()) if side.off is not None and side.n else int(side.c.len))
+        cap = int(min(2 * (int(k) & 0xFFFFFFFF) + 1, 2 * longest + 2))
+    out = np.empty(a.n, dtype=np.uint32)
+    packed = np.zeros((a.n, cap), dtype=np.uint32)
+    n_edits = np.zeros(a.n, dtype=np.uint32)
+    _raise(_n.lib().ta_levenshtein_trace_batch_host(_C.byref(a.c), _C.byref(b.c), a.n, int(k) & 0xFFFFFFFF, _C.byref(c), out.ctypes.data,
+                                                    packed.ctypes.data, n_edits.ctypes.data, cap))
+    if not as_lists:
+        return out, packed, n_edits
+    scripts = []
+    for i in range(a.n):
+        have = min(int(n_edits[i]), cap)
+        if int(n_edits[i]) > cap:
+            raise ValueError("levenshtein_trace_batch_host: pair %d has a script of %d runs, cap = %d" % (i, int(n_edits[i]), cap))
+        scripts.append([(_EDIT_NAMES[int(w) >> 29], int(w) & 0x1FFFFFFF) for w in packed[i, cap - have:]])
+    return out, scripts
+
+
 class ShardedPairs:
     """A pair batch uploaded once and kept resident, sharded over the device set."""
 
