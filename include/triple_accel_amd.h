@@ -14,7 +14,9 @@
  *     src/levenshtein.rs:734-757).
  *   - `*_dev` / `*_batch` functions take DEVICE (HBM) pointers and a hipStream_t passed as
  *     void*; they enqueue work and return without synchronising unless stated.  The plain
- *     functions take HOST pointers, run on the current HIP device and synchronise.
+ *     functions take HOST pointers, run on the current HIP device and synchronise -- except
+ *     where the DEVICE SET takes over (ta_set_devices below: host batches, the queue, searches
+ *     over big haystacks are partitioned over every device of the set inside the library).
  *   - Device string blobs must be readable for TA_BLOB_SLACK bytes past their last byte
  *     (kernels fetch 16-byte pieces).
  *   - There is NO CPU fallback: with no HIP device every compute entry point returns
